@@ -1,0 +1,226 @@
+"""CPU tests of the oracle itself (no GPU): the restated Open3D algorithms against brute force,
+analytic known answers and the invariants of SURVEY.md section 4.  The reference ships no golden
+vectors (parity unpinned), so these self-checks are what anchors the oracle."""
+import numpy as np
+import pytest
+
+
+def _cloud(n, seed, dim=3, scale=1.0):
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-scale, scale, size=(n, 3)).astype(np.float32)
+    if dim == 2:
+        p[:, 2] = 0
+    return p
+
+
+@pytest.mark.parametrize("n,m,radius,dim", [(500, 300, 0.25, 3), (800, 800, 0.1, 2), (64, 1, 3.0, 3), (1, 50, 0.5, 3)])
+@pytest.mark.parametrize("ignore", [False, True])
+def test_hash_search_equals_bruteforce(oracle, n, m, radius, dim, ignore):
+    pts = _cloud(n, 1, dim)
+    qs = pts[:m].copy() if ignore and m <= n else _cloud(m, 2, dim)
+    i0, r0, d0 = oracle.fixed_radius_search(pts, qs, radius, ignore)
+    i1, r1, d1 = oracle.fixed_radius_search(pts, qs, radius, ignore, bruteforce=True)
+    assert r0.dtype == np.int64 and i0.dtype == np.int32 and d0.dtype == np.float32
+    np.testing.assert_array_equal(r0, r1)
+    a, da = oracle.canonical_rows(i0, r0, d0)
+    b, db = oracle.canonical_rows(i1, r1, d1)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(da, db)  # squared L2, bit-exact (same un-fused arithmetic)
+
+
+def test_search_inclusive_radius_and_ignore_by_coordinates(oracle):
+    # points exactly at distance R are neighbours (<=); duplicates of the query are dropped by
+    # coordinate equality, not by index (SURVEY.md section 4 invariant 1)
+    pts = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0], [0, 0, 0], [0.5000001, 0, 0], [1, 1, 1]], np.float32)
+    qs = np.array([[0, 0, 0]], np.float32)
+    idx, rs, d = oracle.fixed_radius_search(pts, qs, 0.5, False)
+    assert sorted(idx.tolist()) == [0, 1, 2, 3]
+    idx, rs, d = oracle.fixed_radius_search(pts, qs, 0.5, True)
+    assert sorted(idx.tolist()) == [1, 2]
+    np.testing.assert_array_equal(np.sort(d), np.float32([0.25, 0.25]))
+
+
+def test_search_empty_inputs(oracle):
+    idx, rs, d = oracle.fixed_radius_search(np.zeros((0, 3), np.float32), _cloud(5, 0), 0.3)
+    assert idx.size == 0 and rs.tolist() == [0] * 6
+    idx, rs, d = oracle.fixed_radius_search(_cloud(5, 0), np.zeros((0, 3), np.float32), 0.3)
+    assert idx.size == 0 and rs.tolist() == [0]
+
+
+def test_windows_known_values(oracle):
+    q = np.float32([0.0, 0.25, 1.0, 1.5])
+    np.testing.assert_allclose(oracle.window("poly6", q), [1.0, 0.421875, 0.0, 0.0], atol=1e-7)
+    np.testing.assert_allclose(oracle.window("peak", q)[:3], [1.0, 0.25, 0.0], atol=1e-7)
+    np.testing.assert_allclose(oracle.window("linear", q)[:3], [1.0, 0.5, 0.0], atol=1e-7)
+    np.testing.assert_allclose(oracle.window("cubic", q)[:3], [4 / 3, 4 / 3 * 0.25, 0.0], atol=1e-6)
+
+
+def test_mapping_on_axis_is_identity(oracle):
+    # a neighbour on a coordinate axis: the volume preserving map is the identity along that axis,
+    # so coordinate = (t/2 + 0.5) * (size-1)  (SURVEY.md section 8c "analytic cases")
+    ext = 2.0  # radius 1
+    t = np.float32([-1, -0.5, 0, 0.3, 1])
+    for axis in range(3):
+        rel = np.zeros((5, 3), np.float32)
+        rel[:, axis] = t
+        c = oracle.filter_coordinates(rel, ext, [4, 4, 4])
+        expect = (t / 2 + 0.5) * 3
+        np.testing.assert_allclose(c[:, axis], expect, atol=1e-6)
+        for other in range(3):
+            if other != axis:
+                np.testing.assert_allclose(c[:, other], 1.5, atol=1e-6)
+
+
+def test_mapping_ball_fills_cube(oracle):
+    # points on the unit sphere land on the cube surface (max |coord| = 0.5 -> 0 or size-1)
+    rng = np.random.default_rng(0)
+    v = rng.normal(size=(2000, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    c = oracle.filter_coordinates(v, 2.0, [4, 4, 4]) / 3.0 - 0.5
+    np.testing.assert_allclose(np.abs(c).max(axis=1), 0.5, atol=2e-6)
+    # interior points stay inside, and the map is odd: L(-r) = -L(r)
+    r = (v * rng.uniform(0, 1, size=(2000, 1))).astype(np.float32)
+    c1 = oracle.filter_coordinates(r, 2.0, [4, 4, 4]) / 3.0 - 0.5
+    c2 = oracle.filter_coordinates(-r, 2.0, [4, 4, 4]) / 3.0 - 0.5
+    assert np.abs(c1).max() <= 0.5 + 1e-6
+    np.testing.assert_allclose(c1, -c2, atol=1e-6)
+
+
+def test_mapping_volume_preserving(oracle):
+    # uniform samples in the ball map to (statistically) uniform samples in the cube
+    rng = np.random.default_rng(1)
+    p = rng.uniform(-1, 1, size=(400000, 3)).astype(np.float32)
+    p = p[(p ** 2).sum(1) <= 1]
+    c = oracle.filter_coordinates(p, 2.0, [2, 2, 2])  # size-1 = 1 -> coords in [0,1]
+    hist, _ = np.histogramdd(c, bins=(4, 4, 4), range=[(0, 1)] * 3)
+    frac = hist / hist.sum()
+    np.testing.assert_allclose(frac, 1 / 64, rtol=0.05)
+
+
+def _conv_case(oracle, seed=0, n=300, m=200, cin=5, cout=7, ks=(4, 4, 4), radius=0.35, dim=3):
+    rng = np.random.default_rng(seed)
+    inp = _cloud(n, seed, dim)
+    out = _cloud(m, seed + 100, dim)
+    feat = rng.normal(size=(n, cin)).astype(np.float32)
+    filt = rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32)
+    idx, rs, d = oracle.fixed_radius_search(inp, out, radius)
+    imp = oracle.window("poly6", d / np.float32(radius * radius))
+    return inp, out, feat, filt, idx, rs, imp, np.float32(2 * radius)
+
+
+def test_cconv_linearity_and_empty_rows(oracle):
+    inp, out, feat, filt, _, _, _, ext = _conv_case(oracle)
+    out = np.concatenate([out, np.float32([[5, 5, 5], [-7, 0, 0]])])  # two outputs with no neighbours
+    idx, rs, d = oracle.fixed_radius_search(inp, out, ext / 2)
+    imp = oracle.window("poly6", d / np.float32(ext / 2) ** 2)
+    f = lambda F, W: oracle.continuous_conv(W, out, ext, inp, F, idx, rs, imp)
+    y = f(feat, filt)
+    np.testing.assert_allclose(f(2 * feat, filt), 2 * y, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(f(feat, 3 * filt), 3 * y, rtol=1e-5, atol=1e-5)
+    empty = np.diff(rs) == 0
+    assert empty.any()
+    assert not y[empty].any()  # normalize=False: rows without neighbours are exactly zero
+
+
+def test_cconv_constant_filter_is_windowed_sum(oracle):
+    # SURVEY section 4 invariant 3: constant filter => out = (sum_j a_ij f_j) @ C, independent of the mapping
+    inp, out, feat, filt, idx, rs, imp, ext = _conv_case(oracle, seed=3)
+    C = np.random.default_rng(5).normal(size=(feat.shape[1], 7)).astype(np.float32)
+    filt = np.broadcast_to(C, filt.shape).copy()
+    y = oracle.continuous_conv(filt, out, ext, inp, feat, idx, rs, imp)
+    row = np.repeat(np.arange(len(rs) - 1), np.diff(rs))
+    s = np.zeros((len(rs) - 1, feat.shape[1]), np.float64)
+    np.add.at(s, row, imp[:, None].astype(np.float64) * feat[idx])
+    np.testing.assert_allclose(y, s @ C, rtol=2e-5, atol=2e-5)
+
+
+def test_cconv_single_neighbour_known_answer(oracle):
+    # one neighbour on the +x axis at t*R: out = a * f * lerp(filter row) computed by hand
+    ks = (1, 1, 4)
+    filt = np.arange(4 * 2 * 3, dtype=np.float32).reshape(1, 1, 4, 2, 3)
+    inp = np.float32([[0.3, 0, 0]])
+    out = np.float32([[0, 0, 0]])
+    feat = np.float32([[2.0, -1.0]])
+    idx, rs = np.int32([0]), np.int64([0, 1])
+    imp = np.float32([0.5])
+    y = oracle.continuous_conv(filt, out, 2.0, inp, feat, idx, rs, imp)
+    x = (0.3 / 2 + 0.5) * 3  # 1.95 -> cells 1 and 2, weights 0.05 / 0.95
+    g = 0.05 * filt[0, 0, 1] + 0.95 * filt[0, 0, 2]
+    np.testing.assert_allclose(y[0], 0.5 * (feat[0] @ g), rtol=1e-5)
+
+
+def test_cconv_f32_close_to_f64(oracle):
+    inp, out, feat, filt, idx, rs, imp, ext = _conv_case(oracle, seed=7, cin=16, cout=8)
+    y32 = oracle.continuous_conv(filt, out, ext, inp, feat, idx, rs, imp)
+    y64 = oracle.continuous_conv(filt, out, ext, inp, feat, idx, rs, imp, f64=True)
+    scale = np.abs(y64).max()
+    assert np.abs(y32 - y64).max() <= 2e-5 * scale
+
+
+def test_cconv_2d_degeneracy(oracle):
+    # kernel [1,H,W] with z = 0: result independent of anything along z; filter z-size 1
+    inp, out, feat, filt, idx, rs, imp, ext = _conv_case(oracle, seed=9, ks=(1, 8, 8), dim=2, radius=0.2, n=600, m=400)
+    y = oracle.continuous_conv(filt, out, ext, inp, feat, idx, rs, imp)
+    assert np.isfinite(y).all() and np.abs(y).max() > 0
+    # embedding the same 2-D filter as the z-constant 3-D filter [2,H,W] gives the same answer
+    filt3 = np.concatenate([filt, filt], axis=0)
+    y3 = oracle.continuous_conv(filt3, out, ext, inp, feat, idx, rs, imp)
+    np.testing.assert_allclose(y, y3, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("ks,sym_axis,dim", [((6, 6, 6), 1, 3), ((1, 8, 8), 1, 2), ((4, 4, 4), 2, 3), ((4, 4, 4), 0, 3)])
+def test_ascc_momentum_and_fusion_identity(oracle, ks, sym_axis, dim):
+    # SURVEY section 4 invariants 4 + 5
+    rng = np.random.default_rng(11)
+    n, cin, cout, radius = 400, 6, 3, 0.3
+    pos = _cloud(n, 21, dim)
+    feat = np.maximum(rng.normal(size=(n, cin)), 0).astype(np.float32)
+    half = list(ks)
+    half[sym_axis] //= 2
+    k = rng.uniform(-1, 1, size=(*half, cin, cout)).astype(np.float32)
+    conv = oracle.ContinuousConvRef(k, window_function="peak", ignore_query_points=True, symmetric=True,
+                                    sym_axis=sym_axis)
+    y = conv(feat, pos, pos, 2 * radius)
+    idx, rs, d = conv.nns
+    assert (np.diff(rs) > 0).mean() > 0.9
+    terms = np.abs(y).sum(axis=0)
+    assert np.all(np.abs(y.sum(axis=0)) <= 2e-5 * terms + 1e-6)  # sum_i out_i = 0
+    # fused form: one CConv over pair features (f_j + f_i) with the mirrored kernel
+    full = oracle.mirror_kernel(k, sym_axis)
+    imp = oracle.window("peak", d / np.float32(radius * radius))
+    row = np.repeat(np.arange(n), np.diff(rs))
+    # emulate pair features by building a per-pair point set
+    pair_pos = pos[idx]
+    pair_feat = feat[idx] + feat[row]
+    pair_idx = np.arange(len(idx), dtype=np.int32)
+    y2 = oracle.continuous_conv(full, pos, 2 * radius, pair_pos, pair_feat, pair_idx, rs, imp)
+    np.testing.assert_allclose(y, y2, rtol=1e-4, atol=1e-5 * np.abs(y).max())
+
+
+def test_reduce_subarrays_sum(oracle):
+    v = np.arange(10, dtype=np.float32)
+    rs = np.int64([0, 3, 3, 10])
+    np.testing.assert_array_equal(oracle.reduce_subarrays_sum(v, rs), [3, 0, 42])
+
+
+def test_grid_pos_properties(oracle):
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(0, 1, size=(500, 3)).astype(np.float32)
+    vs = np.float32([0.1, 0.1, 0.1])
+    g = oracle.grid_pos(pos, vs, centralize=True)
+    # unique lattice points, every particle has its 8 surrounding corners present
+    center = pos.mean(axis=0, dtype=np.float32)
+    lat = np.rint((g - center) / vs).astype(np.int64)
+    assert len(np.unique(lat, axis=0)) == len(lat)
+    s = set(map(tuple, lat))
+    cell = np.floor((pos - center) / vs).astype(np.int64)
+    inner = np.abs((pos - center) / vs - np.rint((pos - center) / vs)).min(axis=1) > 0.11
+    for c in cell[inner][:100]:
+        for o in np.ndindex(2, 2, 2):
+            assert tuple(c + np.array(o)) in s
+    # 2-D: collapsed z axis
+    pos2 = pos.copy()
+    pos2[:, 2] = 0
+    g2 = oracle.grid_pos(pos2, np.float32([0.1, 0.1, 0.0]), centralize=True)
+    assert np.all(g2[:, 2] == 0)
+    assert len(g2) < len(g)
