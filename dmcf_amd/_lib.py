@@ -1,0 +1,100 @@
+"""ctypes binding of libdmcf_hip.so (the C ABI declared in include/dmcf_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libdmcf_hip.so")
+_lib = None
+
+
+class DmcfError(RuntimeError):
+    pass
+
+
+class CconvArgs(ctypes.Structure):
+    """struct dmcf_cconv_args (include/dmcf_hip.h)."""
+    _fields_ = [
+        ("filters", ctypes.c_void_p),
+        ("filter_dims", ctypes.c_int32 * 5),
+        ("sym_axis", ctypes.c_int32),
+        ("out_positions", ctypes.c_void_p),
+        ("n_out", ctypes.c_int64),
+        ("inp_positions", ctypes.c_void_p),
+        ("n_inp", ctypes.c_int64),
+        ("inp_features", ctypes.c_void_p),
+        ("inp_importance", ctypes.c_void_p),
+        ("neighbors_index", ctypes.c_void_p),
+        ("neighbors_row_splits", ctypes.c_void_p),
+        ("neighbors_value", ctypes.c_void_p),
+        ("extent", ctypes.c_float),
+        ("window_fac", ctypes.c_float),
+        ("window", ctypes.c_int32),
+        ("coordinate_mapping", ctypes.c_int32),
+        ("interpolation", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+        ("bias", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+    ]
+
+
+# names every entry point include/dmcf_hip.h declares (tests/test_abi.py cross-checks against the header)
+SYMBOLS = [
+    "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
+    "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write",
+    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward",
+    "dmcf_reduce_subarrays_sum",
+]
+
+
+def build(force=False):
+    """Compile dmcf_amd/csrc/*.hip for gfx950 into dmcf_amd/libdmcf_hip.so (hipcc cross-compiles without a GPU)."""
+    csrc = os.path.join(_PKG, "csrc")
+    args = ["make", "-C", csrc, "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmcfError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    L.dmcf_version.restype = c.c_int
+    L.dmcf_error_string.restype = c.c_char_p
+    L.dmcf_error_string.argtypes = [c.c_int]
+    L.dmcf_last_hip_error.restype = c.c_int
+    L.dmcf_frs_workspace_bytes.restype = c.c_size_t
+    L.dmcf_frs_workspace_bytes.argtypes = [c.c_int64, c.c_int64]
+    L.dmcf_frs_build.restype = c.c_int
+    L.dmcf_frs_build.argtypes = [c.c_void_p, c.c_int64, c.c_float, c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_frs_count.restype = c.c_int
+    L.dmcf_frs_count.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_void_p, c.c_size_t,
+                                 c.c_void_p, c.c_void_p]
+    L.dmcf_frs_write.restype = c.c_int
+    L.dmcf_frs_write.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_void_p, c.c_size_t,
+                                 c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+    L.dmcf_cconv_workspace_bytes.restype = c.c_size_t
+    L.dmcf_cconv_workspace_bytes.argtypes = [c.POINTER(CconvArgs)]
+    L.dmcf_cconv_forward.restype = c.c_int
+    L.dmcf_cconv_forward.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_reduce_subarrays_sum.restype = c.c_int
+    L.dmcf_reduce_subarrays_sum.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise DmcfError(f"{what}: {L.dmcf_error_string(rc).decode()} (code {rc}, hip error {L.dmcf_last_hip_error()})")

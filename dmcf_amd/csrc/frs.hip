@@ -1,0 +1,367 @@
+// Fixed-radius neighbour search for gfx950: cell-sorted uniform grid + one wavefront per query.
+//
+// Replaces ml3d.layers.FixedRadiusSearch (reference call sites utils/convolutions.py:207-210,354-358,
+// utils/tools/losses.py:296-298).  The Open3D structure behind that layer (spatial hash with ~64
+// points per bin, 8 corner bins per query) is NOT what is built here; only its result contract is
+// kept (see include/dmcf_hip.h).  MI355X-first choices:
+//   * cell edge ~= radius (27-cell neighbourhood, ~15 % of candidates are hits, vs ~6.5 % for the
+//     reference's 2R cells) and points re-ordered by cell into one float4 {x,y,z,index} array, so a
+//     query reads <= 9 contiguous x-runs with coalesced 16-B loads instead of chasing indices;
+//   * one 64-lane wavefront per query: lanes stride the flattened candidate list, hits are compacted
+//     with a ballot + mbcnt prefix (no atomics, no LDS), rows come out in a deterministic order;
+//   * everything that sizes the grid (bounding box, cell edge, dims) is computed on the device into a
+//     header inside the workspace, so the build needs no host round trip.
+#include "common.h"
+
+namespace dmcf {
+
+struct FrsHeader {
+    float origin[3];
+    float inv_cell[3];
+    int32_t dims[3];
+    int32_t ncells;
+    uint32_t bb_min[3];  // order-preserving uint encoding of floats
+    uint32_t bb_max[3];
+    float radius;
+    int32_t n_points;
+    int32_t pad[14];
+};
+static_assert(sizeof(FrsHeader) == 128, "header layout");
+
+struct FrsLayout {
+    int64_t n, m, table;
+    size_t off_header, off_cell_start, off_cell_fill, off_point_cell, off_tmp_idx, off_sorted, off_counts,
+        off_scan, scan_bytes, total;
+};
+
+static int64_t frs_table_size(int64_t n) {
+    int64_t t = 4 * n;
+    if (t < 4096) t = 4096;
+    if (t > ((int64_t)1 << 26)) t = (int64_t)1 << 26;
+    return t;
+}
+
+static FrsLayout frs_layout(int64_t n, int64_t m) {
+    FrsLayout L;
+    L.n = n;
+    L.m = m;
+    L.table = frs_table_size(n);
+    size_t off = 0;
+    L.off_header = off;        off += align_up(sizeof(FrsHeader), 256);
+    L.off_cell_start = off;    off += align_up((size_t)(L.table + 1) * 4, 256);
+    L.off_cell_fill = off;     off += align_up((size_t)(L.table + 1) * 4, 256);
+    L.off_point_cell = off;    off += align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+    L.off_tmp_idx = off;       off += align_up((size_t)(n > 0 ? n : 1) * 4, 256);
+    L.off_sorted = off;        off += align_up((size_t)(n > 0 ? n : 1) * 16, 256);
+    L.off_counts = off;        off += align_up((size_t)(m > 0 ? m : 1) * 4, 256);
+    const int64_t scan_n = (L.table + 1) > m ? (L.table + 1) : m;
+    L.scan_bytes = scan_tmp_bytes(scan_n);
+    L.off_scan = off;          off += L.scan_bytes;
+    L.total = off;
+    return L;
+}
+
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+__global__ void frs_init_header(FrsHeader* h, float radius, int32_t n) {
+    if (threadIdx.x == 0) {
+        for (int a = 0; a < 3; ++a) {
+            h->bb_min[a] = 0xffffffffu;
+            h->bb_max[a] = 0u;
+        }
+        h->radius = radius;
+        h->n_points = n;
+    }
+}
+
+__global__ __launch_bounds__(256) void frs_bbox(const float* __restrict__ pts, int64_t n, FrsHeader* h) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, kWave));
+        }
+    }
+    if (lane_id() == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            atomicMin(&h->bb_min[a], f2ord(mn[a]));
+            atomicMax(&h->bb_max[a], f2ord(mx[a]));
+        }
+    }
+}
+
+// one thread: choose the cell edge (>= 1.001 R so that [q-R, q+R] spans at most 3 cells) and coarsen
+// it until the dense grid fits the cell table.  Coarser cells only add candidates, never lose any.
+__global__ void frs_finish_header(FrsHeader* h, int64_t table) {
+    if (threadIdx.x != 0) return;
+    float lo[3], ext[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = ord2f(h->bb_min[a]);
+        const float hi = ord2f(h->bb_max[a]);
+        ext[a] = hi - lo[a];
+        if (!(ext[a] >= 0.0f) || !isfinite(ext[a])) ext[a] = 0.0f;  // empty / non-finite input
+        if (!isfinite(lo[a])) lo[a] = 0.0f;
+    }
+    float cell = h->radius * 1.001f;
+    int32_t d[3];
+    for (int it = 0; it < 64; ++it) {
+        double prod = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            const double cnt = floor((double)ext[a] / (double)cell) + 1.0;
+            d[a] = cnt > 2.0e9 ? 2000000000 : (int32_t)cnt;
+            prod *= cnt;
+        }
+        if (prod <= (double)table) break;
+        const float grow = (float)cbrt(prod / (double)table) * 1.02f;
+        cell *= grow > 1.05f ? grow : 1.05f;
+    }
+    for (int a = 0; a < 3; ++a) {
+        h->origin[a] = lo[a];
+        h->inv_cell[a] = 1.0f / cell;
+        h->dims[a] = d[a];
+    }
+    h->ncells = d[0] * d[1] * d[2];
+}
+
+// cell coordinate along one axis; the SAME function is used for points and for the ends of a query's
+// range, so monotonicity of floor((x - o) * inv) guarantees every in-range point is visited.
+__device__ __forceinline__ int cell_coord(float x, float origin, float inv, int dim) {
+    float c = floorf((x - origin) * inv);
+    c = fminf(fmaxf(c, -1.0f), (float)dim);  // also maps NaN to -1
+    return (int)c;
+}
+
+__global__ __launch_bounds__(256) void frs_count_cells(const float* __restrict__ pts, int64_t n,
+                                                       const FrsHeader* __restrict__ h,
+                                                       int32_t* __restrict__ point_cell,
+                                                       uint32_t* __restrict__ cell_count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        c[a] = cell_coord(pts[3 * i + a], h->origin[a], h->inv_cell[a], h->dims[a]);
+        c[a] = min(max(c[a], 0), h->dims[a] - 1);
+    }
+    const int32_t cell = (c[2] * h->dims[1] + c[1]) * h->dims[0] + c[0];
+    point_cell[i] = cell;
+    atomicAdd(&cell_count[cell], 1u);
+}
+
+__global__ __launch_bounds__(256) void frs_scatter(int64_t n, const int32_t* __restrict__ point_cell,
+                                                   const uint32_t* __restrict__ cell_start,
+                                                   uint32_t* __restrict__ cell_fill, int32_t* __restrict__ tmp_idx) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t cell = point_cell[i];
+    const uint32_t slot = cell_start[cell] + atomicAdd(&cell_fill[cell], 1u);
+    tmp_idx[slot] = (int32_t)i;
+}
+
+// the atomic scatter leaves each cell's members in arbitrary order; rank every point inside its cell
+// by index so the sorted array (and therefore every CSR row) is deterministic.
+__global__ __launch_bounds__(256) void frs_rank_and_place(const float* __restrict__ pts, int64_t n,
+                                                          const int32_t* __restrict__ point_cell,
+                                                          const uint32_t* __restrict__ cell_start,
+                                                          const int32_t* __restrict__ tmp_idx,
+                                                          float4* __restrict__ sorted) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t cell = point_cell[i];
+    const uint32_t b = cell_start[cell], e = cell_start[cell + 1];
+    uint32_t rank = 0;
+    for (uint32_t s = b; s < e; ++s) rank += (tmp_idx[s] < (int32_t)i) ? 1u : 0u;
+    sorted[b + rank] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int32_t)i));
+}
+
+// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queries, int64_t m,
+                                                 const FrsHeader* __restrict__ h,
+                                                 const uint32_t* __restrict__ cell_start,
+                                                 const float4* __restrict__ sorted, float radius, int flags,
+                                                 int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
+                                                 int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist) {
+    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= m) return;  // whole wave leaves
+    const int lane = lane_id();
+    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    const float q[3] = {qx, qy, qz};
+    const float r2 = __fmul_rn(radius, radius);
+    int lo[3], hi[3];
+    bool empty = h->ncells <= 0 || h->n_points <= 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        // slack >> float rounding of (q +- R) and of the distance test; keeps the candidate set a superset
+        const float slack = 1e-4f * radius + 4.8e-7f * (fabsf(q[a]) + radius);
+        lo[a] = max(cell_coord(q[a] - radius - slack, h->origin[a], h->inv_cell[a], h->dims[a]), 0);
+        hi[a] = min(cell_coord(q[a] + radius + slack, h->origin[a], h->inv_cell[a], h->dims[a]), h->dims[a] - 1);
+        empty |= lo[a] > hi[a];
+    }
+    int32_t cnt = 0;
+    if (!empty) {
+        const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
+        const int64_t out_base = WRITE ? row_splits[qi] : 0;
+        const bool ignore = (flags & DMCF_FRS_IGNORE_QUERY_POINT) != 0;
+        // (y,z) rows are taken 64 at a time (9 at most when the cell edge is ~R; more only for coarsened grids)
+        for (int row0 = 0; row0 < ny * nz; row0 += kWave) {
+            const int r = row0 + lane;
+            int32_t start = 0, len = 0;
+            if (r < ny * nz) {
+                const int cy = lo[1] + r % ny, cz = lo[2] + r / ny;
+                const int32_t base = (cz * h->dims[1] + cy) * h->dims[0];
+                start = (int32_t)cell_start[base + lo[0]];
+                len = (int32_t)cell_start[base + hi[0] + 1] - start;
+            }
+            // inclusive scan of run lengths across lanes
+            int32_t incl = len;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int32_t o = __shfl_up(incl, d, kWave);
+                if (lane >= d) incl += o;
+            }
+            const int32_t total = __shfl(incl, kWave - 1, kWave);
+            const int32_t rel = start - (incl - len);  // candidate c of this run sits at sorted[rel + flat]
+            const int nrows = min(ny * nz - row0, kWave);
+            for (int32_t f0 = 0; f0 < total; f0 += kWave) {
+                const int32_t f = f0 + lane;
+                // which run does flat index f fall into: count runs whose inclusive end is <= f
+                int run = 0;
+                for (int k = 0; k < nrows - 1; ++k) run += (f >= __builtin_amdgcn_readlane(incl, k)) ? 1 : 0;
+                const int32_t src = __shfl(rel, run, kWave) + f;
+                bool hit = false;
+                float d2 = 0.0f;
+                int32_t pidx = 0;
+                if (f < total) {
+                    const float4 p = sorted[src];
+                    d2 = dist2_unfused(p.x, p.y, p.z, qx, qy, qz);
+                    hit = d2 <= r2;
+                    if (ignore && p.x == qx && p.y == qy && p.z == qz) hit = false;
+                    pidx = __float_as_int(p.w);
+                }
+                const unsigned long long mask = __ballot(hit);
+                if (WRITE && hit) {
+                    const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                 __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    const int64_t o = out_base + cnt + before;
+                    nbr_index[o] = pidx;
+                    if (nbr_dist) nbr_dist[o] = d2;
+                }
+                cnt += __popcll(mask);
+            }
+        }
+    }
+    if (!WRITE && lane == 0) counts[qi] = cnt;
+}
+
+}  // namespace dmcf
+
+using namespace dmcf;
+
+extern "C" {
+
+size_t dmcf_frs_workspace_bytes(int64_t n_points, int64_t n_queries) {
+    if (n_points < 0 || n_queries < 0) return 0;
+    return frs_layout(n_points, n_queries).total;
+}
+
+int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace, size_t workspace_bytes,
+                   dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || n > 0x7fffffff || !workspace || !(radius > 0.0f) || (n > 0 && !points)) return DMCF_EINVAL;
+    if (((uintptr_t)workspace & 255) != 0) return DMCF_EINVAL;
+    // the layout does not depend on the number of queries up to off_counts; validate with m = 0
+    const FrsLayout L = frs_layout(n, 0);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    char* ws = (char*)workspace;
+    FrsHeader* h = (FrsHeader*)(ws + L.off_header);
+    uint32_t* cell_start = (uint32_t*)(ws + L.off_cell_start);
+    uint32_t* cell_fill = (uint32_t*)(ws + L.off_cell_fill);
+    int32_t* point_cell = (int32_t*)(ws + L.off_point_cell);
+    int32_t* tmp_idx = (int32_t*)(ws + L.off_tmp_idx);
+    float4* sorted = (float4*)(ws + L.off_sorted);
+
+    hipLaunchKernelGGL(frs_init_header, dim3(1), dim3(64), 0, stream, h, radius, (int32_t)n);
+    if (n > 0) {
+        const unsigned g = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(frs_bbox, dim3(g < 1024u ? g : 1024u), dim3(256), 0, stream, points, n, h);
+    }
+    hipLaunchKernelGGL(frs_finish_header, dim3(1), dim3(64), 0, stream, h, L.table);
+    // cell_fill doubles as the histogram: count -> scan into cell_start -> clear -> scatter cursors
+    if (hipMemsetAsync(cell_fill, 0, (size_t)(L.table + 1) * 4, stream) != hipSuccess) return DMCF_ELAUNCH;
+    if (n > 0) {
+        const unsigned g = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(frs_count_cells, dim3(g), dim3(256), 0, stream, points, n, h, point_cell, cell_fill);
+    }
+    // the scan scratch sits after the (query-count dependent) counts array; during the build nothing
+    // else lives there, so use the tail of the workspace the caller actually gave us
+    const size_t scan_need = scan_tmp_bytes(L.table + 1);
+    if (workspace_bytes < L.off_counts + scan_need) return DMCF_EWORKSPACE;
+    int rc = scan_exclusive_u32(cell_fill, cell_start, L.table + 1, ws + workspace_bytes - scan_need, scan_need, stream);
+    if (rc != DMCF_OK) return rc;
+    if (hipMemsetAsync(cell_fill, 0, (size_t)(L.table + 1) * 4, stream) != hipSuccess) return DMCF_ELAUNCH;
+    if (n > 0) {
+        const unsigned g = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(frs_scatter, dim3(g), dim3(256), 0, stream, n, point_cell, cell_start, cell_fill, tmp_idx);
+        hipLaunchKernelGGL(frs_rank_and_place, dim3(g), dim3(256), 0, stream, points, n, point_cell, cell_start,
+                           tmp_idx, sorted);
+    }
+    return check_launch();
+}
+
+int dmcf_frs_count(const float* queries, int64_t m, int64_t n, float radius, int flags, void* workspace,
+                   size_t workspace_bytes, int64_t* row_splits, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_splits || (m > 0 && !queries)) return DMCF_EINVAL;
+    const FrsLayout L = frs_layout(n, m);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    char* ws = (char*)workspace;
+    const FrsHeader* h = (const FrsHeader*)(ws + L.off_header);
+    const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
+    const float4* sorted = (const float4*)(ws + L.off_sorted);
+    int32_t* counts = (int32_t*)(ws + L.off_counts);
+    if (m > 0) {
+        const unsigned g = (unsigned)((m + 3) / 4);
+        hipLaunchKernelGGL((frs_query<false>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted,
+                           radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+    }
+    return scan_counts_to_row_splits(counts, row_splits, m, ws + L.off_scan, L.scan_bytes, stream);
+}
+
+int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int flags, const void* workspace,
+                   size_t workspace_bytes, const int64_t* row_splits, int32_t* neighbors_index,
+                   float* neighbors_distance, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_splits || (m > 0 && !queries)) return DMCF_EINVAL;
+    if (m == 0) return DMCF_OK;
+    if (!neighbors_index) return DMCF_EINVAL;
+    const FrsLayout L = frs_layout(n, m);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    const char* ws = (const char*)workspace;
+    const FrsHeader* h = (const FrsHeader*)(ws + L.off_header);
+    const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
+    const float4* sorted = (const float4*)(ws + L.off_sorted);
+    const unsigned g = (unsigned)((m + 3) / 4);
+    hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
+                       flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// Device-wide prefix scans, reduce_subarrays_sum and the library bookkeeping entry points.
+#include "common.h"
+
+namespace dmcf {
+
+thread_local int g_last_hip_error = 0;
+
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;  // 2048 elements per workgroup
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v) {
+#pragma unroll
+    for (int d = 1; d < kWave; d <<= 1) {
+        T o = __shfl_up(v, d, kWave);
+        if (lane_id() >= d) v += o;
+    }
+    return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive prefix, total in *total
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* total, T* smem /* >= 4 entries */) {
+    const int wave = threadIdx.x >> 6;
+    const T inc = wave_inclusive_scan(v);
+    if (lane_id() == kWave - 1) smem[wave] = inc;
+    __syncthreads();
+    T carry = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kScanThreads / kWave; ++w) {
+        const T s = smem[w];
+        if (w < wave) carry += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return carry + inc - v;
+}
+
+template <typename TIn, typename TAcc>
+__global__ __launch_bounds__(kScanThreads) void scan_block_sums(const TIn* __restrict__ in, int64_t n,
+                                                                TAcc* __restrict__ sums) {
+    __shared__ TAcc smem[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    TAcc s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k)
+        if (base + k < n) s += (TAcc)in[base + k];
+    TAcc total;
+    block_exclusive_scan<TAcc>(s, &total, smem);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+// single workgroup: exclusive scan of the per-block sums in place
+template <typename TAcc>
+__global__ __launch_bounds__(kScanThreads) void scan_sums_inplace(TAcc* __restrict__ sums, int64_t nb) {
+    __shared__ TAcc smem[4];
+    TAcc carry = 0;
+    for (int64_t b0 = 0; b0 < nb; b0 += kScanThreads) {
+        const int64_t b = b0 + threadIdx.x;
+        const TAcc v = b < nb ? sums[b] : (TAcc)0;
+        TAcc total;
+        const TAcc ex = block_exclusive_scan<TAcc>(v, &total, smem);
+        if (b < nb) sums[b] = carry + ex;
+        carry += total;
+    }
+}
+
+// out[i] = exclusive prefix; if WRITE_TOTAL also out[n] = grand total
+template <typename TIn, typename TAcc, bool WRITE_TOTAL>
+__global__ __launch_bounds__(kScanThreads) void scan_block_apply(const TIn* __restrict__ in, int64_t n,
+                                                                 const TAcc* __restrict__ sums,
+                                                                 TAcc* __restrict__ out) {
+    __shared__ TAcc smem[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    TAcc v[kScanItems];
+    TAcc s = 0;
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        v[k] = base + k < n ? (TAcc)in[base + k] : (TAcc)0;
+        s += v[k];
+    }
+    TAcc total;
+    TAcc run = block_exclusive_scan<TAcc>(s, &total, smem) + sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < kScanItems; ++k) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+        if (WRITE_TOTAL && base + k == n - 1) out[n] = run;
+    }
+}
+
+size_t scan_tmp_bytes(int64_t n) {
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
+    return align_up((size_t)(nb + 1) * sizeof(int64_t), 256);
+}
+
+template <typename TIn, typename TAcc, bool WRITE_TOTAL>
+static int scan_impl(const TIn* in, TAcc* out, int64_t n, void* tmp, size_t tmp_bytes, hipStream_t stream) {
+    if (n < 0) return DMCF_EINVAL;
+    if (n == 0) {
+        if (WRITE_TOTAL) {
+            if (hipMemsetAsync(out, 0, sizeof(TAcc), stream) != hipSuccess) return DMCF_ELAUNCH;
+        }
+        return DMCF_OK;
+    }
+    if (tmp_bytes < scan_tmp_bytes(n)) return DMCF_EWORKSPACE;
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
+    TAcc* sums = (TAcc*)tmp;
+    hipLaunchKernelGGL((scan_block_sums<TIn, TAcc>), dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, n, sums);
+    hipLaunchKernelGGL((scan_sums_inplace<TAcc>), dim3(1), dim3(kScanThreads), 0, stream, sums, nb);
+    hipLaunchKernelGGL((scan_block_apply<TIn, TAcc, WRITE_TOTAL>), dim3((unsigned)nb), dim3(kScanThreads), 0,
+                       stream, in, n, sums, out);
+    return check_launch();
+}
+
+int scan_exclusive_u32(const uint32_t* in, uint32_t* out, int64_t n, void* tmp, size_t tmp_bytes,
+                       hipStream_t stream) {
+    return scan_impl<uint32_t, uint32_t, false>(in, out, n, tmp, tmp_bytes, stream);
+}
+
+int scan_counts_to_row_splits(const int32_t* counts, int64_t* row_splits, int64_t n, void* tmp,
+                              size_t tmp_bytes, hipStream_t stream) {
+    return scan_impl<int32_t, int64_t, true>(counts, row_splits, n, tmp, tmp_bytes, stream);
+}
+
+// one wave per row for long rows would be overkill here: rows are neighbour lists (tens to a few
+// thousand entries) and the op runs once per step (models/pbf_model.py:450-453); a 16-lane group per
+// row keeps the loads coalesced inside a row.
+__global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* __restrict__ values,
+                                                                   const int64_t* __restrict__ row_splits,
+                                                                   int64_t n_rows, float* __restrict__ out) {
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int sub = threadIdx.x & 15;
+    if (row >= n_rows) return;
+    const int64_t b = row_splits[row], e = row_splits[row + 1];
+    float s = 0.0f;
+    if (values) {
+        for (int64_t k = b + sub; k < e; k += 16) s += values[k];
+    } else {
+        for (int64_t k = b + sub; k < e; k += 16) s += 1.0f;
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) s += __shfl_xor(s, d, 16);
+    if (sub == 0) out[row] = s;
+}
+
+}  // namespace dmcf
+
+extern "C" {
+
+int dmcf_version(void) { return 100; }
+
+const char* dmcf_error_string(int code) {
+    switch (code) {
+        case DMCF_OK: return "ok";
+        case DMCF_EINVAL: return "invalid argument";
+        case DMCF_EWORKSPACE: return "workspace too small";
+        case DMCF_ELAUNCH: return "HIP error while enqueuing (see dmcf_last_hip_error)";
+        case DMCF_EUNSUPPORTED: return "option not implemented on the HIP path";
+        default: return "unknown error code";
+    }
+}
+
+int dmcf_last_hip_error(void) { return dmcf::g_last_hip_error; }
+
+int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
+                              dmcf_stream_t stream) {
+    if (n_rows < 0 || (n_rows > 0 && (!row_splits || !out))) return DMCF_EINVAL;
+    if (n_rows == 0) return DMCF_OK;
+    const int64_t threads = n_rows * 16;
+    const unsigned grid = (unsigned)((threads + 255) / 256);
+    hipLaunchKernelGGL(dmcf::reduce_subarrays_sum_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, values,
+                       row_splits, n_rows, out);
+    return dmcf::check_launch();
+}
+
+}  // extern "C"

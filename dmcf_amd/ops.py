@@ -1,0 +1,244 @@
+"""Operator surface of the hot path on MI355X -- the stand-in for ``open3d.ml.tf`` (``ml3d``).
+
+Same names, argument meaning and error behaviour as the Open3D operators the reference calls
+(paths relative to the reference tree):
+
+  ml3d.layers.FixedRadiusSearch    utils/convolutions.py:207-210 (ctor), :354-358 (call),
+                                   utils/tools/losses.py:296-298 (tuple-unpacked)
+  ml3d.ops.continuous_conv         utils/convolutions.py:414-431, :454
+  ml3d.ops.reduce_subarrays_sum    models/pbf_model.py:450-453
+
+Tensors are torch CUDA (= ROCm) tensors; torch is only plumbing here (device memory, streams).
+All arithmetic happens in libdmcf_hip.so through its C ABI (include/dmcf_hip.h).  There is no CPU
+fallback: calling these with CPU tensors or without the built library raises.
+"""
+import collections
+import ctypes
+
+import torch
+
+from . import _lib
+
+NeighborSearchResult = collections.namedtuple(
+    "NeighborSearchResult", ["neighbors_index", "neighbors_row_splits", "neighbors_distance"])
+
+MAPPINGS = {"ball_to_cube_radial": 0, "ball_to_cube_volume_preserving": 1, "identity": 2}
+INTERPOLATIONS = {"linear": 0, "linear_border": 1, "nearest_neighbor": 2}
+WINDOWS = {None: 0, "explicit": 1, "poly6": 2, "cubic": 3, "linear": 4, "peak": 5, "cubic_grad": 6}
+
+FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE = 1, 2, 4, 8
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev_f32(t, name, cols=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch tensor")
+    if not t.is_cuda:
+        raise _lib.DmcfError(f"{name} is on {t.device}: the DMCF hot path runs on the GPU only (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32, got {t.dtype}")
+    if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
+        raise ValueError(f"{name} must have shape [n,{cols}], got {tuple(t.shape)}")
+    return t.contiguous()
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class SpatialHashTable:
+    """Result of :func:`build_spatial_hash_table`: the cell-sorted grid of one point set for one radius.
+
+    Plays the role of Open3D's (hash_table_index, hash_table_cell_splits, hash_table_splits) triple,
+    which the reference can pass as ``fixed_radius_search_hash_table`` (utils/convolutions.py:283,358).
+    """
+
+    def __init__(self, points, radius, workspace, n_queries_capacity):
+        self.points = points
+        self.radius = float(radius)
+        self.workspace = workspace
+        self.n_queries_capacity = n_queries_capacity
+
+
+def build_spatial_hash_table(points, radius, n_queries=None, **_ignored):
+    """ml3d.ops.build_spatial_hash_table equivalent (hash_table_size_factor etc. are accepted and ignored:
+    the structure is a dense cell-sorted grid, see dmcf_amd/csrc/frs.hip)."""
+    L = _lib.lib()
+    points = _dev_f32(points, "points", 3)
+    n = points.shape[0]
+    m = n if n_queries is None else int(n_queries)
+    nbytes = L.dmcf_frs_workspace_bytes(n, m)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    _lib.check(L.dmcf_frs_build(_ptr(points), n, float(radius), _ptr(ws), nbytes, _stream()), "dmcf_frs_build")
+    return SpatialHashTable(points, radius, ws, m)
+
+
+def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
+                        hash_table=None):
+    """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
+    neighbors_distance float32 [P] (squared L2; empty if not return_distances))."""
+    L = _lib.lib()
+    points = _dev_f32(points, "points", 3)
+    queries = _dev_f32(queries, "queries", 3)
+    radius = float(radius)
+    if not radius > 0:
+        raise ValueError("radius must be positive")
+    n, m = points.shape[0], queries.shape[0]
+    if hash_table is None or hash_table.n_queries_capacity < m or hash_table.points.data_ptr() != points.data_ptr() \
+            or hash_table.radius != radius:
+        hash_table = build_spatial_hash_table(points, radius, n_queries=m)
+    ws = hash_table.workspace
+    nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
+    flags = 1 if ignore_query_point else 0
+    row_splits = torch.empty(m + 1, dtype=torch.int64, device=points.device)
+    _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
+               "dmcf_frs_count")
+    total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
+    index = torch.empty(total, dtype=torch.int32, device=points.device)
+    dist = torch.empty(total if return_distances else 0, dtype=torch.float32, device=points.device)
+    _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _ptr(index),
+                                _ptr(dist) if return_distances else None, _stream()), "dmcf_frs_write")
+    return NeighborSearchResult(index, row_splits, dist)
+
+
+class FixedRadiusSearch:
+    """Mirror of ``ml3d.layers.FixedRadiusSearch`` (ctor utils/convolutions.py:207-210; call :354-358)."""
+
+    def __init__(self, metric="L2", ignore_query_point=False, return_distances=False,
+                 max_hash_table_size=32 * 2 ** 20, index_dtype=torch.int32, **kwargs):
+        if metric != "L2":
+            # every DMCF config uses the default radius_search_metric='L2' (utils/convolutions.py:165)
+            raise NotImplementedError(f"metric {metric!r}: only 'L2' is implemented on the HIP path")
+        if index_dtype != torch.int32:
+            raise NotImplementedError("index_dtype must be int32 (Open3D 0.15.2 returns int32 indices)")
+        self.metric = metric
+        self.ignore_query_point = ignore_query_point
+        self.return_distances = return_distances
+        self.max_hash_table_size = max_hash_table_size
+
+    def __call__(self, points, queries, radius, points_row_splits=None, queries_row_splits=None,
+                 hash_table_size_factor=1 / 64, hash_table=None):
+        if points_row_splits is not None or queries_row_splits is not None:
+            raise NotImplementedError("batched row_splits are not used by DMCF (batch items are looped, "
+                                      "pipelines/simulator.py:68-70)")
+        if isinstance(radius, torch.Tensor):
+            radius = float(radius)
+        return fixed_radius_search(points, queries, radius, self.ignore_query_point, self.return_distances,
+                                   hash_table=hash_table)
+
+    call = __call__
+
+
+def _empty(t):
+    return t is None or (isinstance(t, torch.Tensor) and t.numel() == 0)
+
+
+def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
+                  neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
+                  align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
+                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False):
+    """One call of dmcf_cconv_forward.  ``window``: None | 'explicit' (neighbors_value = importance) |
+    'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances)."""
+    L = _lib.lib()
+    filters = _dev_f32(filters, "filters")
+    if filters.dim() != 5:
+        raise ValueError("filters must have shape [D,H,W,Cin,Cout]")
+    out_positions = _dev_f32(out_positions, "out_positions", 3)
+    inp_positions = _dev_f32(inp_positions, "inp_positions", 3)
+    cin, cout = filters.shape[3], filters.shape[4]
+    inp_features = _dev_f32(inp_features, "inp_features", cin)
+    if inp_features.shape[0] != inp_positions.shape[0]:
+        raise ValueError("inp_features and inp_positions disagree on the number of points")
+    n_out = out_positions.shape[0]
+    if neighbors_index.dtype != torch.int32 or neighbors_row_splits.dtype != torch.int64:
+        raise TypeError("neighbors_index must be int32 and neighbors_row_splits int64")
+    if neighbors_row_splits.shape[0] != n_out + 1:
+        raise ValueError("neighbors_row_splits must have n_out+1 entries")
+    if window not in WINDOWS:
+        raise NotImplementedError(f"window {window!r}")
+    if window is not None:
+        if _empty(neighbors_value) and neighbors_index.numel() > 0:
+            raise ValueError("window given but no per-neighbour values")
+        if neighbors_value is None:
+            neighbors_value = torch.empty(0, dtype=torch.float32, device=filters.device)
+        neighbors_value = _dev_f32(neighbors_value, "neighbors_value")
+        if neighbors_value.shape[0] != neighbors_index.shape[0]:
+            raise ValueError("neighbors_value and neighbors_index disagree on the number of pairs")
+    if _empty(inp_importance):
+        inp_importance = None
+    else:
+        inp_importance = _dev_f32(inp_importance, "inp_importance")
+    if bias is not None:
+        bias = _dev_f32(bias, "bias")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an out tensor")
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=filters.device)
+    else:
+        if out.shape != (n_out, cout) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out has the wrong shape / dtype / layout")
+    a = _lib.CconvArgs()
+    a.filters = filters.data_ptr()
+    for d in range(5):
+        a.filter_dims[d] = filters.shape[d]
+    a.sym_axis = int(sym_axis)
+    a.out_positions = out_positions.data_ptr()
+    a.n_out = n_out
+    a.inp_positions = inp_positions.data_ptr()
+    a.n_inp = inp_positions.shape[0]
+    a.inp_features = inp_features.data_ptr()
+    a.inp_importance = None if inp_importance is None else inp_importance.data_ptr()
+    a.neighbors_index = neighbors_index.contiguous().data_ptr()
+    a.neighbors_row_splits = neighbors_row_splits.contiguous().data_ptr()
+    a.neighbors_value = None if window is None else neighbors_value.data_ptr()
+    a.extent = float(extent)
+    a.window_fac = float(window_fac)
+    a.window = WINDOWS[window]
+    a.coordinate_mapping = MAPPINGS[coordinate_mapping]
+    a.interpolation = INTERPOLATIONS[interpolation]
+    a.flags = ((FLAG_ALIGN_CORNERS if align_corners else 0) | (FLAG_NORMALIZE if normalize else 0) |
+               (FLAG_SYMMETRIC if symmetric else 0) | (FLAG_ACCUMULATE if accumulate else 0))
+    a.bias = None if bias is None else bias.data_ptr()
+    a.out = out.data_ptr()
+    nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+    _lib.check(L.dmcf_cconv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_cconv_forward")
+    return out
+
+
+def continuous_conv(filters, out_positions, extents, offset, inp_positions, inp_features, inp_importance,
+                    neighbors_index, neighbors_row_splits, neighbors_importance, align_corners=True,
+                    coordinate_mapping="ball_to_cube_radial", interpolation="linear", normalize=True,
+                    max_temp_mem_MB=64, **_ignored):
+    """Mirror of ``ml3d.ops.continuous_conv`` with the keyword set of utils/convolutions.py:414-431.
+
+    ``extents`` must hold a single value (DMCF always passes a scalar extent, :352-353,:390-392);
+    ``offset`` must be zero (:200-201).  An empty tensor means "absent" for the importance inputs (:335,:376).
+    """
+    ext = extents if isinstance(extents, torch.Tensor) else torch.as_tensor(extents)
+    if ext.numel() != 1:
+        raise NotImplementedError("per-point extents (RadiusSearch path, utils/convolutions.py:366-370) "
+                                  "are not used by DMCF and not implemented")
+    if offset is not None and bool(torch.as_tensor(offset).ne(0).any()):
+        raise NotImplementedError("non-zero offset is not used by DMCF and not implemented")
+    window = None if _empty(neighbors_importance) else "explicit"
+    return cconv_forward(filters, out_positions, float(ext), inp_positions, inp_features, neighbors_index,
+                         neighbors_row_splits, neighbors_value=neighbors_importance, window=window,
+                         inp_importance=inp_importance, align_corners=align_corners,
+                         coordinate_mapping=coordinate_mapping, interpolation=interpolation, normalize=normalize)
+
+
+def reduce_subarrays_sum(values, row_splits):
+    """Mirror of ``o3dml.ops.reduce_subarrays_sum`` (models/pbf_model.py:450-453)."""
+    L = _lib.lib()
+    values = _dev_f32(values, "values")
+    if row_splits.dtype != torch.int64:
+        raise TypeError("row_splits must be int64")
+    n_rows = row_splits.shape[0] - 1
+    out = torch.empty(n_rows, dtype=torch.float32, device=values.device)
+    _lib.check(L.dmcf_reduce_subarrays_sum(_ptr(values), _ptr(row_splits.contiguous()), n_rows, _ptr(out), _stream()),
+               "dmcf_reduce_subarrays_sum")
+    return out

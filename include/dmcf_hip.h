@@ -1,0 +1,159 @@
+/*
+ * dmcf_hip.h -- C ABI of libdmcf_hip.so: the MI355X (gfx950) implementation of DMCF's per-step
+ * particle hot path.  This is the drop-in boundary: these entry points are what the reference's
+ * Python layer binds in place of the Open3D (open3d==0.15.2) TensorFlow operators it calls.
+ * Paths below are relative to the reference tree (tum-pbs/DMCF).
+ *
+ *   reference operator (call site)                               replaced by
+ *   ------------------------------------------------------------ -------------------------------
+ *   ml3d.layers.FixedRadiusSearch = build_spatial_hash_table +   dmcf_frs_build / dmcf_frs_count /
+ *     fixed_radius_search  (utils/convolutions.py:207-210,        dmcf_frs_write
+ *     354-358; utils/tools/losses.py:296-298,339-341)
+ *   window functions (utils/tools/losses.py:8-44) applied at     DMCF_WINDOW_* fused into
+ *     utils/convolutions.py:359-379                               dmcf_cconv_forward
+ *   ml3d.ops.continuous_conv (utils/convolutions.py:414-431)     dmcf_cconv_forward
+ *   ASCC: mirror :410-412 + second continuous_conv :433-458      dmcf_cconv_forward(DMCF_FLAG_SYMMETRIC)
+ *   o3dml.ops.reduce_subarrays_sum (models/pbf_model.py:450-453) dmcf_reduce_subarrays_sum
+ *   grid_pos / tf.unique (utils/tools/losses.py:136-181)         dmcf_grid_pos_*
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, a stream handle (hipStream_t passed as void*); no
+ *     torch / HIP types in any signature.
+ *   - every function returns DMCF_OK (0) or a negative DMCF_E* code; nothing throws; arguments are
+ *     validated on the host; kernels are enqueued on `stream` and NOT synchronised.
+ *   - ownership: the caller owns every buffer.  The library never allocates device memory; scratch
+ *     comes from a caller-supplied workspace whose size the *_workspace_bytes functions report.
+ *   - stateless and re-entrant: ordering only through `stream`.
+ *   - layouts: positions [n,3] float32 row-major xyz (z = 0 in 2-D scenes); features [n,C] float32
+ *     row-major; filters [D(z),H(y),W(x),Cin,Cout] float32 row-major; CSR neighbour lists with
+ *     int32 indices and int64 row splits (the dtypes of Open3D 0.15.2's op); distances are
+ *     squared L2.
+ *   - two-phase search because the number of pairs is data dependent:
+ *       build -> count (fills row_splits) -> caller reads row_splits[m], allocates -> write.
+ */
+#ifndef DMCF_HIP_H_
+#define DMCF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMCF_OK 0
+#define DMCF_EINVAL (-1)      /* bad argument (null pointer, negative size, unsupported option) */
+#define DMCF_EWORKSPACE (-2)  /* workspace too small */
+#define DMCF_ELAUNCH (-3)     /* HIP reported an error when enqueuing (see dmcf_last_hip_error) */
+#define DMCF_EUNSUPPORTED (-4) /* valid in the reference, not implemented on this path yet */
+
+typedef void* dmcf_stream_t; /* hipStream_t */
+
+/* library / ABI version (major*10000 + minor*100 + patch) and error text */
+int dmcf_version(void);
+const char* dmcf_error_string(int code);
+int dmcf_last_hip_error(void); /* hipError_t of the last failed enqueue on this thread */
+
+/* ------------------------------------------------------------------------------------------------
+ * Fixed-radius search.  Replaces ml3d.layers.FixedRadiusSearch(metric='L2', ignore_query_point,
+ * return_distances)(points, queries, radius)  (utils/convolutions.py:207-210, 354-358).
+ * Result contract (what the reference's callers observe): for every query i the SET
+ *   { j : ((dx*dx + dy*dy) + dz*dz) <= radius*radius }     float32, un-fused, inclusive,
+ * minus points whose coordinates equal the query's when DMCF_FRS_IGNORE_QUERY_POINT is set.
+ * The order inside a row is implementation defined in the reference (hash-bin order, atomics);
+ * here it is deterministic: ascending grid cell (z, y, x), then ascending point index.
+ * ---------------------------------------------------------------------------------------------- */
+#define DMCF_FRS_IGNORE_QUERY_POINT 1
+
+/* bytes of workspace for a search structure over n_points that will serve up to n_queries queries */
+size_t dmcf_frs_workspace_bytes(int64_t n_points, int64_t n_queries);
+
+/* build the cell-sorted uniform grid of `points` in `workspace` (device memory, 256-B aligned) */
+int dmcf_frs_build(const float* points, int64_t n_points, float radius, void* workspace,
+                   size_t workspace_bytes, dmcf_stream_t stream);
+
+/* count neighbours of each query and write the int64 exclusive prefix sum to row_splits[0..m];
+ * n_points / radius / workspace must be the ones given to dmcf_frs_build */
+int dmcf_frs_count(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags,
+                   void* workspace, size_t workspace_bytes, int64_t* row_splits, dmcf_stream_t stream);
+
+/* write neighbors_index[P] (int32) and, if not NULL, neighbors_distance[P] (squared L2) */
+int dmcf_frs_write(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags,
+                   const void* workspace, size_t workspace_bytes, const int64_t* row_splits,
+                   int32_t* neighbors_index, float* neighbors_distance, dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Continuous convolution (CConv) and its antisymmetric variant (ASCC).
+ * Replaces ml3d.ops.continuous_conv(filters, out_positions, extents[1,1], offset=0, inp_positions,
+ * inp_features, inp_importance, neighbors_index, neighbors_row_splits, neighbors_importance,
+ * align_corners, coordinate_mapping, interpolation, normalize)  (utils/convolutions.py:414-431):
+ *     out[i,:] = 1/psi_i * sum_{p in row i} a_p * s_j * sum_c f_j[c] * g(Lambda(x_j - x_i))[c,:]
+ * with j = neighbors_index[p], a_p the per-neighbour importance, s_j the per-point importance,
+ * psi_i = sum_p a_p when DMCF_FLAG_NORMALIZE (else 1).
+ * With DMCF_FLAG_SYMMETRIC the call computes the whole ASCC layer body
+ * (utils/convolutions.py:410-412 and 433-458) in one pass:
+ *     g = concat([-flip_zyx(filters), filters], axis=sym_axis);
+ *     out[i,:] = sum_p a_p * sum_c (f_j[c] + f_i[c]) * g(Lambda(x_j - x_i))[c,:]
+ * which requires inp == out point sets (n_inp == n_out).
+ * ---------------------------------------------------------------------------------------------- */
+enum dmcf_mapping {
+    DMCF_MAP_BALL_TO_CUBE_RADIAL = 0,
+    DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING = 1,
+    DMCF_MAP_IDENTITY = 2
+};
+enum dmcf_interpolation { DMCF_INTERP_LINEAR = 0, DMCF_INTERP_LINEAR_BORDER = 1, DMCF_INTERP_NEAREST = 2 };
+/* how the per-neighbour importance a_p is obtained from `neighbors_value` */
+enum dmcf_window {
+    DMCF_WINDOW_NONE = 0,       /* a_p = 1; neighbors_value ignored (may be NULL) */
+    DMCF_WINDOW_EXPLICIT = 1,   /* a_p = neighbors_value[p] (user supplied importance) */
+    /* a_p = w(q), q = neighbors_value[p] / radius^2, neighbors_value = squared distances
+     * (utils/convolutions.py:359-362, 375-379; formulas utils/tools/losses.py:8-44) */
+    DMCF_WINDOW_POLY6 = 2,
+    DMCF_WINDOW_CUBIC = 3,
+    DMCF_WINDOW_LINEAR = 4,
+    DMCF_WINDOW_PEAK = 5,
+    DMCF_WINDOW_CUBIC_GRAD = 6
+};
+#define DMCF_FLAG_ALIGN_CORNERS 1
+#define DMCF_FLAG_NORMALIZE 2
+#define DMCF_FLAG_SYMMETRIC 4  /* ASCC: filters is the stored half kernel, see above */
+#define DMCF_FLAG_ACCUMULATE 8 /* out += result instead of out = result (add_merge, models/hrnet.py:115-116) */
+
+typedef struct dmcf_cconv_args {
+    const float* filters;      /* [D,H,W,Cin,Cout]; with SYMMETRIC: dims[sym_axis] is the stored half size */
+    int32_t filter_dims[5];    /* D(z), H(y), W(x), Cin, Cout of `filters` as passed */
+    int32_t sym_axis;          /* 0..2, index into (z,y,x); only with DMCF_FLAG_SYMMETRIC */
+    const float* out_positions; /* [n_out,3] */
+    int64_t n_out;
+    const float* inp_positions; /* [n_inp,3] */
+    int64_t n_inp;
+    const float* inp_features;   /* [n_inp,Cin] */
+    const float* inp_importance; /* [n_inp] or NULL (always NULL in DMCF: models/hrnet.py:91-92) */
+    const int32_t* neighbors_index;       /* [P] */
+    const int64_t* neighbors_row_splits;  /* [n_out+1] */
+    const float* neighbors_value;         /* [P] squared distances or importances, see dmcf_window */
+    float extent;              /* scalar filter extent (diameter); radius = extent/2 */
+    float window_fac;          /* multiplier of the window function ("fac", losses.py:8), normally 1 */
+    int32_t window;            /* enum dmcf_window */
+    int32_t coordinate_mapping; /* enum dmcf_mapping */
+    int32_t interpolation;      /* enum dmcf_interpolation */
+    int32_t flags;              /* DMCF_FLAG_* */
+    const float* bias;          /* [Cout] or NULL; added after normalisation (convolutions.py:466-467) */
+    float* out;                 /* [n_out,Cout] */
+} dmcf_cconv_args;
+
+size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);
+int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t workspace_bytes,
+                       dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * o3dml.ops.reduce_subarrays_sum(values, row_splits) (models/pbf_model.py:450-453):
+ *   out[i] = sum(values[row_splits[i] : row_splits[i+1]]);  values == NULL means all ones.
+ * ---------------------------------------------------------------------------------------------- */
+int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
+                              dmcf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMCF_HIP_H_ */

@@ -1,0 +1,75 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/dmcf_hip.h declares (no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def hip_lib():
+    from dmcf_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.lib()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "dmcf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmcf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(hip_lib):
+    from dmcf_amd import _lib
+    declared = _declared_symbols()
+    assert declared, "no prototypes found in include/dmcf_hip.h"
+    assert sorted(_lib.SYMBOLS) == declared
+    for name in declared:
+        assert hasattr(hip_lib, name), f"{name} declared in dmcf_hip.h but not exported"
+
+
+def test_version_and_error_strings(hip_lib):
+    assert hip_lib.dmcf_version() >= 100
+    assert hip_lib.dmcf_error_string(0) == b"ok"
+    assert b"workspace" in hip_lib.dmcf_error_string(-2)
+
+
+def test_workspace_queries_and_host_validation(hip_lib):
+    # host-side argument validation runs without a device
+    assert hip_lib.dmcf_frs_workspace_bytes(1000, 1000) > 1000 * 16
+    assert hip_lib.dmcf_frs_workspace_bytes(-1, 0) == 0
+    assert hip_lib.dmcf_frs_build(None, 10, 0.1, None, 0, None) == -1  # null workspace -> DMCF_EINVAL
+    assert hip_lib.dmcf_reduce_subarrays_sum(None, None, -1, None, None) == -1
+    from dmcf_amd._lib import CconvArgs
+    a = CconvArgs()
+    assert hip_lib.dmcf_cconv_forward(ctypes.byref(a), None, 0, None) == -1  # zero filter dims
+
+
+def test_struct_layout_matches_header():
+    # field order of struct dmcf_cconv_args in the header == ctypes mirror
+    from dmcf_amd._lib import CconvArgs
+    text = open(os.path.join(ROOT, "include", "dmcf_hip.h")).read()
+    body = text[text.index("typedef struct dmcf_cconv_args {"):text.index("} dmcf_cconv_args;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = re.findall(r"\b([a-z_]+)(?:\[5\])?;", body)
+    assert names == [f[0] for f in CconvArgs._fields_]
+
+
+def test_product_does_not_import_oracle():
+    # the oracle is test infrastructure; nothing under dmcf_amd/ may reference it
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "dmcf_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "libdmcf_oracle" not in src, f
+
+
+def test_ops_refuse_cpu_tensors(hip_lib):
+    import torch
+    from dmcf_amd import ops, _lib
+    with pytest.raises(_lib.DmcfError):
+        ops.fixed_radius_search(torch.zeros(4, 3), torch.zeros(4, 3), 0.5)

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP operators (through the C ABI) against the CPU oracle on seeded inputs.
+
+Bars (BASELINE.json north_star): neighbour indices bit-exact as per-row sets, squared distances
+bit-exact (same un-fused float32 arithmetic); CConv / ASCC outputs within 1e-5 of the output scale
+(float32 op, summation order differs: LDS atomics + different contraction order)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but torch.cuda.is_available() is False")
+    return torch.device("cuda:0")
+
+
+def _cloud(n, seed, dim=3, scale=1.0):
+    rng = np.random.default_rng(seed)
+    p = rng.uniform(-scale, scale, size=(n, 3)).astype(np.float32)
+    if dim == 2:
+        p[:, 2] = 0
+    elif dim == 1:
+        p[:, 0] = 0
+        p[:, 2] = 0
+    return p
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _check_search(oracle, dev, pts, qs, radius, ignore):
+    from dmcf_amd import ops
+    res = ops.fixed_radius_search(_t(pts, dev), _t(qs, dev), radius, ignore_query_point=ignore, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in res)
+    i0, r0, d0 = oracle.fixed_radius_search(pts, qs, radius, ignore)
+    assert idx.dtype == np.int32 and rs.dtype == np.int64 and d.dtype == np.float32
+    np.testing.assert_array_equal(rs, r0)
+    a, da = oracle.canonical_rows(idx, rs, d)
+    b, db = oracle.canonical_rows(i0, r0, d0)
+    np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(da, db)
+    return idx, rs, d
+
+
+@pytest.mark.parametrize("n,m,radius,dim", [
+    (2000, 1500, 0.15, 3), (3000, 3000, 0.05, 2), (500, 700, 0.3, 1), (64, 1, 3.0, 3), (1, 50, 0.5, 3),
+    (5000, 100, 0.9, 3), (20000, 20000, 0.08, 3)])
+@pytest.mark.parametrize("ignore", [False, True])
+def test_frs_matches_oracle(oracle, dev, n, m, radius, dim, ignore):
+    pts = _cloud(n, 1, dim)
+    qs = pts[:m].copy() if (ignore and m <= n) else _cloud(m, 2, dim)
+    _check_search(oracle, dev, pts, qs, radius, ignore)
+
+
+def test_frs_rows_deterministic_order(oracle, dev):
+    # documented order: ascending grid cell then ascending point index -> two runs agree exactly
+    from dmcf_amd import ops
+    pts = _t(_cloud(30000, 5), dev)
+    a = ops.fixed_radius_search(pts, pts, 0.06, return_distances=True)
+    b = ops.fixed_radius_search(pts, pts, 0.06, return_distances=True)
+    assert torch.equal(a.neighbors_index, b.neighbors_index)
+    assert torch.equal(a.neighbors_distance, b.neighbors_distance)
+
+
+def test_frs_edge_cases(oracle, dev):
+    from dmcf_amd import ops
+    # empty point set / empty query set
+    r = ops.fixed_radius_search(torch.zeros(0, 3, device=dev), _t(_cloud(5, 0), dev), 0.3)
+    assert r.neighbors_index.numel() == 0 and r.neighbors_row_splits.tolist() == [0] * 6
+    r = ops.fixed_radius_search(_t(_cloud(5, 0), dev), torch.zeros(0, 3, device=dev), 0.3)
+    assert r.neighbors_index.numel() == 0 and r.neighbors_row_splits.tolist() == [0]
+    # inclusive radius and ignore-by-coordinates (duplicates of the query point are all dropped)
+    pts = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0], [0, 0, 0], [0.5000001, 0, 0], [1, 1, 1]], np.float32)
+    qs = np.array([[0, 0, 0]], np.float32)
+    idx, rs, d = _check_search(oracle, dev, pts, qs, 0.5, False)
+    assert sorted(idx.tolist()) == [0, 1, 2, 3]
+    idx, rs, d = _check_search(oracle, dev, pts, qs, 0.5, True)
+    assert sorted(idx.tolist()) == [1, 2]
+    # two far apart clusters: the dense grid must coarsen its cells, results unchanged
+    a = _cloud(3000, 3, scale=0.5)
+    b = _cloud(3000, 4, scale=0.5) + np.float32([4000.0, -2500.0, 900.0])
+    pts = np.concatenate([a, b])
+    _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False)
+    # queries far outside the bounding box of the points
+    _check_search(oracle, dev, a, b[:100].copy(), 0.2, False)
+    # all points identical
+    same = np.zeros((300, 3), np.float32) + np.float32(0.25)
+    _check_search(oracle, dev, same, same[:10].copy(), 0.1, False)
+    _check_search(oracle, dev, same, same[:10].copy(), 0.1, True)
+
+
+def test_frs_lattice_ties(oracle, dev):
+    # regular lattice: many distances exactly equal to R (inclusive test must agree bit for bit)
+    g = np.arange(12, dtype=np.float32) * np.float32(0.25)
+    pts = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    _check_search(oracle, dev, pts, pts, 0.5, True)
+    _check_search(oracle, dev, pts, pts, 0.75, False)
+
+
+def test_frs_hash_table_reuse(oracle, dev):
+    from dmcf_amd import ops
+    pts = _t(_cloud(4000, 8), dev)
+    q1, q2 = _t(_cloud(1000, 9), dev), _t(_cloud(4000, 10), dev)
+    table = ops.build_spatial_hash_table(pts, 0.2)
+    frs = ops.FixedRadiusSearch(return_distances=True)
+    for q in (q1, q2):
+        r = frs(pts, q, 0.2, hash_table=table)
+        i0, r0, d0 = oracle.fixed_radius_search(pts.cpu().numpy(), q.cpu().numpy(), 0.2)
+        np.testing.assert_array_equal(r.neighbors_row_splits.cpu().numpy(), r0)
+
+
+def _conv_inputs(oracle, seed, n, m, cin, cout, ks, radius, dim=3, same=False):
+    rng = np.random.default_rng(seed)
+    inp = _cloud(n, seed, dim)
+    out = inp if same else _cloud(m, seed + 100, dim)
+    feat = rng.normal(size=(n, cin)).astype(np.float32)
+    filt = rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32)
+    return inp, out, feat, filt
+
+
+def _close(a, ref64, tol=1e-5):
+    scale = max(np.abs(ref64).max(), 1e-30)
+    err = np.abs(a.astype(np.float64) - ref64).max() / scale
+    assert err <= tol, f"max error {err:.3e} of output scale"
+
+
+@pytest.mark.parametrize("cin,cout", [(1, 1), (3, 2), (4, 8), (7, 8), (8, 16), (16, 32), (24, 4), (32, 32), (5, 64), (32, 3)])
+@pytest.mark.parametrize("ks,dim,radius", [((4, 4, 4), 3, 0.3), ((1, 8, 8), 2, 0.12), ((1, 8, 1), 1, 0.2), ((3, 5, 2), 3, 0.3)])
+def test_cconv_matches_oracle(oracle, dev, cin, cout, ks, dim, radius):
+    from dmcf_amd import ops
+    n, m = (700, 450) if dim == 3 else (900, 600)
+    inp, out, feat, filt = _conv_inputs(oracle, cin * 100 + cout, n, m, cin, cout, ks, radius, dim)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    imp = oracle.window("poly6", d / np.float32(radius) ** 2)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, imp, f64=True)
+    y = ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6")
+    _close(y.cpu().numpy(), ref)
+    # the reference operator signature with an explicit importance array gives the same answer
+    y2 = ops.continuous_conv(_t(filt, dev), _t(out, dev), torch.tensor([[2 * radius]]), torch.zeros(3), _t(inp, dev),
+                             _t(feat, dev), torch.ones(0), nns.neighbors_index, nns.neighbors_row_splits,
+                             _t(imp, dev), align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
+                             interpolation="linear", normalize=False)
+    _close(y2.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("window", [None, "poly6", "cubic", "linear", "peak", "cubic_grad"])
+def test_cconv_windows(oracle, dev, window):
+    from dmcf_amd import ops
+    radius = 0.3
+    inp, out, feat, filt = _conv_inputs(oracle, 5, 600, 400, 6, 5, (4, 4, 4), radius)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    imp = oracle.window(window, d / np.float32(radius) ** 2)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, imp, f64=True)
+    y = ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window=window)
+    _close(y.cpu().numpy(), ref, 2e-5)
+
+
+@pytest.mark.parametrize("mapping", ["ball_to_cube_radial", "ball_to_cube_volume_preserving", "identity"])
+@pytest.mark.parametrize("interp", ["linear", "linear_border", "nearest_neighbor"])
+@pytest.mark.parametrize("align,normalize", [(True, False), (False, True)])
+def test_cconv_option_matrix(oracle, dev, mapping, interp, align, normalize):
+    from dmcf_amd import ops
+    radius = 0.3
+    inp, out, feat, filt = _conv_inputs(oracle, 9, 500, 300, 4, 6, (4, 3, 5), radius)
+    pimp = np.random.default_rng(3).uniform(0.5, 1.5, size=500).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    imp = oracle.window("poly6", d / np.float32(radius) ** 2)
+    kw = dict(align_corners=align, coordinate_mapping=mapping, interpolation=interp, normalize=normalize)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, imp, inp_importance=pimp, f64=True, **kw)
+    y = ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
+                          inp_importance=_t(pimp, dev), **kw)
+    y = y.cpu().numpy()
+    if interp == "nearest_neighbor":
+        # a coordinate within float rounding of x.5 may round to the other cell: allow a few such rows
+        scale = np.abs(ref).max()
+        bad = (np.abs(y - ref).max(axis=1) > 2e-5 * scale).mean()
+        assert bad < 0.02
+    else:
+        _close(y, ref, 2e-5)
+
+
+def test_cconv_bias_accumulate_and_empty_rows(oracle, dev):
+    from dmcf_amd import ops
+    radius = 0.25
+    inp, out, feat, filt = _conv_inputs(oracle, 13, 500, 300, 8, 16, (4, 4, 4), radius)
+    out = np.concatenate([out, np.float32([[9, 9, 9], [-9, 0, 0]])])
+    bias = np.random.default_rng(1).normal(size=16).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    imp = oracle.window("poly6", d / np.float32(radius) ** 2)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, imp, f64=True)
+    args = (_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+            nns.neighbors_row_splits)
+    kw = dict(neighbors_value=nns.neighbors_distance, window="poly6")
+    y = ops.cconv_forward(*args, bias=_t(bias, dev), **kw).cpu().numpy()
+    _close(y, ref + bias)
+    assert np.array_equal(y[-2:], np.stack([bias, bias]))  # rows without neighbours: exactly the bias
+    acc = torch.full((out.shape[0], 16), 2.0, device=dev)
+    ops.cconv_forward(*args, out=acc, accumulate=True, **kw)
+    _close(acc.cpu().numpy(), ref + 2.0)
+
+
+@pytest.mark.parametrize("ks,sym_axis,dim,cin,cout", [((6, 6, 6), 1, 3, 32, 3), ((1, 8, 8), 1, 2, 32, 2), ((4, 4, 4), 2, 3, 6, 3),
+                                                      ((4, 4, 4), 0, 3, 5, 1), ((2, 2, 6), 2, 3, 9, 12)])
+def test_ascc_matches_two_pass_oracle_and_conserves_momentum(oracle, dev, ks, sym_axis, dim, cin, cout):
+    from dmcf_amd import ops
+    rng = np.random.default_rng(17)
+    n, radius = 1200, 0.2 if dim == 3 else 0.08
+    pos = _cloud(n, 23, dim)
+    feat = np.maximum(rng.normal(size=(n, cin)), 0).astype(np.float32)
+    half = list(ks)
+    half[sym_axis] //= 2
+    k = rng.uniform(-1, 1, size=(*half, cin, cout)).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(pos, dev), _t(pos, dev), radius, ignore_query_point=True, return_distances=True)
+    conv = oracle.ContinuousConvRef(k, window_function="peak", ignore_query_points=True, symmetric=True,
+                                    sym_axis=sym_axis, f64=True)
+    ref = conv(feat, pos, pos, 2 * radius, nns=tuple(x.cpu().numpy() for x in nns))
+    y = ops.cconv_forward(_t(k, dev), _t(pos, dev), 2 * radius, _t(pos, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="peak",
+                          symmetric=True, sym_axis=sym_axis).cpu().numpy()
+    _close(y, ref, 2e-5)
+    terms = np.abs(y).sum(axis=0)
+    assert np.all(np.abs(y.astype(np.float64).sum(axis=0)) <= 2e-5 * terms + 1e-6)
+
+
+def test_reduce_subarrays_sum(oracle, dev):
+    from dmcf_amd import ops
+    rng = np.random.default_rng(0)
+    counts = rng.integers(0, 70, size=500)
+    rs = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    v = rng.normal(size=rs[-1]).astype(np.float32)
+    y = ops.reduce_subarrays_sum(_t(v, dev), _t(rs, dev)).cpu().numpy()
+    np.testing.assert_allclose(y, oracle.reduce_subarrays_sum(v, rs), rtol=1e-5, atol=1e-5)
+
+
+def test_scale_properties_200k(oracle, dev):
+    """Size-independent properties at a size the oracle would not finish quickly:
+    row counts symmetric (j in N(i) <=> i in N(j)), ASCC momentum conservation, CConv linearity."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(0)
+    g = np.arange(58, dtype=np.float32) * np.float32(0.05)
+    pos = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    pos = (pos + rng.uniform(-0.005, 0.005, size=pos.shape)).astype(np.float32)  # 195k particles
+    P = _t(pos, dev)
+    nns = ops.fixed_radius_search(P, P, 0.1, ignore_query_point=True, return_distances=True)
+    n = pos.shape[0]
+    deg = torch.diff(nns.neighbors_row_splits)
+    indeg = torch.zeros(n, dtype=torch.int64, device=dev).index_add_(0, nns.neighbors_index.long(), torch.ones_like(nns.neighbors_index, dtype=torch.int64))
+    assert torch.equal(deg, indeg)
+    assert 25 < deg.float().mean().item() < 40
+    feat = torch.relu(torch.randn(n, 32, device=dev, generator=torch.Generator(device=dev).manual_seed(1)))
+    k = torch.rand(6, 3, 6, 32, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) - 0.5
+    y = ops.cconv_forward(k, P, 0.2, P, feat, nns.neighbors_index, nns.neighbors_row_splits,
+                          neighbors_value=nns.neighbors_distance, window="peak", symmetric=True, sym_axis=1)
+    tot = y.double().sum(0).abs()
+    assert torch.all(tot <= 2e-5 * y.double().abs().sum(0))
+    W = torch.rand(4, 4, 4, 32, 32, device=dev) - 0.5
+    kw = dict(neighbors_value=nns.neighbors_distance, window="poly6")
+    a = ops.cconv_forward(W, P, 0.2, P, feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
+    b = ops.cconv_forward(W, P, 0.2, P, 2 * feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
+    assert torch.allclose(b, 2 * a, rtol=1e-4, atol=1e-4 * a.abs().max().item())
