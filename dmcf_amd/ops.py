@@ -99,8 +99,10 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
     index = torch.empty(total, dtype=torch.int32, device=points.device)
     dist = torch.empty(total if return_distances else 0, dtype=torch.float32, device=points.device)
-    _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _ptr(index),
-                                _ptr(dist) if return_distances else None, _stream()), "dmcf_frs_write")
+    if total > 0:
+        _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits),
+                                    _ptr(index), _ptr(dist) if return_distances else None, _stream()),
+                   "dmcf_frs_write")
     return NeighborSearchResult(index, row_splits, dist)
 
 

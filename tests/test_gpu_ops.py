@@ -33,11 +33,11 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-def _check_search(oracle, dev, pts, qs, radius, ignore):
+def _check_search(oracle, dev, pts, qs, radius, ignore, bruteforce=False):
     from dmcf_amd import ops
     res = ops.fixed_radius_search(_t(pts, dev), _t(qs, dev), radius, ignore_query_point=ignore, return_distances=True)
     idx, rs, d = (x.cpu().numpy() for x in res)
-    i0, r0, d0 = oracle.fixed_radius_search(pts, qs, radius, ignore)
+    i0, r0, d0 = oracle.fixed_radius_search(pts, qs, radius, ignore, bruteforce=bruteforce)
     assert idx.dtype == np.int32 and rs.dtype == np.int64 and d.dtype == np.float32
     np.testing.assert_array_equal(rs, r0)
     a, da = oracle.canonical_rows(idx, rs, d)
@@ -85,7 +85,13 @@ def test_frs_edge_cases(oracle, dev):
     a = _cloud(3000, 3, scale=0.5)
     b = _cloud(3000, 4, scale=0.5) + np.float32([4000.0, -2500.0, 900.0])
     pts = np.concatenate([a, b])
-    _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False)
+    # at |x| ~ 4000 one float ulp is 0.5 % of R: Open3D's corner-voxel candidate set (restated by the
+    # hash oracle) drops a few pairs whose voxel lies one rounding step outside fl(q +- R); the contract
+    # of the HIP path is the distance test itself, i.e. the brute-force set, of which the hash result
+    # is a subset (documented deviation).
+    idx, rs, d = _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False, bruteforce=True)
+    ih, rh, dh = oracle.fixed_radius_search(pts, pts[::3].copy(), 0.05, False)
+    assert np.all(np.diff(rh) <= np.diff(rs)) and 0 < rs[-1] - rh[-1] < 0.01 * rs[-1]
     # queries far outside the bounding box of the points
     _check_search(oracle, dev, a, b[:100].copy(), 0.2, False)
     # all points identical
