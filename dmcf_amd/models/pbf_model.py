@@ -1,0 +1,253 @@
+"""PBFNet -- mirror of the reference's ``models/pbf_model.py:31-517`` (inference path) on PyTorch-ROCm.
+
+Constructor keywords are the reference's (pbf_model.py:32-74) because YAML keys are passed straight
+through (run_pipeline.py:114).  Per step:
+
+  transform    pbf_model.py:252-280   translate / scale / grav_eqvar rotation
+  preprocess   pbf_model.py:303-438   semi-implicit Euler, boundary crop, features, two input CConvs +
+                                      two Dense, multi-scale point sets
+  forward      (subclasses)           HRNet / SymNet / CConv
+  postprocess  pbf_model.py:440-489   output -> position correction, new pos / vel
+  inv_transform pbf_model.py:282-301
+
+Everything particle-sized goes through the HIP library (ContinuousConv -> dmcf_amd.ops); torch does the
+[N,3] elementwise plumbing and the Dense GEMMs.
+"""
+import numpy as np
+import torch
+
+from .. import _lib, ops
+from ..utils.convolutions import ContinuousConv
+from ..utils.tools.losses import get_dilated_pos, get_window_func
+from .base_model import BaseModel, Dense
+
+
+def align_vector(v0, v1):
+    """Rotation taking direction v0 to v1 (pbf_model.py:12-28), Rodrigues form."""
+    v0n = v0 / (torch.linalg.norm(v0) + 1e-9)
+    v1n = v1 / (torch.linalg.norm(v1) + 1e-9)
+    v = torch.linalg.cross(v0n, v1n)
+    c = torch.dot(v0n, v1n)
+    s = torch.linalg.norm(v)
+    if float(s) < 1e-6:
+        return torch.eye(3, device=v0.device) * (-1.0 if float(c) < 0 else 1.0)
+    zero = torch.zeros((), device=v0.device)
+    vx = torch.stack([torch.stack([zero, -v[2], v[1]]), torch.stack([v[2], zero, -v[0]]),
+                      torch.stack([-v[1], v[0], zero])])
+    return torch.eye(3, device=v0.device) + vx + (vx @ vx) / (1 + c)
+
+
+class PBFNet(BaseModel):
+    def __init__(self, name="PBFNet", kernel_size=[4, 4, 4], channels=16, strides=[1], particle_radii=[0.05],
+                 coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear", window=None,
+                 window_dens=None, ignore_query_points=False, grav=-9.81, transformation={}, loss=None,
+                 timestep=0.01, dens_radius=None, circular=False, dens_feats=False, pres_feats=False, equivar=False,
+                 use_vel=True, use_acc=True, use_feats=False, use_box_feats=True, use_pre_adv=False, use_bnds=True,
+                 dens_norm=False, rest_dens=3.5, stiffness=20.0, voxel_size=None, centralize=False,
+                 out_scale=[0.01, 0.01, 0.01], sample_pad=0, sample_hyst=0.1, part_scale=1.0, **kwargs):
+        super().__init__(name=name, **kwargs)
+        if dens_radius is None:
+            dens_radius = particle_radii
+        for flag, val in (("dens_feats", dens_feats), ("pres_feats", pres_feats), ("dens_norm", dens_norm),
+                          ("equivar", equivar)):
+            if val:
+                # False in every shipped config; needs compute_density / PointSampling
+                raise NotImplementedError(f"{flag}=True is outside the MI355X hot path (SURVEY.md section 8f rank 3)")
+        # NN setup (pbf_model.py:79-97)
+        self.kernel_size = kernel_size
+        self.channel = channels
+        self.strides = strides
+        self.particle_radii = particle_radii
+        self.coordinate_mapping = coordinate_mapping
+        self.interpolation = interpolation
+        self.window = window
+        self.ignore_query_points = ignore_query_points
+        self.voxel_size = None if voxel_size is None else np.asarray(voxel_size, dtype=np.float32)
+        self.centralize = centralize
+        self.circular = circular
+        self.transformation = transformation or {}
+        self.sample_pad = sample_pad
+        self.sample_hyst = sample_hyst
+        # feats setup (pbf_model.py:99-115)
+        self.dens_radius = dens_radius
+        self.out_scale = [float(v) for v in out_scale]
+        self.window_dens = window_dens
+        self.use_vel = use_vel
+        self.use_acc = use_acc
+        self.use_feats = use_feats
+        self.use_box_feats = use_box_feats
+        self.use_pre_adv = use_pre_adv
+        self.use_bnds = use_bnds
+        # physics setup (pbf_model.py:117-121)
+        self.timestep = timestep
+        self.grav = grav
+        self.part_scale = part_scale
+        self.num_fluid_neighbors = 1
+
+        self._all_convs = []  # (name, conv) in creation order == checkpoint key order (pbf_model.py:223)
+        self.fluid_convs = self.get_cconv(name="fluid_obs", filters=channels, activation=None,
+                                          window_func=self.window, circular=circular)
+        self.fluid_dense = Dense(units=channels, name="fluid_dense")
+        self.obs_convs = self.get_cconv(name="obs_conv", filters=channels, activation=None,
+                                        window_func=self.window, circular=circular)
+        self.obs_dense = Dense(units=channels, name="obs_dense")
+        if self.use_pre_adv:  # pbf_model.py:154-175
+            self.adv_convs = torch.nn.ModuleList([
+                self.get_cconv(name="adv_conv0", filters=channels, activation=None, window_func=self.window,
+                               circular=circular),
+                self.get_cconv(name="adv_conv1", filters=channels, activation=None, window_func=self.window,
+                               circular=circular)])
+            self.adv_dense = torch.nn.ModuleList([Dense(units=channels, name="adv_dense0"),
+                                                  Dense(units=channels, name="adv_dense1")])
+        self.setup()
+
+    def setup(self):
+        return
+
+    def get_cconv(self, name, kernel_size=None, activation=None, ignore_query_points=None, window_func=None,
+                  normalize=False, **kwargs):
+        """pbf_model.py:197-224: the factory fixing every CConv flag of the hot path."""
+        if kernel_size is None:
+            kernel_size = self.kernel_size
+        if ignore_query_points is None:
+            ignore_query_points = self.ignore_query_points
+        conv = ContinuousConv(name=name, kernel_size=kernel_size, activation=activation, align_corners=True,
+                              interpolation=self.interpolation, coordinate_mapping=self.coordinate_mapping,
+                              normalize=normalize, window_function=get_window_func(window_func),
+                              radius_search_ignore_query_points=ignore_query_points,
+                              use_dense_layer_for_center=False, **kwargs)
+        self._all_convs.append((name, conv))
+        return conv
+
+    def integrate_pos_vel(self, pos1, vel1, acc1=None):
+        """Semi-implicit Euler (pbf_model.py:234-240)."""
+        dt = self.timestep
+        if acc1 is None:
+            acc1 = torch.tensor([0.0, self.grav, 0.0], dtype=torch.float32, device=pos1.device)
+        vel2 = vel1 + dt * acc1
+        pos2 = pos1 + dt * vel2
+        return pos2, vel2
+
+    def compute_new_pos_vel(self, pos1, vel1, pos2, vel2, pos_correction):
+        """pbf_model.py:242-250."""
+        dt = self.timestep
+        pos = pos2 + pos_correction
+        vel = (pos - pos1) / dt
+        return pos, vel
+
+    def transform(self, data, training=True, **kwargs):
+        pos, vel, acc, feats, box, bfeats = data
+        dev = pos.device
+        if "translate" in self.transformation:  # pbf_model.py:255-259
+            translate = torch.tensor(self.transformation["translate"], dtype=torch.float32, device=dev)
+            pos = pos + translate
+            box = box + translate
+        if "scale" in self.transformation:  # :261-267
+            scale = torch.tensor(self.transformation["scale"], dtype=torch.float32, device=dev)
+            pos = pos * scale
+            box = box * scale
+            vel = vel * scale
+            if acc is not None:
+                acc = acc * scale
+        if "grav_eqvar" in self.transformation:  # :269-278
+            grav_eqvar = torch.tensor(self.transformation["grav_eqvar"], dtype=torch.float32, device=dev)
+            self.R = align_vector(grav_eqvar, acc[0])
+            pos, vel, acc, box, bfeats = (x @ self.R for x in (pos, vel, acc, box, bfeats))
+        return [pos, vel, acc, feats, box, bfeats]
+
+    def inv_transform(self, prev, data, **kwargs):
+        pos, vel = prev
+        dev = pos.device
+        if "grav_eqvar" in self.transformation:  # pbf_model.py:285-289
+            R = self.R.t()
+            pos = pos @ R
+            vel = vel @ R
+        if "scale" in self.transformation:  # :291-294
+            scale = torch.tensor(self.transformation["scale"], dtype=torch.float32, device=dev).clamp(min=1e-5)
+            pos = pos / scale
+            vel = vel / scale
+        if "translate" in self.transformation:  # :296-299
+            pos = pos - torch.tensor(self.transformation["translate"], dtype=torch.float32, device=dev)
+        return pos, vel
+
+    def preprocess(self, data, training=True, vel_corr=None, tape=None, **kwargs):
+        _pos, _vel, acc, feats, box, bfeats = data
+        if vel_corr is not None:
+            vel = vel_corr
+            pos = _pos + vel * self.timestep
+        else:
+            pos, vel = self.integrate_pos_vel(_pos, _vel, acc)  # :318
+        filter_extent = [float(np.float32(r) * np.float32(2)) for r in self.particle_radii]  # :328
+        # boundary particles outside the fluid AABB +- 2 r_max are dropped every step (:330-336)
+        lo = pos.min(dim=0).values - filter_extent[-1]
+        hi = pos.max(dim=0).values + filter_extent[-1]
+        fltr = ((box >= lo) & (box <= hi)).all(dim=1)
+        box = box[fltr]
+        bfeats = bfeats[fltr]
+
+        fluid_feats = [torch.ones_like(pos[:, :1])]  # :338-347
+        if self.use_vel:
+            fluid_feats.append(vel)
+        if self.use_acc:
+            if acc is None:
+                raise ValueError("use_acc=True needs per-particle accelerations (pbf_model.py:341-342)")
+            fluid_feats.append(acc)
+        if self.use_feats:
+            fluid_feats.append(feats)
+        box_feats = [torch.ones_like(box[:, :1])]
+        if self.use_box_feats:
+            box_feats.append(bfeats)
+        all_pos = torch.cat([pos, box], dim=0)  # :349
+        self.all_pos = all_pos
+        fluid_feats = torch.cat(fluid_feats, dim=-1)
+        box_feats = torch.cat(box_feats, dim=-1)
+        self.inp_feats = fluid_feats
+        self.inp_bfeats = box_feats
+
+        ans_conv = self.fluid_convs(fluid_feats * self.part_scale, pos, all_pos, filter_extent[0], None)  # :378
+        ans_dense = self.fluid_dense(fluid_feats)
+        ans_obs = self.obs_convs(box_feats * self.part_scale, box, all_pos, filter_extent[0], None)  # :382
+        ans_dense_obs = self.obs_dense(box_feats)
+        ans_dense = torch.cat([ans_dense, ans_dense_obs], dim=0)
+        if self.use_pre_adv:  # :388-399
+            _all_pos = torch.cat([_pos, box], dim=0)
+            pre_adv_feats = torch.ones_like(_pos[:, :1])
+            if self.use_vel:
+                pre_adv_feats = torch.cat([pre_adv_feats, _vel], dim=-1)
+            ans_adv = self.adv_convs[0](pre_adv_feats * self.part_scale, _pos, all_pos, filter_extent[0], None)
+            ans_dens_adv = torch.cat([self.adv_dense[0](pre_adv_feats), ans_dense_obs], dim=0)
+            fluid_feats = torch.cat([ans_conv, ans_obs, ans_adv, ans_dense, ans_dens_adv], dim=-1)
+        else:
+            fluid_feats = torch.cat([ans_conv, ans_obs, ans_dense], dim=-1)  # :411
+
+        dilated_pos, _, idx = get_dilated_pos(all_pos if self.use_bnds else pos, self.strides,
+                                              voxel_size=self.voxel_size, centralize=self.centralize,
+                                              pad=self.sample_pad, hyst=self.sample_hyst)  # :413-419
+        self.dilated_pos = dilated_pos
+        return [dilated_pos, fluid_feats, idx, None]
+
+    def postprocess(self, prev, data, training=True, vel_corr=None, **kwargs):
+        pos, vel, acc = data[:3]
+        pcnt = pos.shape[0]
+        # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
+        nns = self.fluid_convs.nns
+        counts = torch.empty(nns.neighbors_row_splits.shape[0] - 1, dtype=torch.float32, device=pos.device)
+        _lib.check(_lib.lib().dmcf_reduce_subarrays_sum(None, ops._ptr(nns.neighbors_row_splits), counts.shape[0],
+                                                        ops._ptr(counts), ops._stream()), "dmcf_reduce_subarrays_sum")
+        self.num_fluid_neighbors = counts[:pcnt]
+
+        out = prev
+        if out.shape[-1] == 1:  # :466-469
+            out = out.repeat(1, 3)
+        elif out.shape[-1] == 2:
+            out = torch.cat([out, out[:, :1]], dim=-1)
+        out_scale = torch.tensor(self.out_scale, dtype=torch.float32, device=pos.device)
+        self.pos_correction = out_scale * out[:pcnt]  # :474
+        self.obs = out_scale * out[pcnt:]
+        if vel_corr is not None:
+            vel2 = vel_corr
+            pos2 = pos + vel2 * self.timestep
+        else:
+            pos2, vel2 = self.integrate_pos_vel(pos, vel, acc)  # :484
+        pos2_corrected, vel2_corrected = self.compute_new_pos_vel(pos, vel, pos2, vel2, self.pos_correction)
+        return [pos2_corrected, vel2_corrected]

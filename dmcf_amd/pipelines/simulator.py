@@ -1,0 +1,83 @@
+"""Simulator -- mirror of the inference surface of the reference's ``pipelines/simulator.py:37-109``.
+
+``run_inference(inputs)`` (simulator.py:57-71) takes a list of per-scene input lists
+``[pos, vel, acc|None, feats|None, box, box_normals]`` and returns ``[pos', vel'] + inputs[2:]`` per scene so
+the result is fed back verbatim; ``run_rollout(inputs, timesteps)`` (:73-109) loops it.  The reference has
+no ``step()``; it is provided as an alias because BASELINE.json names that surface.
+
+Training / validation / HDF5 writing are out of scope of the hot path.  The number of particles may change
+between steps (run_sample.py:173-177 adds inflow), so nothing here assumes a fixed N.
+"""
+import logging
+import time
+
+import numpy as np
+import torch
+
+from ..utils.config import Config
+from ..utils.convolutions import neighbor_cache
+
+log = logging.getLogger(__name__)
+
+
+class Simulator:
+    def __init__(self, model, dataset=None, name="Simulator", main_log_dir="./logs/", device="cuda", split="train",
+                 **kwargs):
+        self.cfg = Config(dict(kwargs, name=name, main_log_dir=main_log_dir, device=device, split=split))
+        self.name = name
+        self.model = model
+        self.dataset = dataset
+        if device in ("gpu", "cuda"):
+            device = "cuda"
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the DMCF hot path runs on the GPU only (no CPU fallback)")
+        self.timing = []
+
+    def _to_device(self, x):
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        return x.to(self.device, dtype=torch.float32)
+
+    @torch.no_grad()
+    def run_inference(self, inputs):
+        """simulator.py:57-71."""
+        results = []
+        for bi in range(len(inputs)):
+            with neighbor_cache():
+                pos, vel = self.model(inputs[bi], training=False)
+            results.append([pos, vel] + list(inputs[bi][2:]))
+        return results
+
+    def step(self, inputs):
+        """Alias of :meth:`run_inference` (one simulated time step)."""
+        return self.run_inference(inputs)
+
+    @torch.no_grad()
+    def run_rollout(self, inputs, timesteps=2):
+        """simulator.py:73-109.  ``inputs``: list of dicts with [T,N,3] arrays ``pos, vel, grav, box,
+        box_normals`` (frame 0 is used), as produced by get_rollout (dataset_reader_physics.py:410-456)."""
+        inputs = [[self._to_device(data["pos"][0]), self._to_device(data["vel"][0]),
+                   self._to_device(data["grav"][0]) if data.get("grav") is not None and data["grav"][0] is not None
+                   else None, None, self._to_device(data["box"][0]), self._to_device(data["box_normals"][0])]
+                  for data in inputs]
+        results = [[] for _ in range(len(inputs))]
+        self.run_inference(inputs[:1])  # "dummy init": builds the lazily created weights (simulator.py:94)
+        timing = []
+        for i in range(len(inputs)):
+            results[i].append(inputs[i])
+        for _ in range(timesteps - 1):
+            torch.cuda.synchronize(self.device)
+            start = time.time()
+            for i in range(len(inputs)):
+                inputs[i] = self.run_inference(inputs[i:i + 1])[0]
+            torch.cuda.synchronize(self.device)
+            timing.append(time.time() - start)
+            for i in range(len(inputs)):
+                results[i].append(inputs[i])
+        self.timing = timing
+        if timing:
+            log.info("Average runtime: %.05f" % (np.mean(timing) / len(inputs)))
+        return results

@@ -1,0 +1,271 @@
+"""ContinuousConv layer -- mirror of the reference's ``utils/convolutions.py:34-473`` on PyTorch-ROCm.
+
+Same constructor keywords (convolutions.py:150-175), same ``call`` signature (:277-286), same side
+attributes read by callers (``.nns``, ``._avg_neighbors``, ``._conv_values``, ``._conv_output``), same
+weight names (``kernel``, ``bias``), so the model code and configs of the reference drop onto it.
+What differs is underneath: the radius search, the window function, the CConv itself and the whole
+ASCC body (mirror + two continuous_conv calls + batched matmul, :410-412,:433-458) are one HIP
+search + one HIP kernel launch each (dmcf_amd/ops.py -> libdmcf_hip.so).
+
+Inference only: the layer does not record autograd history (training is out of scope, SURVEY.md
+section 2 row 16).
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .tools.losses import WindowFunction
+
+__all__ = ["ContinuousConv", "neighbor_cache"]
+
+
+class _NeighborCache:
+    """Per-step reuse of neighbour lists and grids.
+
+    The reference runs its own FixedRadiusSearch inside every ContinuousConv.call
+    (convolutions.py:354-358), 18/27/43 searches per step of which only 12/12/19 are distinct
+    (SURVEY.md section 3.2).  Inside ``with neighbor_cache():`` a search is keyed by
+    (points, queries, radius, ignore_query_point) -- tensors by storage identity -- and computed once;
+    the cell-sorted grid of a point set is shared between searches with the same radius.
+    Results are identical to searching again (same inputs, deterministic kernel)."""
+
+    def __init__(self):
+        self.depth = 0
+        self.lists = {}
+        self.tables = {}
+        self.keepalive = []
+
+    def __enter__(self):
+        self.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        self.depth -= 1
+        if self.depth == 0:
+            self.lists.clear()
+            self.tables.clear()
+            self.keepalive.clear()
+        return False
+
+    @staticmethod
+    def _key(t):
+        return (t.data_ptr(), tuple(t.shape), t._version)
+
+    def search(self, frs, points, queries, radius):
+        if self.depth == 0:
+            return frs(points, queries, radius)
+        points = points.contiguous()
+        queries = queries.contiguous()
+        tkey = (self._key(points), float(radius))
+        key = (tkey, self._key(queries), frs.ignore_query_point, frs.return_distances)
+        hit = self.lists.get(key)
+        if hit is not None:
+            return hit
+        table = self.tables.get(tkey)
+        if table is None or table.n_queries_capacity < queries.shape[0]:
+            table = ops.build_spatial_hash_table(points, radius, n_queries=max(points.shape[0], queries.shape[0]))
+            self.tables[tkey] = table
+        res = frs(points, queries, radius, hash_table=table)
+        self.lists[key] = res
+        self.keepalive.append((points, queries))  # keep storage alive so data_ptr keys stay unique
+        return res
+
+
+_CACHE = _NeighborCache()
+
+
+def neighbor_cache():
+    """Context manager enabling per-step neighbour-list reuse (see :class:`_NeighborCache`)."""
+    return _CACHE
+
+
+def _init_tensor(name, shape, device):
+    """Keras initializer strings used by the reference: 'uniform' = RandomUniform(-0.05, 0.05)
+    (convolutions.py:156), 'zeros' (:157), 'glorot_uniform' (:169)."""
+    if callable(name):
+        return name(shape).to(device)
+    if name == "uniform":
+        return torch.empty(shape, device=device).uniform_(-0.05, 0.05)
+    if name == "zeros":
+        return torch.zeros(shape, device=device)
+    if name == "glorot_uniform":
+        fan_in, fan_out = shape[-2] * int(np.prod(shape[:-2])), shape[-1] * int(np.prod(shape[:-2]))
+        limit = math.sqrt(6.0 / (fan_in + fan_out))
+        return torch.empty(shape, device=device).uniform_(-limit, limit)
+    raise NotImplementedError(f"initializer {name!r}")
+
+
+_ACTIVATIONS = {None: None, "linear": None, "relu": torch.relu, "tanh": torch.tanh}
+
+
+class ContinuousConv(torch.nn.Module):
+    r"""Continuous convolution of Ummenhofer & Koltun (ICLR 2020) with DMCF's antisymmetric option:
+
+        (f*g)(x) = 1/psi(x) * sum_{i in N(x,R)} a(x_i, x) f_i g(Lambda(x_i - x))
+
+    Arguments are those of the reference layer (utils/convolutions.py:67-149).  Unsupported
+    combinations raise instead of silently computing something else.
+    """
+
+    def __init__(self, filters, kernel_size, activation=None, use_bias=True, kernel_initializer="uniform",
+                 bias_initializer="zeros", kernel_regularizer=None, bias_regularizer=None, align_corners=True,
+                 coordinate_mapping="ball_to_cube_radial", interpolation="linear", normalize=True,
+                 radius_search_ignore_query_points=False, radius_search_metric="L2", offset=None,
+                 window_function=None, use_dense_layer_for_center=False,
+                 dense_kernel_initializer="glorot_uniform", dense_kernel_regularizer=None, in_channels=None,
+                 symmetric=False, sym_axis=2, circular=False, name=None, trainable=True, device=None, **kwargs):
+        super().__init__()
+        self.layer_name = name
+        self.filters = filters
+        self.kernel_size = [int(k) for k in kernel_size]
+        if activation not in _ACTIVATIONS and not callable(activation):
+            raise NotImplementedError(f"activation {activation!r}")
+        self.activation = _ACTIVATIONS.get(activation, activation) if not callable(activation) else activation
+        self.use_bias = use_bias
+        self.kernel_initializer = kernel_initializer
+        self.bias_initializer = bias_initializer
+        self.align_corners = align_corners
+        if coordinate_mapping not in ops.MAPPINGS:
+            raise ValueError(f"coordinate_mapping {coordinate_mapping!r}")
+        if interpolation not in ops.INTERPOLATIONS:
+            raise ValueError(f"interpolation {interpolation!r}")
+        self.coordinate_mapping = coordinate_mapping
+        self.interpolation = interpolation
+        self.normalize = normalize
+        self.radius_search_ignore_query_points = radius_search_ignore_query_points
+        self.radius_search_metric = radius_search_metric
+        self.dense_kernel_initializer = dense_kernel_initializer
+        self.symmetric = symmetric
+        self.sym_axis = sym_axis
+        self.circular = circular
+        if offset is not None and any(float(o) != 0.0 for o in torch.as_tensor(offset).reshape(-1)):
+            raise NotImplementedError("non-zero offset (never used by DMCF, convolutions.py:200-201)")
+        self.offset = torch.zeros(3)
+        self.window_function = window_function
+        # convolutions.py:207-210
+        self.fixed_radius_search = ops.FixedRadiusSearch(
+            metric=self.radius_search_metric, ignore_query_point=self.radius_search_ignore_query_points,
+            return_distances=self.window_function is not None)
+        self.use_dense_layer_for_center = use_dense_layer_for_center
+        self.dense = None
+        self.in_channels = None
+        self.kernel = None
+        self.bias = None
+        self._device = device
+        self.nns = None
+
+    # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
+    def build(self, in_channels, device=None):
+        device = device or self._device or "cuda"
+        self.in_channels = int(in_channels)
+        if self.circular:
+            kshape = (math.ceil(max(self.kernel_size) / 2), self.in_channels, self.filters)  # :231-234
+        elif self.symmetric:
+            sh = list(self.kernel_size)
+            assert sh[self.sym_axis] % 2 == 0  # :244
+            sh[self.sym_axis] = sh[self.sym_axis] // 2
+            kshape = (*sh, self.in_channels, self.filters)
+        else:
+            kshape = (*self.kernel_size, self.in_channels, self.filters)
+        self.kernel = torch.nn.Parameter(_init_tensor(self.kernel_initializer, kshape, device), requires_grad=False)
+        if self.use_bias:
+            self.bias = torch.nn.Parameter(_init_tensor(self.bias_initializer, (self.filters,), device),
+                                           requires_grad=False)
+        if self.use_dense_layer_for_center:
+            w = _init_tensor(self.dense_kernel_initializer, (self.in_channels, self.filters), device)
+            self.dense = torch.nn.Parameter(w, requires_grad=False)
+
+    def _expanded_kernel(self):
+        """circular kernels (convolutions.py:395-409): ring index = max_axis floor(|grid offset|)."""
+        ks = self.kernel_size
+        zr, yr, xr = torch.meshgrid(*[torch.arange(k, device=self.kernel.device) for k in ks], indexing="ij")
+        size_xyz = torch.tensor(ks[::-1], dtype=torch.float32, device=self.kernel.device)
+        gp = torch.stack([xr, yr, zr], dim=-1).to(torch.float32) - size_xyz / 2.0 + 0.5
+        mask = (gp * 2.0) / size_xyz
+        idx = torch.floor(gp.abs()).max(dim=-1).values.to(torch.int64)
+        kernel = self.kernel[idx]
+        if self.symmetric:
+            # NOTE: the reference multiplies by mask[..., None, :] (shape [D,H,W,1,3]), which only
+            # broadcasts when filters == 3 (convolutions.py:408-409)
+            kernel = kernel * mask.unsqueeze(-2)
+        return kernel
+
+    @torch.no_grad()
+    def forward(self, inp_features, inp_positions, out_positions, extents, inp_importance=None,
+                fixed_radius_search_hash_table=None, user_neighbors_index=None, user_neighbors_row_splits=None,
+                user_neighbors_importance=None):
+        if self.kernel is None:
+            self.build(inp_features.shape[-1], inp_features.device)
+        if isinstance(extents, torch.Tensor):
+            if extents.dim() > 0 and extents.numel() != 1:
+                raise NotImplementedError("per-point extents (RadiusSearch, convolutions.py:366-370) are never "
+                                          "used by DMCF and not implemented")
+            extent = float(extents)
+        else:
+            extent = float(np.float32(extents))
+        window, window_fac, neighbors_value = None, 1.0, None
+        if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :341-349
+            neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
+            if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
+                window, neighbors_value = "explicit", user_neighbors_importance
+        else:
+            radius = float(np.float32(0.5) * np.float32(extent))  # :353
+            if fixed_radius_search_hash_table is not None:
+                self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
+                                                    hash_table=fixed_radius_search_hash_table)
+            else:
+                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
+            neighbors_index, neighbors_row_splits = self.nns.neighbors_index, self.nns.neighbors_row_splits
+            if self.window_function is not None:  # :359-379
+                if isinstance(self.window_function, WindowFunction):
+                    window, window_fac = self.window_function.name, self.window_function.fac
+                    neighbors_value = self.nns.neighbors_distance  # d^2; q = d^2/R^2 is formed in the kernel
+                else:
+                    q = self.nns.neighbors_distance / (np.float32(radius) * np.float32(radius))
+                    window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
+        # stats (convolutions.py:385-388); a 0-dim device tensor, no host sync
+        n_out = out_positions.shape[0]
+        self._avg_neighbors = neighbors_index.shape[0] / max(n_out, 1)
+
+        kernel = self.kernel
+        symmetric = self.symmetric
+        if self.circular:
+            kernel = self._expanded_kernel()
+            symmetric = False  # the mask already made it antisymmetric; second pass still applies below
+            if self.symmetric:
+                raise NotImplementedError("circular + symmetric kernels (filters must be 3 in the reference; "
+                                          "no shipped config uses circular: True)")
+        self._conv_values = {
+            "filters": kernel, "out_positions": out_positions, "extents": extent, "offset": self.offset,
+            "inp_positions": inp_positions, "inp_features": inp_features, "inp_importance": inp_importance,
+            "neighbors_index": neighbors_index, "neighbors_row_splits": neighbors_row_splits,
+            "neighbors_importance": neighbors_value, "align_corners": self.align_corners,
+            "coordinate_mapping": self.coordinate_mapping, "interpolation": self.interpolation,
+            "normalize": self.normalize,
+        }
+        if symmetric and self.normalize:
+            raise NotImplementedError("symmetric=True with normalize=True (DMCF always uses normalize=False, "
+                                      "models/pbf_model.py:203)")
+        fuse_bias = self.use_bias and not self.use_dense_layer_for_center
+        out_features = ops.cconv_forward(
+            kernel, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
+            neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
+            align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
+            interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
+            bias=self.bias if fuse_bias else None)
+        self._conv_output = out_features
+        if self.use_dense_layer_for_center:  # :462-464
+            self._dense_output = inp_features @ self.dense
+            out_features = out_features + self._dense_output
+            if self.use_bias:
+                out_features = out_features + self.bias
+        if self.activation is not None:
+            out_features = self.activation(out_features)
+        return out_features
+
+    call = forward
+
+    def compute_output_shape(self, inp_features_shape):
+        return (None, self.filters)

@@ -1,0 +1,120 @@
+"""Window functions and multi-scale point sets -- mirror of the hot-path part of the reference's
+``utils/tools/losses.py`` (same function names and arguments).
+
+  get_window_func   losses.py:8-44     poly6 / cubic / linear / peak / cubic_grad on q = d^2/R^2
+  grid_pos          losses.py:136-181  dilated voxel-corner lattice, de-duplicated (tf.unique order)
+  get_dilated_pos   losses.py:249-284  one point set per stride (voxel_size path)
+
+Losses / density helpers (losses.py:47-110, 287-414) are training / validation only and out of
+scope for the inference hot path.
+"""
+import numpy as np
+import torch
+
+
+class WindowFunction:
+    """Callable returned by :func:`get_window_func`.
+
+    Calling it on a tensor of normalised squared distances evaluates the formula with torch (generic
+    use, e.g. user code).  ``ContinuousConv`` recognises the object and instead passes ``name`` /
+    ``fac`` to the HIP kernel, which evaluates the same formula per neighbour inside the splat
+    (dmcf_amd/csrc/cconv.hip: window_value) so no [P]-sized importance array is materialised.
+    """
+
+    def __init__(self, name, fac=1.0):
+        self.name = name
+        self.fac = float(fac)
+
+    def __call__(self, q):
+        fac = self.fac
+        if self.name == "poly6":  # losses.py:11-12
+            return fac * torch.clamp((1 - q) ** 3, 0, 1)
+        if self.name == "cubic":  # losses.py:15-20
+            s = torch.sqrt(q)
+            inner = torch.where(s <= 0.5, 6 * (s ** 3 - q) + 1, 2 * (1 - s) ** 3)
+            return fac * 4 / 3 * torch.where(q <= 1, inner, torch.zeros_like(s))
+        if self.name == "linear":  # losses.py:23-25
+            return fac * (1 - torch.sqrt(q))
+        if self.name == "peak":  # losses.py:28-30
+            return fac * (1 - 2 * torch.sqrt(q) + q)
+        if self.name == "cubic_grad":  # losses.py:33-39
+            s = torch.sqrt(q)
+            inner = torch.where(s <= 0.5, 18 * q - 12 * s, -6 * (1 - s) ** 2)
+            return fac * 4 / 3 * torch.where(q <= 1, inner, torch.zeros_like(s))
+        raise NotImplementedError(self.name)
+
+    def __repr__(self):
+        return f"WindowFunction({self.name!r}, fac={self.fac})"
+
+
+def get_window_func(typ, fac=1.0, **kwargs):
+    """losses.py:8-44.  ``typ is None`` -> None (no window), unknown -> NotImplementedError."""
+    if typ is None:
+        return None
+    if typ in ("poly6", "cubic", "linear", "peak", "cubic_grad"):
+        return WindowFunction(typ, fac)
+    raise NotImplementedError()
+
+
+def _unique_first_occurrence(idx):
+    """tf.unique(idx)[0]: unique values in order of first appearance (losses.py:171)."""
+    uniq, inverse = torch.unique(idx, sorted=True, return_inverse=True)
+    first = torch.full((uniq.shape[0],), idx.shape[0], dtype=torch.int64, device=idx.device)
+    first.scatter_reduce_(0, inverse, torch.arange(idx.shape[0], device=idx.device), reduce="amin")
+    return uniq[torch.argsort(first)]
+
+
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1):
+    """losses.py:136-181: lattice corners of the voxels (edge ``voxel_size``) that contain a particle,
+    with +-``hyst`` hysteresis; axes with voxel_size < 1e-5 collapse (2-D / 1-D scenes)."""
+    # voxel_size is kept on the host (list / numpy float32) so that the axis collapse test does not
+    # force a device round trip; values are float32 like the reference's tf.constant
+    vs_host = np.asarray(voxel_size.detach().cpu() if isinstance(voxel_size, torch.Tensor) else voxel_size,
+                         dtype=np.float32).reshape(3)
+    voxel_size = torch.from_numpy(vs_host.copy()).to(pos.device)
+    center = None
+    if centralize:
+        center = pos.mean(dim=0)  # :138
+        pos = pos - center
+    active = voxel_size >= 1e-5
+    vs = torch.clamp(voxel_size, min=1e-5)
+    h = torch.where(active, torch.full_like(vs, hyst), torch.zeros_like(vs))
+    scaled = pos / vs
+    dpos = torch.cat([torch.floor(scaled - h).to(torch.int32), torch.floor(scaled + h).to(torch.int32)], dim=0)  # :142-150
+    active_host = (vs_host >= 1e-5).tolist()
+    ranges = [torch.arange(-pad, 2 + pad, device=pos.device) if a else torch.arange(0, 1, device=pos.device)
+              for a in active_host]  # :151-161
+    offset = torch.stack(torch.meshgrid(*ranges, indexing="ij"), dim=-1).reshape(1, -1, 3).to(torch.int32)
+    dpos = (dpos.unsqueeze(1) + offset).reshape(-1, 3)
+    minp = dpos.min(dim=0).values  # :167-170
+    maxp = dpos.max(dim=0).values - minp + 1
+    maxp64 = maxp.to(torch.int64)
+    mult = torch.stack([torch.ones_like(maxp64[0]), maxp64[0], maxp64[0] * maxp64[1]])
+    idx = ((dpos - minp).to(torch.int64) * mult).sum(dim=-1)
+    idx = _unique_first_occurrence(idx)  # :171
+    gpos = torch.stack([idx % maxp64[0], idx // maxp64[0] % maxp64[1], idx // (maxp64[0] * maxp64[1])], dim=-1) \
+        + minp.to(torch.int64)  # :172-174
+    if centralize:
+        return gpos.to(torch.float32) * voxel_size + center  # :177
+    return gpos.to(torch.float32) * voxel_size + voxel_size / 2  # :179
+
+
+def get_dilated_pos(pos, strides, voxel_size=None, centralize=False, pad=0, hyst=0.1):
+    """losses.py:249-284 -> (dilated_pos, pcnt, idx).  Every coarse level is computed from the
+    full-resolution set (:268).  The farthest-point-sampling branch (voxel_size is None, :274-282) needs
+    the reference's FPS custom op and is not on the path of any shipped multi-scale config."""
+    pcnt, dilated_pos, idx = [], [], []
+    for stride in strides:
+        if stride == 1:
+            pcnt.append(pos.shape[0])
+            dilated_pos.append(pos)
+            idx.append(None)
+        else:
+            if voxel_size is None:
+                raise NotImplementedError("strides > 1 without voxel_size need farthest point sampling "
+                                          "(utils/tools/sampling.cu), which is out of scope (SURVEY.md section 8f rank 4)")
+            vs = voxel_size.detach().cpu().numpy() if isinstance(voxel_size, torch.Tensor) else voxel_size
+            v_scale = np.asarray(vs, dtype=np.float32) * np.float32(stride)  # :266
+            dilated_pos.append(grid_pos(pos, v_scale, centralize=centralize, pad=pad, hyst=hyst))
+            pcnt.append(dilated_pos[-1].shape[0])
+    return dilated_pos, pcnt, idx

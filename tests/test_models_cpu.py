@@ -1,0 +1,102 @@
+"""CPU tests of the host logic: configs, checkpoint reader, model construction (no GPU compute)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+REF = "/root/reference"
+
+
+def test_config_dicts_match_reference_yaml():
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present (GPU box)")
+    from dmcf_amd.utils.config import Config
+    from tools import configs
+    for name, d in configs.BY_NAME.items():
+        cfg = Config.load_from_file(os.path.join(REF, "configs", name + ".yml"))
+        for k, v in d.items():
+            assert cfg.model[k] == v, (name, k)
+
+
+def test_config_cli_overrides():
+    from dmcf_amd.utils.config import Config
+    cfg = Config(dict(dataset=dict(dataset_path=None), model=dict(timestep=0.02, use_acc=False, strides=[1, 2]),
+                      pipeline=dict(version="3d")))
+    d, p, m = Config.merge_cfg_file(cfg, dict(dataset_path="/data", ckpt_path="ck"),
+                                    {"model.timestep": "0.01", "model.use_acc": "true", "model.strides": "[1, 2, 4]"})
+    assert d["dataset_path"] == "/data" and m["ckpt_path"] == "ck"
+    assert m["timestep"] == 0.01 and m["use_acc"] is True and m["strides"] == [1, 2, 4]
+
+
+@pytest.mark.parametrize("name,n_convs", [("Liquid3d", 18), ("WaterRamps", 27), ("WBC-SPH", 43)])
+def test_architecture_matches_checkpoint_index(name, n_convs):
+    """Golden check against the reference's own checkpoint indices (tests/golden/ckpt_shapes.json): the layer
+    list built from the config has exactly the variables / shapes the shipped checkpoints hold."""
+    from dmcf_amd import models
+    from dmcf_amd.utils import tf_checkpoint as tc
+    from tools import configs, scenes
+    shapes = json.load(open(os.path.join(GOLDEN, "ckpt_shapes.json")))[name]
+    cfg = configs.BY_NAME[name]
+    model = getattr(models, cfg["name"])(**cfg)
+    assert len(model._all_convs) == n_convs
+    w = scenes.random_weights(cfg)
+    assert {k: list(v.shape) for k, v in w.items()} == shapes  # same keys, same shapes
+    assert tc.load_into_model(model, w, device="cpu") == len([k for k in shapes if k.endswith("/kernel")])
+
+
+def test_tf_checkpoint_reader_on_reference_blob():
+    if not os.path.isdir(REF):
+        pytest.skip("reference tree not present (GPU box)")
+    from dmcf_amd.utils import tf_checkpoint as tc
+    w = tc.load_checkpoint(os.path.join(REF, "checkpoints/Liquid3d/ckpt"))
+    model_vars = {k: v for k, v in w.items() if k.startswith("model/")}
+    assert sum(v.size for v in model_vars.values()) == 275084
+    assert all(np.isfinite(v).all() for v in model_vars.values())
+    fix = np.load(os.path.join(GOLDEN, "liquid3d_weights.npz"))
+    assert sorted(fix.files) == sorted(model_vars)
+    for k in fix.files:
+        np.testing.assert_array_equal(fix[k], model_vars[k])
+    assert int(w["optimizer/iter"]) == 51000
+
+
+def test_box_scene_generator():
+    from tools import scenes
+    s = scenes.box_scene(10)
+    assert s["pos"].shape == (1000, 3) and s["box"].shape == (14 ** 3 - 10 ** 3, 3)
+    np.testing.assert_allclose(np.linalg.norm(s["box_normals"], axis=1), 1, atol=1e-6)
+    s2 = scenes.box_scene(10, dim=2)
+    assert s2["pos"].shape == (100, 3) and np.all(s2["pos"][:, 2] == 0) and s2["box"].shape == (14 ** 2 - 100, 3)
+
+
+def test_window_functions_match_oracle(oracle):
+    import torch
+    from dmcf_amd.utils.tools.losses import get_window_func
+    q = np.linspace(0, 1.2, 50).astype(np.float32)
+    for typ in ("poly6", "cubic", "linear", "peak", "cubic_grad"):
+        w = get_window_func(typ)(torch.from_numpy(q)).numpy()
+        np.testing.assert_allclose(w, oracle.window(typ, q), atol=1e-6)
+    assert get_window_func(None) is None
+    with pytest.raises(NotImplementedError):
+        get_window_func("gauss")
+
+
+def test_grid_pos_matches_oracle(oracle):
+    import torch
+    from dmcf_amd.utils.tools.losses import grid_pos, get_dilated_pos
+    rng = np.random.default_rng(0)
+    pos = rng.uniform(-1, 1, size=(3000, 3)).astype(np.float32)
+    for vs, cen in (([0.1, 0.1, 0.1], True), ([0.1, 0.1, 0.1], False), ([0.05, 0.05, 0.0], True), ([0.0, 0.02, 0.0], True)):
+        p = pos.copy()
+        for a in range(3):
+            if vs[a] == 0:
+                p[:, a] = 0
+        g = grid_pos(torch.from_numpy(p), vs, centralize=cen).numpy()
+        ref = oracle.grid_pos(p, vs, centralize=cen)
+        assert g.shape == ref.shape
+        # same lattice points in the same (first occurrence) order; centre may differ by float rounding of the mean
+        np.testing.assert_allclose(g, ref, atol=2e-6)
+    d, cnt, idx = get_dilated_pos(torch.from_numpy(pos), [1, 2, 4], voxel_size=[0.05, 0.05, 0.05], centralize=True)
+    assert cnt[0] == 3000 and cnt[1] > cnt[2] and idx == [None]

@@ -1,0 +1,117 @@
+"""Synthetic scenes for the parity tests and bench.py (SURVEY.md section 8d / BASELINE.md "Inputs").
+
+The reference's datasets are not in the tree (download scripts, no network), so the benchmark
+configurations use seeded synthetic stand-ins with the real network architectures.
+"""
+import numpy as np
+
+
+def box_scene(side, h=0.05, jitter=0.1, vel_std=0.1, shell_layers=2, seed=0, dim=3, origin=(0.0, 0.0, 0.0)):
+    """Config 5 ("synthetic 3-D box"): a cube of side^3 fluid particles on a jittered lattice of spacing h
+    (jitter U(-jitter*h, jitter*h), default_rng(seed)), velocities N(0, vel_std^2) (default_rng(seed+1)),
+    enclosed by a closed shell of ``shell_layers`` lattice layers of boundary particles with inward normals.
+    dim=2 gives the planar analogue (z = 0).  Returns dict(pos, vel, box, box_normals) float32."""
+    rng = np.random.default_rng(seed)
+    ax = (np.arange(side, dtype=np.float64) + 0.5) * h
+    axes = [ax, ax, ax if dim == 3 else np.zeros(1)]
+    pos = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    jit = rng.uniform(-jitter * h, jitter * h, size=pos.shape)
+    if dim == 2:
+        jit[:, 2] = 0
+    pos = pos + jit
+    vel = np.random.default_rng(seed + 1).normal(0.0, vel_std, size=pos.shape)
+    if dim == 2:
+        vel[:, 2] = 0
+    L = shell_layers
+    bx = (np.arange(-L, side + L, dtype=np.float64) + 0.5) * h
+    baxes = [bx, bx, bx if dim == 3 else np.zeros(1)]
+    grid = np.stack(np.meshgrid(*baxes, indexing="ij"), -1).reshape(-1, 3)
+    gi = np.stack(np.meshgrid(*[np.arange(-L, side + L) if (dim == 3 or a < 2) else np.zeros(1, dtype=np.int64)
+                                for a in range(3)], indexing="ij"), -1).reshape(-1, 3)
+    nd = 3 if dim == 3 else 2
+    outside_lo = gi[:, :nd] < 0
+    outside_hi = gi[:, :nd] >= side
+    is_shell = (outside_lo | outside_hi).any(axis=1)
+    box = grid[is_shell]
+    normals = np.zeros_like(box)
+    normals[:, :nd] = outside_lo[is_shell].astype(np.float64) - outside_hi[is_shell].astype(np.float64)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    o = np.asarray(origin, dtype=np.float64)
+    return dict(pos=(pos + o).astype(np.float32), vel=vel.astype(np.float32), box=(box + o).astype(np.float32),
+                box_normals=normals.astype(np.float32))
+
+
+def model_inputs(scene, device=None, grav=None):
+    """[pos, vel, acc|None, feats|None, box, box_normals] as the Simulator feeds the model
+    (pipelines/simulator.py:83-90).  numpy arrays, or torch tensors on ``device``."""
+    acc = None
+    if grav is not None:
+        acc = np.broadcast_to(np.asarray(grav, dtype=np.float32), scene["pos"].shape).copy()
+    data = [scene["pos"], scene["vel"], acc, None, scene["box"], scene["box_normals"]]
+    if device is None:
+        return data
+    import torch
+    return [None if x is None else torch.from_numpy(np.ascontiguousarray(x)).to(device) for x in data]
+
+
+def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
+    """Seeded stand-in weights U(lo, hi) in the reference's checkpoint key layout, for the architectures whose
+    trained blobs are absent (.MISSING_LARGE_BLOBS: WaterRamps, WBC-SPH).  Shapes follow the constructors
+    (models/pbf_model.py:134-152, models/hrnet.py:39-67, models/sym_net.py:42-53, models/cconv.py:36-49)."""
+    rng = np.random.default_rng(seed)
+    c = dict(model_cfg)
+    ks = list(c.get("kernel_size", [4, 4, 4]))
+    name = c.get("name", "SymNet")
+    lc = c["layer_channels"]
+    w = {}
+
+    def conv(key, cin, cout, kernel=ks, bias=True):
+        w[key + "/kernel"] = rng.uniform(lo, hi, size=(*kernel, cin, cout)).astype(np.float32)
+        if bias:
+            w[key + "/bias"] = rng.uniform(lo, hi, size=(cout,)).astype(np.float32)
+
+    def dense(key, cin, cout):
+        w[key + "/kernel"] = rng.uniform(-0.3, 0.3, size=(cin, cout)).astype(np.float32)
+        w[key + "/bias"] = rng.uniform(lo, hi, size=(cout,)).astype(np.float32)
+
+    n_fluid = fluid_channels or (1 + (3 if c.get("use_vel", True) else 0) + (3 if c.get("use_acc", True) else 0))
+    n_box = 1 + (3 if c.get("use_box_feats", True) else 0)
+    if name == "CConv":
+        ch0 = lc[0]
+        conv("model/fluid_convs", n_fluid, ch0)
+        dense("model/fluid_dense", n_fluid, ch0)
+        conv("model/obs_convs", n_box, ch0)
+        dense("model/obs_dense", n_box, ch0)
+        cin = 3 * ch0
+        for i in range(1, len(lc)):
+            conv(f"model/_all_convs/{i + 1}/1", cin, lc[i])
+            dense(f"model/denses/{i - 1}", cin, lc[i])
+            cin = lc[i]
+        return w
+    trunk = lc[:-1] if name == "SymNet" else lc
+    ch0 = trunk[0][0][0]
+    conv("model/fluid_convs", n_fluid, ch0)
+    dense("model/fluid_dense", n_fluid, ch0)
+    conv("model/obs_convs", n_box, ch0)
+    dense("model/obs_dense", n_box, ch0)
+    idx = 2
+    prev = [3 * ch0]
+    for i in range(1, len(trunk)):
+        cur = []
+        for j in range(len(trunk[i])):
+            ch = trunk[i][j][0]
+            for l in range(len(prev)):
+                conv(f"model/_all_convs/{idx}/1", prev[l], ch)
+                idx += 1
+                if l == j:
+                    dense(f"model/denses/{i - 1}/{j}/0/{l}", prev[l], ch)
+            cur.append(ch)
+        prev = cur
+    if name == "SymNet":
+        sk = list(c.get("sym_kernel_size", [6, 6, 6]))
+        sk[c.get("sym_axis", 2)] //= 2
+        cin = prev[0]
+        for i, ch in enumerate(lc[-1][-1]):
+            conv(f"model/sym_convs/{i}", cin, ch, kernel=sk, bias=False)
+            cin = ch
+    return w
