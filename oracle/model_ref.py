@@ -74,6 +74,7 @@ class ModelRef:
         self._alias = {}
         self.nns_cache = {}
         self.pairs = 0
+        self.record = None  # set to [] to record every CConv call (inputs + output) of the next step
 
     # ---- weights --------------------------------------------------------------------------------
     def _conv_weights(self, index, alias=None):
@@ -100,6 +101,10 @@ class ModelRef:
                                    interpolation=self.interpolation, f64=self.f64)
         out = conv(feats, inp_pos, out_pos, f32(extent), nns=nns)
         self.last_nns = nns
+        if self.record is not None:
+            self.record.append(dict(index=index, kernel=kernel, bias=None if symmetric else bias, feats=feats,
+                                    inp_pos=inp_pos, out_pos=out_pos, extent=float(extent), window=window,
+                                    ignore=ignore, symmetric=symmetric, nns=nns, out=out))
         return out
 
     # ---- stages ---------------------------------------------------------------------------------

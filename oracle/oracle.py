@@ -271,7 +271,10 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1):
     voxel_size = _f32(voxel_size).reshape(3)
     center = None
     if centralize:
-        center = (pos.sum(axis=0, dtype=np.float32) / np.float32(pos.shape[0])).astype(np.float32)
+        # tf.reduce_mean (losses.py:138) reduces with Eigen's vectorised tree reduction: float32 result within
+        # an ulp or two of the exact mean.  numpy's float32 sum over axis 0 accumulates naively (error ~N*eps),
+        # so form the mean in float64 and round once.
+        center = pos.mean(axis=0, dtype=np.float64).astype(np.float32)
         pos = pos - center
     vs = np.maximum(voxel_size, np.float32(1e-5))
     h = np.where(voxel_size >= 1e-5, np.float32(hyst), np.float32(0)).astype(np.float32)
