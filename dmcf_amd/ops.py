@@ -29,6 +29,32 @@ WINDOWS = {None: 0, "explicit": 1, "poly6": 2, "cubic": 3, "linear": 4, "peak": 
 FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE = 1, 2, 4, 8
 
 
+class LaunchTimer:
+    """Optional per-launch timing with HIP events on the stream the kernels are enqueued on (torch's current
+    stream).  bench.py installs one to measure the CConv kernel's average launch duration inside the timed
+    region; when ``ops.timer`` is None (the default) nothing is recorded."""
+
+    def __init__(self):
+        self.records = []  # (kind, meta dict, start event, end event)
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, kind, meta, start):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.records.append((kind, meta, start, ev))
+
+    def results(self):
+        """-> list of (kind, meta, milliseconds); call after a device synchronise."""
+        return [(k, m, s.elapsed_time(e)) for k, m, s, e in self.records]
+
+
+timer = None
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -72,7 +98,10 @@ def build_spatial_hash_table(points, radius, n_queries=None, **_ignored):
     m = n if n_queries is None else int(n_queries)
     nbytes = L.dmcf_frs_workspace_bytes(n, m)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=points.device)
+    t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_frs_build(_ptr(points), n, float(radius), _ptr(ws), nbytes, _stream()), "dmcf_frs_build")
+    if timer is not None:
+        timer.end("frs_build", dict(n_points=n), t0)
     return SpatialHashTable(points, radius, ws, m)
 
 
@@ -94,6 +123,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
     flags = 1 if ignore_query_point else 0
     row_splits = torch.empty(m + 1, dtype=torch.int64, device=points.device)
+    t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
     total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
@@ -103,6 +133,8 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits),
                                     _ptr(index), _ptr(dist) if return_distances else None, _stream()),
                    "dmcf_frs_write")
+    if timer is not None:
+        timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=total), t0)
     return NeighborSearchResult(index, row_splits, dist)
 
 
@@ -207,7 +239,14 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a.out = out.data_ptr()
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+    t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_cconv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_cconv_forward")
+    if timer is not None:
+        kdims = [int(d) for d in filters.shape[:3]]
+        if symmetric:
+            kdims[int(sym_axis)] *= 2
+        timer.end("cconv", dict(pairs=int(neighbors_index.shape[0]), n_out=n_out, cin=cin, cout=cout,
+                                K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric)), t0)
     return out
 
 
