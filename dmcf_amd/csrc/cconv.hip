@@ -6,28 +6,40 @@
 // Formulation (same factorisation as the Open3D CPU code, which is what makes the op cheap):
 //   B_i[k,c] = sum_{j in N(i)} a_ij * w_k(Lambda(x_j - x_i)) * f_j[c]        (gather + trilinear splat)
 //   out_i[o] = sum_{k,c} B_i[k,c] * W[k,c,o]                                  (dense contraction)
-// MI355X mapping:
-//   * a workgroup (4 wavefronts) owns a tile of TM consecutive output points; B for the tile lives in
-//     LDS as [TM][K*CC+1] floats (+1 pads the row stride off the 32-bank period), channel-chunked by
-//     CC in {4,8} so that TM stays large enough to amortise the filter reads;
-//   * splat: a wavefront walks one output point's CSR row 64 neighbours at a time.  Phase 1 has one
-//     LANE PER NEIGHBOUR: index / position gather, window function, ball->cube mapping (sqrt, atan,
-//     divisions) are paid once per pair per chunk at full lane utilisation.  Phase 2 re-maps lanes to
-//     (corner, channel): the pair's parameters are broadcast with v_readlane (CC=8) and every lane
-//     issues one ds_add_f32 into B -- 8*CC LDS adds per pair, no read-modify-write, no races between
-//     the wavefronts that share a tile;
-//   * contraction from LDS against the filter streamed through L1/L2, accumulators in registers
-//     across channel chunks; normalisation, bias and the add_merge accumulation are fused into the
-//     epilogue store;
+//
+// MI355X mapping (one workgroup = 8 wavefronts = a tile of 16 consecutive output points, two
+// workgroups per CU so that one tile's LDS-bound splat overlaps the other's MFMA-bound contraction):
+//   * B of the tile lives in LDS as [16][K*CC+4] floats, channel-chunked by CC (8, or 4 for Cin <= 4).
+//   * splat, phase 1 -- ONE LANE PER NEIGHBOUR, 64 at a time: index, distance, position and the CC
+//     feature floats of the neighbour are gathered with independent (batched) loads, the window
+//     function and the ball->cube mapping (sqrt, atan, divisions) are evaluated once per pair at full
+//     lane utilisation, and the 8 trilinear corner weights plus the importance-scaled features are
+//     parked in a per-wave LDS staging area.
+//   * splat, phase 2 -- lanes re-mapped to (corner, channel): per pair one v_readlane (base cell), two
+//     LDS reads (corner weight, feature), one multiply and one ds_add_f32 into B.  A pair's 8 corners
+//     are 8 distinct cells and a point's row of B belongs to one wave, so the adds never collide.
+//   * contraction on the matrix cores in exact fp32: v_mfma_f32_16x16x4_f32, M = the 16 points,
+//     N = 16 output channels per tile, K = the K*CC splat entries of the chunk split over the 8
+//     waves; A fragments come from B with ds_read_b128, the filter is pre-packed (pack_filter) into
+//     the B-fragment order so each lane fetches its 4 values with one coalesced 16-byte load from L2.
+//     Accumulators stay in registers across channel chunks; the 8 partial tiles are reduced through
+//     LDS, then normalisation, bias and the add_merge accumulation are applied in the store.
 //   * ASCC is the same kernel with pair features (f_j + f_i) and the mirrored kernel, i.e. the fused
-//     single-pass form of the reference's two continuous_conv calls + batched matmul;
+//     single-pass form of the reference's two continuous_conv calls + batched matmul.
 //   * consecutive tiles go to the same XCD (blockIdx swizzle) so neighbouring outputs share one L2.
 #include "common.h"
 
 namespace dmcf {
 
+constexpr int kThreads = 512;
+constexpr int kWaves = kThreads / 64;
+constexpr int TM = 16;           // output points per workgroup (MFMA M)
+constexpr int kMaxNT = 4;        // N tiles of 16 output channels (Cout <= 64)
+constexpr int kWStride = 8;      // staged corner weights per pair
+constexpr int kFStride = 12;     // staged features per pair (8 used; 12 keeps ds_write_b128 conflict-free)
+
 struct CconvParams {
-    const float* W;  // [K][cin][cout] full kernel
+    const float* Wp;  // packed filter, see pack_filter
     int sx, sy, sz, K, cin, cout;
     const float* out_pos;
     const float* inp_pos;
@@ -41,7 +53,12 @@ struct CconvParams {
     int window, mapping, interp, flags;
     const float* bias;
     float* out;
-    int TM, KCp, ntiles, tiles_per_xcd;
+    int KCp;       // row stride of B in floats: roundup(K*CC,16) + 4
+    int nblocks;   // roundup(K*CC,16)/16 : 16-wide k blocks per chunk
+    int NT;        // ceil(cout/16)
+    int nchunks;   // ceil(cin/CC)
+    int bfloats;   // floats reserved for B / the reduction buffer (whichever is larger)
+    int ntiles, tiles_per_xcd;
 };
 
 // ---- per-pair math (float restatement of Open3D's CoordinateTransformation.h, see oracle/dmcf_oracle.c)
@@ -114,11 +131,6 @@ __device__ __forceinline__ void filter_coords(float& x, float& y, float& z, cons
         if (p.sy % 2 == 0) y -= 0.5f;
         if (p.sz % 2 == 0) z -= 0.5f;
     }
-    if (p.interp == DMCF_INTERP_LINEAR) {  // coordinate clamping
-        x = fminf((float)(p.sx - 1), fmaxf(0.0f, x));
-        y = fminf((float)(p.sy - 1), fmaxf(0.0f, y));
-        z = fminf((float)(p.sz - 1), fmaxf(0.0f, z));
-    }
 }
 
 // window functions of utils/tools/losses.py:8-44 on q = d^2 / R^2
@@ -149,245 +161,300 @@ __device__ __forceinline__ float window_value(int window, float v, float r2, flo
     return 1.0f;
 }
 
-// weight and filter cell of corner t (bit0 = x, bit1 = y, bit2 = z) for filter coordinates (x,y,z)
-__device__ __forceinline__ void corner(int t, float x, float y, float z, const CconvParams& p, float& w, int& cell) {
-    if (p.interp == DMCF_INTERP_NEAREST) {
-        int xi = (int)roundf(x), yi = (int)roundf(y), zi = (int)roundf(z);
-        xi = min(max(xi, 0), p.sx - 1);
-        yi = min(max(yi, 0), p.sy - 1);
-        zi = min(max(zi, 0), p.sz - 1);
-        w = (t == 0) ? 1.0f : 0.0f;
-        cell = (zi * p.sy + yi) * p.sx + xi;
+// Interpolation along one axis as (base cell b, weight of b, weight of b+1) with 0 <= b <= max(s-2, 0),
+// so that the two cells are always inside the filter array (for s == 1 the second weight is 0 and
+// the lane offsets of "b+1" collapse onto b).  Equivalent to Open3D's clamped / bordered / nearest
+// lookups: weights that the library would put on a clamped duplicate or outside cell are 0 here.
+__device__ __forceinline__ void axis_weights(float x, int s, int interp, int& b, float& w0, float& w1) {
+    const int bmax = s >= 2 ? s - 2 : 0;
+    if (interp == DMCF_INTERP_NEAREST) {
+        int c = (int)roundf(x);
+        c = min(max(c, 0), s - 1);
+        b = min(c, bmax);
+        w0 = (c == b) ? 1.0f : 0.0f;
+        w1 = 1.0f - w0;
         return;
     }
-    const float xf = floorf(x), yf = floorf(y), zf = floorf(z);
-    const float a = x - xf, b = y - yf, c = z - zf;
-    int xi = (int)xf + (t & 1), yi = (int)yf + ((t >> 1) & 1), zi = (int)zf + ((t >> 2) & 1);
-    w = ((t & 1) ? a : 1.0f - a) * ((t & 2) ? b : 1.0f - b) * ((t & 4) ? c : 1.0f - c);
-    if (p.interp == DMCF_INTERP_LINEAR) {
-        xi = min(xi, p.sx - 1);
-        yi = min(yi, p.sy - 1);
-        zi = min(zi, p.sz - 1);
-    } else {  // LINEAR_BORDER: zero outside the filter array
-        const bool inside = xi >= 0 && xi < p.sx && yi >= 0 && yi < p.sy && zi >= 0 && zi < p.sz;
-        if (!inside) {
-            w = 0.0f;
-            xi = yi = zi = 0;
-        }
+    if (interp == DMCF_INTERP_LINEAR) {  // coordinate clamping
+        x = fminf((float)(s - 1), fmaxf(0.0f, x));
+        const float xf = fminf(floorf(x), (float)bmax);
+        b = (int)xf;
+        const float a = x - xf;  // in [0,1]; == 1 exactly when x == s-1 (then all weight on cell s-1)
+        w0 = 1.0f - a;
+        w1 = a;
+        if (s == 1) { w0 = 1.0f; w1 = 0.0f; }
+        return;
     }
-    cell = (zi * p.sy + yi) * p.sx + xi;
+    // LINEAR_BORDER: cells xf and xf+1 with weights (1-a, a); cells outside [0, s-1] contribute nothing
+    const float xf = floorf(x);
+    const float a = x - xf;
+    const float c0 = xf, c1 = xf + 1.0f;
+    const bool in0 = c0 >= 0.0f && c0 <= (float)(s - 1), in1 = c1 >= 0.0f && c1 <= (float)(s - 1);
+    const float v0 = in0 ? 1.0f - a : 0.0f, v1 = in1 ? a : 0.0f;
+    if (!in0 && !in1) { b = 0; w0 = w1 = 0.0f; return; }
+    if (in0 && in1) { b = (int)c0; w0 = v0; w1 = v1; return; }  // then c0 <= s-2
+    if (in0) {  // c0 == s-1, c1 outside
+        if (s >= 2) { b = s - 2; w0 = 0.0f; w1 = v0; } else { b = 0; w0 = v0; w1 = 0.0f; }
+        return;
+    }
+    // in1 only: c1 == 0, c0 == -1
+    b = 0; w0 = v1; w1 = 0.0f;
 }
 
-constexpr int kThreads = 256;
-constexpr int kMaxAcc = 8;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int CC>
-__global__ __launch_bounds__(kThreads) void cconv_kernel(const CconvParams p) {
-    extern __shared__ float smem[];
-    float* Bt = smem;                           // [TM][KCp]
-    float* norm = smem + (size_t)p.TM * p.KCp;  // [TM]
+__global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KCp = p.KCp, cin = p.cin, cout = p.cout;
+    float* Bt = smem;                                   // [TM][KCp]
+    float* norm = Bt + p.bfloats;                       // [TM]
+    float* stage = norm + TM + (size_t)wave * 64 * (kWStride + kFStride);
+    float* wst = stage;                                 // [64][kWStride]
+    float* fst = stage + 64 * kWStride;                 // [64][kFStride]
     // XCD-aware tile order: blocks b, b+8, b+16.. (same XCD) take consecutive tiles
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
-    const int64_t pt0 = (int64_t)tile * p.TM;
-    const int TM = p.TM, KCp = p.KCp, cin = p.cin, cout = p.cout;
+    const int64_t pt0 = (int64_t)tile * TM;
     const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
-    constexpr int PP = 64 / (8 * CC);  // pairs per splat instruction
+    constexpr int PP = 64 / (8 * CC);  // pairs per splat instruction (1 for CC=8, 2 for CC=4)
 
-    // contraction thread mapping
-    const int TPP = kThreads / TM;  // threads per output point (power of two, 8..64)
-    const int cpt = tid / TPP, cog = tid % TPP;
-    const bool ksplit = cout <= kMaxAcc;  // few outputs: split K across the point's threads instead
-    float acc[kMaxAcc];
+    // phase-2 lane role: corner t (bit0 x, bit1 y, bit2 z), channel c, pair slot within the instruction
+    const int t = (lane / CC) & 7, c = lane % CC, slot = lane / (8 * CC);
+    const int dxo = (p.sx >= 2) ? 1 : 0, dyo = (p.sy >= 2) ? p.sx : 0, dzo = (p.sz >= 2) ? p.sx * p.sy : 0;
+    const int lane_off = (((t & 1) ? dxo : 0) + ((t & 2) ? dyo : 0) + ((t & 4) ? dzo : 0)) * CC + c;
+    // a "+1" corner along an axis of size 1 has weight 0 and would alias the base cell: such lanes stay idle
+    const bool lane_live = !(((t & 1) && p.sx < 2) || ((t & 2) && p.sy < 2) || ((t & 4) && p.sz < 2));
+
+    f32x4 acc[kMaxNT];
 #pragma unroll
-    for (int u = 0; u < kMaxAcc; ++u) acc[u] = 0.0f;
+    for (int n = 0; n < kMaxNT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     if (tid < TM) norm[tid] = 0.0f;
+    const int mi = lane & 15, mg = lane >> 4;  // MFMA roles: A row / B column index, k index
 
-    for (int c0 = 0; c0 < cin; c0 += CC) {
-        for (int e = tid; e < TM * KCp; e += kThreads) Bt[e] = 0.0f;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int c0 = chunk * CC;
+        for (int e = tid * 4; e < TM * KCp; e += kThreads * 4) *(f32x4*)(Bt + e) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
         // ---------------- splat ----------------
-        for (int pt = wave; pt < TM; pt += kThreads / 64) {
+        for (int pt = wave; pt < TM; pt += kWaves) {
             const int64_t i = pt0 + pt;
             if (i >= p.n_out) break;
             const int64_t rb = p.rs[i], re = p.rs[i + 1];
             const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
-            const int t = (lane / CC) & 7, c = lane % CC;
-            const bool cvalid = (c0 + c) < cin;
-            const float fi = (symmetric && cvalid) ? p.inp_feat[i * cin + c0 + c] : 0.0f;
+            float fi[CC];
+#pragma unroll
+            for (int u = 0; u < CC; ++u) fi[u] = (symmetric && c0 + u < cin) ? p.inp_feat[i * cin + c0 + u] : 0.0f;
             float* Brow = Bt + (size_t)pt * KCp;
             float nsum = 0.0f;
             for (int64_t pb = rb; pb < re; pb += 64) {
                 const int npairs = (int)min((int64_t)64, re - pb);
-                // phase 1: one lane per neighbour
-                int j = 0;
-                float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
-                if (lane < npairs) {
-                    const int64_t pp = pb + lane;
-                    j = p.idx[pp];
-                    a = window_value(p.window, p.nval ? p.nval[pp] : 0.0f, p.r2, p.window_fac);
-                    nsum += a;
-                    if (p.inp_imp) a *= p.inp_imp[j];
-                    x = p.inp_pos[3 * (int64_t)j] - ox;
-                    y = p.inp_pos[3 * (int64_t)j + 1] - oy;
-                    z = p.inp_pos[3 * (int64_t)j + 2] - oz;
-                    filter_coords(x, y, z, p);
+                // ---- phase 1: one lane per neighbour
+                int base = 0;
+                {
+                    int j = 0;
+                    float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
+                    float f[CC];
+#pragma unroll
+                    for (int u = 0; u < CC; ++u) f[u] = 0.0f;
+                    if (lane < npairs) {
+                        const int64_t pp = pb + lane;
+                        j = p.idx[pp];
+                        const float nv = p.nval ? p.nval[pp] : 0.0f;
+                        const float* fp = p.inp_feat + (int64_t)j * cin + c0;
+                        if ((cin & 3) == 0) {  // rows are 16-byte aligned: vector gathers
+#pragma unroll
+                            for (int u = 0; u < CC; u += 4) {
+                                if (c0 + u < cin) {
+                                    const f32x4 v = *(const f32x4*)(fp + u);
+                                    f[u] = v.x; f[u + 1] = v.y; f[u + 2] = v.z; f[u + 3] = v.w;
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int u = 0; u < CC; ++u)
+                                if (c0 + u < cin) f[u] = fp[u];
+                        }
+                        x = p.inp_pos[3 * (int64_t)j] - ox;
+                        y = p.inp_pos[3 * (int64_t)j + 1] - oy;
+                        z = p.inp_pos[3 * (int64_t)j + 2] - oz;
+                        a = window_value(p.window, nv, p.r2, p.window_fac);
+                        nsum += a;
+                        if (p.inp_imp) a *= p.inp_imp[j];
+                        filter_coords(x, y, z, p);
+                    }
+                    int bx, by, bz;
+                    float wx0, wx1, wy0, wy1, wz0, wz1;
+                    axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
+                    axis_weights(y, p.sy, p.interp, by, wy0, wy1);
+                    axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                    base = ((bz * p.sy + by) * p.sx + bx) * CC;
+                    // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
+                    const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+                    float* wr = wst + lane * kWStride;
+                    *(f32x4*)(wr) = (f32x4){w00 * wz0, w10 * wz0, w01 * wz0, w11 * wz0};
+                    *(f32x4*)(wr + 4) = (f32x4){w00 * wz1, w10 * wz1, w01 * wz1, w11 * wz1};
+                    float* fr = fst + lane * kFStride;
+                    if (symmetric) {
+#pragma unroll
+                        for (int u = 0; u < CC; ++u) f[u] += fi[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CC; u += 4)
+                        *(f32x4*)(fr + u) = (f32x4){f[u] * a, f[u + 1] * a, f[u + 2] * a, f[u + 3] * a};
                 }
-                // phase 2: lanes = (pair slot, corner, channel)
+                // the staging area is private to this wave: its LDS operations are ordered, no barrier
+                // ---- phase 2: lanes = (pair slot, corner, channel)
                 for (int q = 0; q < npairs; q += PP) {
-                    int jq;
-                    float aq, xq, yq, zq;
+                    int bq;
                     bool valid = true;
                     if constexpr (PP == 1) {
-                        jq = __builtin_amdgcn_readlane(j, q);
-                        aq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), q));
-                        xq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), q));
-                        yq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(y), q));
-                        zq = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(z), q));
+                        bq = __builtin_amdgcn_readlane(base, q);
                     } else {
-                        const int slot = q + lane / (8 * CC);
-                        valid = slot < npairs;
-                        jq = __shfl(j, slot, 64);
-                        aq = __shfl(a, slot, 64);
-                        xq = __shfl(x, slot, 64);
-                        yq = __shfl(y, slot, 64);
-                        zq = __shfl(z, slot, 64);
+                        const int b0 = __builtin_amdgcn_readlane(base, q);
+                        const int b1 = __builtin_amdgcn_readlane(base, min(q + 1, 63));
+                        bq = slot ? b1 : b0;
+                        valid = (q + slot) < npairs;
                     }
-                    float w;
-                    int cell;
-                    corner(t, xq, yq, zq, p, w, cell);
-                    if (valid && cvalid) {
-                        float f = p.inp_feat[(int64_t)jq * cin + c0 + c];
-                        if (symmetric) f += fi;
-                        const float val = w * (f * aq);
-                        __hip_atomic_fetch_add(&Brow[cell * CC + c], val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const int qq = min(q + slot, 63);
+                    const float w = wst[qq * kWStride + t];
+                    const float fv = fst[qq * kFStride + c];
+                    // Plain read-modify-write instead of ds_add_f32: the LDS float atomic retires ~1 lane per
+                    // 3 clocks on gfx950 (measured: ~200 clk per 64-lane instruction), a b32 read + write pair
+                    // costs ~6.  It is race free: the row belongs to this wave, LDS operations of a wave are
+                    // processed in order, and the active lanes of one instruction hit distinct addresses
+                    // (8 distinct cells x CC channels; lanes whose "+1" cell collapses onto the base cell
+                    // because that filter axis has size 1 carry weight 0 and are masked off).
+                    float* dst = &Brow[bq + lane_off];
+                    if constexpr (PP == 1) {
+                        if (lane_live) *dst = *dst + w * fv;
+                    } else {
+                        // two pairs of the same point per instruction may share cells: one slot at a time
+                        if (lane_live && valid && slot == 0) *dst = *dst + w * fv;
+                        if (lane_live && valid && slot == 1) *dst = *dst + w * fv;
                     }
                 }
             }
-            if (c0 == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
+            if (chunk == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
 #pragma unroll
                 for (int d = 32; d >= 1; d >>= 1) nsum += __shfl_xor(nsum, d, 64);
                 if (lane == 0) norm[pt] = nsum;
             }
         }
         __syncthreads();
-        // ---------------- contraction of this channel chunk ----------------
-        const float* Brow = Bt + (size_t)cpt * KCp;
-        const int KC = p.K * CC;
-        if (!ksplit) {
-            for (int kc = 0; kc < KC; ++kc) {
-                const int k = kc / CC, c = kc % CC;
-                if (c0 + c >= cin) continue;
-                const float b = Brow[kc];
-                const float* Wrow = p.W + ((size_t)k * cin + c0 + c) * cout;
+        // ---------------- contraction of this channel chunk on the matrix cores ----------------
+        // out[16 x 16*NT] += B[16 x KC] * Wp_chunk[KC x 16*NT], k blocks of 16 dealt round-robin to the waves
+        const float* Wc = p.Wp + (size_t)chunk * p.nblocks * (4 * p.NT * 16 * 4);
+        for (int blk = wave; blk < p.nblocks; blk += kWaves) {
+            const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * KCp + blk * 16 + mg * 4);
+            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
 #pragma unroll
-                for (int u = 0; u < kMaxAcc; ++u) {
-                    const int o = cog + u * TPP;
-                    if (o < cout) acc[u] = fmaf(b, Wrow[o], acc[u]);
+            for (int n = 0; n < kMaxNT; ++n) {
+                if (n < p.NT) {
+                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
                 }
-            }
-        } else {
-            for (int kc = cog; kc < KC; kc += TPP) {
-                const int k = kc / CC, c = kc % CC;
-                if (c0 + c >= cin) continue;
-                const float b = Brow[kc];
-                const float* Wrow = p.W + ((size_t)k * cin + c0 + c) * cout;
-#pragma unroll
-                for (int u = 0; u < kMaxAcc; ++u)
-                    if (u < cout) acc[u] = fmaf(b, Wrow[u], acc[u]);
             }
         }
         __syncthreads();
     }
 
-    // ---------------- epilogue ----------------
-    const int64_t i = pt0 + cpt;
-    if (ksplit) {
+    // ---------------- cross-wave reduction + epilogue ----------------
+    // D layout of 16x16x4: lane l, reg r -> row (point) 4*(l>>4)+r, column (channel) l&15
+    float* red = Bt;  // [kWaves][TM][16*NT]  (B is dead now; 8*16*64*4 = 32 KiB at most)
+    const int ncol = 16 * p.NT;
 #pragma unroll
-        for (int u = 0; u < kMaxAcc; ++u)
-            for (int d = TPP >> 1; d >= 1; d >>= 1) acc[u] += __shfl_xor(acc[u], d, 64);
+    for (int n = 0; n < kMaxNT; ++n) {
+        if (n < p.NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((size_t)wave * TM + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+        }
     }
-    if (i < p.n_out) {
-        float inv_norm = 1.0f;
-        if (p.flags & DMCF_FLAG_NORMALIZE) {
-            const float nv = norm[cpt];
-            inv_norm = nv != 0.0f ? 1.0f / nv : 1.0f;
-        }
+    __syncthreads();
+    for (int e = tid; e < TM * cout; e += kThreads) {
+        const int pt = e / cout, o = e % cout;
+        const int64_t i = pt0 + pt;
+        if (i >= p.n_out) continue;
+        float v = 0.0f;
 #pragma unroll
-        for (int u = 0; u < kMaxAcc; ++u) {
-            const int o = ksplit ? u : cog + u * TPP;
-            const bool mine = ksplit ? (cog == 0 && u < cout) : (o < cout);
-            if (mine) {
-                float v = acc[u];
-                if (p.flags & DMCF_FLAG_NORMALIZE) v *= inv_norm;
-                if (p.bias) v += p.bias[o];
-                float* dst = p.out + i * cout + o;
-                if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
-                *dst = v;
-            }
+        for (int w = 0; w < kWaves; ++w) v += red[((size_t)w * TM + pt) * ncol + o];
+        if (p.flags & DMCF_FLAG_NORMALIZE) {
+            const float nv = norm[pt];
+            if (nv != 0.0f) v /= nv;
         }
+        if (p.bias) v += p.bias[o];
+        float* dst = p.out + i * cout + o;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        *dst = v;
     }
 }
 
-// full[z,y,x,c,o] = concat([-half[::-1,::-1,::-1], half], axis=sym_axis)   (utils/convolutions.py:410-412)
-__global__ void mirror_kernel(const float* __restrict__ half, float* __restrict__ full, int d0, int d1, int d2,
-                              int inner, int sym_axis) {
-    // d0,d1,d2: FULL spatial dims (z,y,x); inner = cin*cout
-    const int64_t total = (int64_t)d0 * d1 * d2 * inner;
-    const int hd[3] = {sym_axis == 0 ? d0 / 2 : d0, sym_axis == 1 ? d1 / 2 : d1, sym_axis == 2 ? d2 / 2 : d2};
+// Packs [K][cin][cout] (optionally mirrored: ASCC, utils/convolutions.py:410-412) into the B-fragment
+// order of v_mfma_f32_16x16x4_f32 per channel chunk:
+//   Wp[chunk][blk][g][n][j][q] = W[cell][c0 + cc][16 n + j],  kc = 16 blk + 4 g + q = cell*CC + cc
+// zero where kc >= K*CC, c0+cc >= cin or 16n+j >= cout.
+__global__ void pack_filter(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2, int cin,
+                            int cout, int CC, int nchunks, int nblocks, int NT, int symmetric, int sym_axis) {
+    const int K = d0 * d1 * d2;
+    const int64_t total = (int64_t)nchunks * nblocks * 4 * NT * 16 * 4;
+    const int hd[3] = {(symmetric && sym_axis == 0) ? d0 / 2 : d0, (symmetric && sym_axis == 1) ? d1 / 2 : d1,
+                       (symmetric && sym_axis == 2) ? d2 / 2 : d2};
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int in = (int)(e % inner);
-        int64_t s = e / inner;
-        int c[3];
-        c[2] = (int)(s % d2); s /= d2;
-        c[1] = (int)(s % d1); s /= d1;
-        c[0] = (int)s;
-        const int h = hd[sym_axis];
-        float sign = 1.0f;
-        int hc[3] = {c[0], c[1], c[2]};
-        if (c[sym_axis] >= h) {
-            hc[sym_axis] = c[sym_axis] - h;
-        } else {
-            sign = -1.0f;
-            for (int a = 0; a < 3; ++a) hc[a] = hd[a] - 1 - c[a];
+        int64_t s = e;
+        const int q = (int)(s & 3); s >>= 2;
+        const int j = (int)(s & 15); s >>= 4;
+        const int n = (int)(s % NT); s /= NT;
+        const int g = (int)(s & 3); s >>= 2;
+        const int blk = (int)(s % nblocks); s /= nblocks;
+        const int chunk = (int)s;
+        const int kc = 16 * blk + 4 * g + q, cell = kc / CC, ci = chunk * CC + kc % CC, o = 16 * n + j;
+        float v = 0.0f;
+        if (cell < K && ci < cin && o < cout) {
+            int cz = cell / (d1 * d2), cy = (cell / d2) % d1, cx = cell % d2;
+            int c3[3] = {cz, cy, cx};
+            float sign = 1.0f;
+            if (symmetric) {
+                const int h = hd[sym_axis];
+                if (c3[sym_axis] >= h) {
+                    c3[sym_axis] -= h;
+                } else {
+                    sign = -1.0f;
+                    for (int a = 0; a < 3; ++a) c3[a] = hd[a] - 1 - c3[a];
+                }
+            }
+            v = sign * src[((((int64_t)c3[0] * hd[1] + c3[1]) * hd[2] + c3[2]) * cin + ci) * cout + o];
         }
-        full[e] = sign * half[(((int64_t)hc[0] * hd[1] + hc[1]) * hd[2] + hc[2]) * inner + in];
+        dst[e] = v;
     }
 }
 
 struct LaunchCfg {
-    int CC, TM;
-    size_t lds;
+    int CC, KCp, nblocks, NT, nchunks;
+    size_t lds, packed_floats, bfloats;
 };
 
-static LaunchCfg choose_cfg(int K, int cin, int cout) {
-    // LDS budget per workgroup: two workgroups per CU out of 160 KiB
-    const size_t budget = 80 * 1024;
-    LaunchCfg best = {4, 4, 0};
-    double best_score = -1.0;
-    const int ccs[2] = {8, 4};
-    for (int ci = 0; ci < 2; ++ci) {
-        const int CC = ccs[ci];
-        if (CC == 8 && cin <= 4) continue;  // half of the splat lanes would idle
-        for (int TM = 32; TM >= 4; TM >>= 1) {
-            if (cout > kMaxAcc && (cout + (kThreads / TM) - 1) / (kThreads / TM) > kMaxAcc) continue;
-            const size_t lds = ((size_t)TM * (K * CC + 1) + TM) * sizeof(float);
-            if (lds > budget) continue;
-            const double score = (double)TM * CC;  // filter reuse x fewer passes over the neighbour list
-            if (score > best_score) {
-                best_score = score;
-                best = {CC, TM, lds};
-            }
-            break;
-        }
-    }
-    if (best_score < 0) {
-        // very large filters: one workgroup per CU, smallest tile
-        best = {4, 4, ((size_t)4 * (K * 4 + 1) + 4) * sizeof(float)};
-    }
-    return best;
+static LaunchCfg make_cfg(int K, int cin, int cout) {
+    LaunchCfg c;
+    c.CC = cin <= 4 ? 4 : 8;
+    const int KC = K * c.CC;
+    const int KCpad = (KC + 15) / 16 * 16;
+    c.KCp = KCpad + 4;
+    c.nblocks = KCpad / 16;
+    c.NT = (cout + 15) / 16;
+    c.nchunks = (cin + c.CC - 1) / c.CC;
+    size_t b_floats = (size_t)TM * c.KCp;
+    const size_t red_floats = (size_t)kWaves * TM * 16 * c.NT;
+    if (b_floats < red_floats) b_floats = red_floats;  // the reduction buffer reuses B
+    c.bfloats = b_floats;
+    c.lds = (b_floats + TM + (size_t)kWaves * 64 * (kWStride + kFStride)) * sizeof(float);
+    c.packed_floats = (size_t)c.nchunks * c.nblocks * 4 * c.NT * 16 * 4;
+    return c;
 }
 
 }  // namespace dmcf
@@ -409,26 +476,29 @@ static int validate(const dmcf_cconv_args* a) {
         if (a->sym_axis < 0 || a->sym_axis > 2) return DMCF_EINVAL;
         if (a->n_inp != a->n_out) return DMCF_EINVAL;
     }
-    if (a->filter_dims[4] > 64) return DMCF_EUNSUPPORTED;
+    if (a->filter_dims[4] > 16 * kMaxNT) return DMCF_EUNSUPPORTED;
     if (a->n_out > 0) {
         if (!a->filters || !a->out_positions || !a->neighbors_row_splits || !a->out) return DMCF_EINVAL;
-        if (a->window != DMCF_WINDOW_NONE && !a->neighbors_value) {
-            // legal only when there are no pairs at all; cannot know here, so require it
-            return DMCF_EINVAL;
-        }
+        if (a->window != DMCF_WINDOW_NONE && !a->neighbors_value) return DMCF_EINVAL;
     }
     return DMCF_OK;
 }
 
-size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
-    if (!a) return 0;
-    size_t bytes = 256;
+static void full_dims(const dmcf_cconv_args* a, int& dz, int& dy, int& dx) {
+    dz = a->filter_dims[0]; dy = a->filter_dims[1]; dx = a->filter_dims[2];
     if (a->flags & DMCF_FLAG_SYMMETRIC) {
-        size_t full = 2;
-        for (int d = 0; d < 5; ++d) full *= (size_t)(a->filter_dims[d] > 0 ? a->filter_dims[d] : 1);
-        bytes += align_up(full * sizeof(float), 256);
+        if (a->sym_axis == 0) dz *= 2;
+        if (a->sym_axis == 1) dy *= 2;
+        if (a->sym_axis == 2) dx *= 2;
     }
-    return bytes;
+}
+
+size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
+    if (!a || validate(a) != DMCF_OK) return 256;
+    int dz, dy, dx;
+    full_dims(a, dz, dy, dx);
+    const LaunchCfg cfg = make_cfg(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
+    return 256 + align_up(cfg.packed_floats * sizeof(float), 256);
 }
 
 int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspace_bytes, dmcf_stream_t stream_) {
@@ -436,28 +506,27 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     int rc = validate(a);
     if (rc != DMCF_OK) return rc;
     if (a->n_out == 0) return DMCF_OK;
+    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
     if (workspace_bytes < dmcf_cconv_workspace_bytes(a)) return DMCF_EWORKSPACE;
 
     CconvParams p;
-    int dz = a->filter_dims[0], dy = a->filter_dims[1], dx = a->filter_dims[2];
+    int dz, dy, dx;
+    full_dims(a, dz, dy, dx);
     p.cin = a->filter_dims[3];
     p.cout = a->filter_dims[4];
-    p.W = a->filters;
-    if (a->flags & DMCF_FLAG_SYMMETRIC) {
-        if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
-        if (a->sym_axis == 0) dz *= 2;
-        if (a->sym_axis == 1) dy *= 2;
-        if (a->sym_axis == 2) dx *= 2;
-        float* full = (float*)workspace;
-        const int inner = p.cin * p.cout;
-        const int64_t total = (int64_t)dz * dy * dx * inner;
-        const unsigned g = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(mirror_kernel, dim3(g < 4096u ? g : 4096u), dim3(256), 0, stream, a->filters, full, dz, dy,
-                           dx, inner, a->sym_axis);
-        p.W = full;
-    }
     p.sx = dx; p.sy = dy; p.sz = dz;
     p.K = dx * dy * dz;
+    const LaunchCfg cfg = make_cfg(p.K, p.cin, p.cout);
+    if (cfg.lds > 160 * 1024) return DMCF_EUNSUPPORTED;
+    {
+        float* packed = (float*)workspace;
+        const int64_t total = (int64_t)cfg.packed_floats;
+        const unsigned g = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
+                           p.cin, p.cout, cfg.CC, cfg.nchunks, cfg.nblocks, cfg.NT,
+                           (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
+        p.Wp = packed;
+    }
     p.out_pos = a->out_positions;
     p.inp_pos = a->inp_positions;
     p.inp_feat = a->inp_features;
@@ -476,23 +545,24 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.flags = a->flags;
     p.bias = a->bias;
     p.out = a->out;
-
-    const LaunchCfg cfg = choose_cfg(p.K, p.cin, p.cout);
-    if (cfg.lds > 160 * 1024) return DMCF_EUNSUPPORTED;
-    p.TM = cfg.TM;
-    p.KCp = p.K * cfg.CC + 1;
-    const int64_t ntiles = (a->n_out + cfg.TM - 1) / cfg.TM;
+    p.KCp = cfg.KCp;
+    p.nblocks = cfg.nblocks;
+    p.NT = cfg.NT;
+    p.nchunks = cfg.nchunks;
+    p.bfloats = (int)cfg.bfloats;
+    const int64_t ntiles = (a->n_out + TM - 1) / TM;
     if (ntiles > 0x7fffffff / 8) return DMCF_EUNSUPPORTED;
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    hipError_t e;
     if (cfg.CC == 8) {
-        if (cfg.lds > 64 * 1024)
-            hipFuncSetAttribute((const void*)cconv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+        e = hipFuncSetAttribute((const void*)cconv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
         hipLaunchKernelGGL((cconv_kernel<8>), dim3(grid), dim3(kThreads), cfg.lds, stream, p);
     } else {
-        if (cfg.lds > 64 * 1024)
-            hipFuncSetAttribute((const void*)cconv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+        e = hipFuncSetAttribute((const void*)cconv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+        if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
         hipLaunchKernelGGL((cconv_kernel<4>), dim3(grid), dim3(kThreads), cfg.lds, stream, p);
     }
     return check_launch();

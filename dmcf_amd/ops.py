@@ -68,7 +68,10 @@ def _dev_f32(t, name, cols=None):
         raise TypeError(f"{name} must be float32, got {t.dtype}")
     if cols is not None and (t.dim() != 2 or t.shape[1] != cols):
         raise ValueError(f"{name} must have shape [n,{cols}], got {tuple(t.shape)}")
-    return t.contiguous()
+    t = t.contiguous()
+    if t.data_ptr() % 16:  # the kernels use 16-byte vector loads on feature / filter rows
+        t = t.clone()
+    return t
 
 
 def _ptr(t):
@@ -126,14 +129,18 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
+    if timer is not None:
+        timer.end("frs_count", dict(n_points=n, n_queries=m), t0)
     total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
     index = torch.empty(total, dtype=torch.int32, device=points.device)
     dist = torch.empty(total if return_distances else 0, dtype=torch.float32, device=points.device)
+    t1 = timer.begin() if timer is not None else None
     if total > 0:
         _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits),
                                     _ptr(index), _ptr(dist) if return_distances else None, _stream()),
                    "dmcf_frs_write")
     if timer is not None:
+        timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=total), t1)
         timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=total), t0)
     return NeighborSearchResult(index, row_splits, dist)
 

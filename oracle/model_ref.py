@@ -163,12 +163,13 @@ class ModelRef:
         self.all_pos = all_pos
         fluid_feats = np.concatenate(fluid_feats, axis=-1).astype(f32)
         box_feats = np.concatenate(box_feats, axis=-1).astype(f32)
+        # get_cconv (pbf_model.py:208-209): ignore_query_points=None -> the model-level flag, also for the input convs
         ans_conv = self._cconv(0, "model/fluid_convs", fluid_feats * self.part_scale, pos, all_pos, filter_extent[0],
-                               self.window)
+                               self.window, ignore=self.ignore_query_points)
         self.fluid_nns = self.last_nns
         ans_dense = self._dense("model/fluid_dense", fluid_feats)
         ans_obs = self._cconv(1, "model/obs_convs", box_feats * self.part_scale, box, all_pos, filter_extent[0],
-                              self.window)
+                              self.window, ignore=self.ignore_query_points)
         ans_dense_obs = self._dense("model/obs_dense", box_feats)
         ans_dense = np.concatenate([ans_dense, ans_dense_obs], axis=0)
         feats_out = np.concatenate([ans_conv, ans_obs, ans_dense], axis=-1).astype(f32)
