@@ -53,8 +53,9 @@ struct CconvParams {
     int window, mapping, interp, flags;
     const float* bias;
     float* out;
-    int KCp;       // row stride of B in floats: roundup(K*CC,16) + 4
-    int nblocks;   // roundup(K*CC,16)/16 : 16-wide k blocks per chunk
+    int PS;        // plane stride of B in floats (see cell_offset)
+    int KCp;       // row stride of B in floats: sz*PS padded to 4 (mod 64)
+    int nblocks;   // sz*PS/16 : 16-wide k blocks per chunk
     int NT;        // ceil(cout/16)
     int nchunks;   // ceil(cin/CC)
     int bfloats;   // floats reserved for B / the reduction buffer (whichever is larger)
@@ -202,12 +203,21 @@ __device__ __forceinline__ void axis_weights(float x, int s, int interp, int& b,
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// float offset of filter cell (bx,by,bz) inside a row of B.  z planes are padded to a multiple of 16
+// floats (+16 when the plane is a multiple of 64 floats, so that the +z corners of a pair fall on
+// other LDS banks than the -z corners) -- "PS" = plane stride.
+__device__ __forceinline__ int cell_offset(int bx, int by, int bz, int sx, int PS, int CC) {
+    return bz * PS + (by * sx + bx) * CC;
+}
 
 template <int CC>
 __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KCp = p.KCp, cin = p.cin, cout = p.cout;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KCp = p.KCp, cin = p.cin, cout = p.cout, PS = p.PS;
     float* Bt = smem;                                   // [TM][KCp]
     float* norm = Bt + p.bfloats;                       // [TM]
     float* stage = norm + TM + (size_t)wave * 64 * (kWStride + kFStride);
@@ -218,12 +228,29 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     if (tile >= p.ntiles) return;
     const int64_t pt0 = (int64_t)tile * TM;
     const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
-    constexpr int PP = 64 / (8 * CC);  // pairs per splat instruction (1 for CC=8, 2 for CC=4)
 
-    // phase-2 lane role: corner t (bit0 x, bit1 y, bit2 z), channel c, pair slot within the instruction
-    const int t = (lane / CC) & 7, c = lane % CC, slot = lane / (8 * CC);
-    const int dxo = (p.sx >= 2) ? 1 : 0, dyo = (p.sy >= 2) ? p.sx : 0, dzo = (p.sz >= 2) ? p.sx * p.sy : 0;
-    const int lane_off = (((t & 1) ? dxo : 0) + ((t & 2) ? dyo : 0) + ((t & 4) ? dzo : 0)) * CC + c;
+    // Each wave owns two points of the tile, one per half-wave (h): rows wave and wave + 8 of B.
+    const int h = lane >> 5, pl = lane & 31;
+    const int pt = wave + kWaves * h;
+    const int64_t i = pt0 + pt;
+    const bool pt_valid = i < p.n_out;
+    int64_t rb = 0, re = 0;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (pt_valid) {
+        rb = p.rs[i];
+        re = p.rs[i + 1];
+        ox = p.out_pos[3 * i]; oy = p.out_pos[3 * i + 1]; oz = p.out_pos[3 * i + 2];
+    }
+    const int cnt = (int)(re - rb);
+    const int cnt_max = max(__builtin_amdgcn_readlane(cnt, 0), __builtin_amdgcn_readlane(cnt, 32));
+    const int nbatch = (cnt_max + 31) / 32;
+    float* Brow = Bt + (size_t)pt * KCp;
+
+    // phase-2 lane role inside a half-wave: corner t (bit0 x, bit1 y, bit2 z) x 4 channel groups
+    constexpr int CPL = CC / 4;  // channels per lane (2 -> 64-bit read-modify-write, 1 -> 32-bit)
+    const int t = pl >> 2, c4 = pl & 3;
+    const int lane_off = cell_offset((t & 1) && p.sx >= 2, ((t >> 1) & 1) && p.sy >= 2, ((t >> 2) & 1) && p.sz >= 2,
+                                     p.sx, PS, CC) + c4 * CPL;
     // a "+1" corner along an axis of size 1 has weight 0 and would alias the base cell: such lanes stay idle
     const bool lane_live = !(((t & 1) && p.sx < 2) || ((t & 2) && p.sy < 2) || ((t & 4) && p.sz < 2));
 
@@ -239,109 +266,108 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         for (int e = tid * 4; e < TM * KCp; e += kThreads * 4) *(f32x4*)(Bt + e) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();
         // ---------------- splat ----------------
-        for (int pt = wave; pt < TM; pt += kWaves) {
-            const int64_t i = pt0 + pt;
-            if (i >= p.n_out) break;
-            const int64_t rb = p.rs[i], re = p.rs[i + 1];
-            const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
-            float fi[CC];
+        float fi[CC];
 #pragma unroll
-            for (int u = 0; u < CC; ++u) fi[u] = (symmetric && c0 + u < cin) ? p.inp_feat[i * cin + c0 + u] : 0.0f;
-            float* Brow = Bt + (size_t)pt * KCp;
-            float nsum = 0.0f;
-            for (int64_t pb = rb; pb < re; pb += 64) {
-                const int npairs = (int)min((int64_t)64, re - pb);
-                // ---- phase 1: one lane per neighbour
-                int base = 0;
-                {
-                    int j = 0;
-                    float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
-                    float f[CC];
+        for (int u = 0; u < CC; ++u)
+            fi[u] = (symmetric && pt_valid && c0 + u < cin) ? p.inp_feat[i * cin + c0 + u] : 0.0f;
+        float nsum = 0.0f;
+        for (int bi = 0; bi < nbatch; ++bi) {
+            // ---- phase 1: one lane per neighbour, 32 neighbours of each of the wave's two points
+            const int64_t pp = rb + 32 * bi + pl;
+            const bool pvalid = pp < re;
+            int np_h = cnt - 32 * bi;  // pairs of this half in the batch (may be <= 0)
+            np_h = min(max(np_h, 0), 32);
+            int base = 0;
+            {
+                int j = 0;
+                float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
+                float f[CC];
 #pragma unroll
-                    for (int u = 0; u < CC; ++u) f[u] = 0.0f;
-                    if (lane < npairs) {
-                        const int64_t pp = pb + lane;
-                        j = p.idx[pp];
-                        const float nv = p.nval ? p.nval[pp] : 0.0f;
-                        const float* fp = p.inp_feat + (int64_t)j * cin + c0;
-                        if ((cin & 3) == 0) {  // rows are 16-byte aligned: vector gathers
+                for (int u = 0; u < CC; ++u) f[u] = 0.0f;
+                if (pvalid) {
+                    j = p.idx[pp];
+                    const float nv = p.nval ? p.nval[pp] : 0.0f;
+                    const float* fp = p.inp_feat + (int64_t)j * cin + c0;
+                    if ((cin & 3) == 0) {  // rows are 16-byte aligned: vector gathers
 #pragma unroll
-                            for (int u = 0; u < CC; u += 4) {
-                                if (c0 + u < cin) {
-                                    const f32x4 v = *(const f32x4*)(fp + u);
-                                    f[u] = v.x; f[u + 1] = v.y; f[u + 2] = v.z; f[u + 3] = v.w;
-                                }
+                        for (int u = 0; u < CC; u += 4) {
+                            if (c0 + u < cin) {
+                                const f32x4 v = *(const f32x4*)(fp + u);
+                                f[u] = v.x; f[u + 1] = v.y; f[u + 2] = v.z; f[u + 3] = v.w;
                             }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < CC; ++u)
-                                if (c0 + u < cin) f[u] = fp[u];
                         }
-                        x = p.inp_pos[3 * (int64_t)j] - ox;
-                        y = p.inp_pos[3 * (int64_t)j + 1] - oy;
-                        z = p.inp_pos[3 * (int64_t)j + 2] - oz;
-                        a = window_value(p.window, nv, p.r2, p.window_fac);
-                        nsum += a;
-                        if (p.inp_imp) a *= p.inp_imp[j];
-                        filter_coords(x, y, z, p);
-                    }
-                    int bx, by, bz;
-                    float wx0, wx1, wy0, wy1, wz0, wz1;
-                    axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
-                    axis_weights(y, p.sy, p.interp, by, wy0, wy1);
-                    axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
-                    base = ((bz * p.sy + by) * p.sx + bx) * CC;
-                    // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
-                    const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
-                    float* wr = wst + lane * kWStride;
-                    *(f32x4*)(wr) = (f32x4){w00 * wz0, w10 * wz0, w01 * wz0, w11 * wz0};
-                    *(f32x4*)(wr + 4) = (f32x4){w00 * wz1, w10 * wz1, w01 * wz1, w11 * wz1};
-                    float* fr = fst + lane * kFStride;
-                    if (symmetric) {
+                    } else {
 #pragma unroll
-                        for (int u = 0; u < CC; ++u) f[u] += fi[u];
+                        for (int u = 0; u < CC; ++u)
+                            if (c0 + u < cin) f[u] = fp[u];
                     }
-#pragma unroll
-                    for (int u = 0; u < CC; u += 4)
-                        *(f32x4*)(fr + u) = (f32x4){f[u] * a, f[u + 1] * a, f[u + 2] * a, f[u + 3] * a};
+                    x = p.inp_pos[3 * (int64_t)j] - ox;
+                    y = p.inp_pos[3 * (int64_t)j + 1] - oy;
+                    z = p.inp_pos[3 * (int64_t)j + 2] - oz;
+                    a = window_value(p.window, nv, p.r2, p.window_fac);
+                    nsum += a;
+                    if (p.inp_imp) a *= p.inp_imp[j];
+                    filter_coords(x, y, z, p);
                 }
-                // the staging area is private to this wave: its LDS operations are ordered, no barrier
-                // ---- phase 2: lanes = (pair slot, corner, channel)
-                for (int q = 0; q < npairs; q += PP) {
-                    int bq;
-                    bool valid = true;
-                    if constexpr (PP == 1) {
-                        bq = __builtin_amdgcn_readlane(base, q);
-                    } else {
-                        const int b0 = __builtin_amdgcn_readlane(base, q);
-                        const int b1 = __builtin_amdgcn_readlane(base, min(q + 1, 63));
-                        bq = slot ? b1 : b0;
-                        valid = (q + slot) < npairs;
-                    }
-                    const int qq = min(q + slot, 63);
-                    const float w = wst[qq * kWStride + t];
-                    const float fv = fst[qq * kFStride + c];
-                    // Plain read-modify-write instead of ds_add_f32: the LDS float atomic retires ~1 lane per
-                    // 3 clocks on gfx950 (measured: ~200 clk per 64-lane instruction), a b32 read + write pair
-                    // costs ~6.  It is race free: the row belongs to this wave, LDS operations of a wave are
-                    // processed in order, and the active lanes of one instruction hit distinct addresses
-                    // (8 distinct cells x CC channels; lanes whose "+1" cell collapses onto the base cell
-                    // because that filter axis has size 1 carry weight 0 and are masked off).
-                    float* dst = &Brow[bq + lane_off];
-                    if constexpr (PP == 1) {
-                        if (lane_live) *dst = *dst + w * fv;
-                    } else {
-                        // two pairs of the same point per instruction may share cells: one slot at a time
-                        if (lane_live && valid && slot == 0) *dst = *dst + w * fv;
-                        if (lane_live && valid && slot == 1) *dst = *dst + w * fv;
-                    }
+                int bx, by, bz;
+                float wx0, wx1, wy0, wy1, wz0, wz1;
+                axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
+                axis_weights(y, p.sy, p.interp, by, wy0, wy1);
+                axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                base = cell_offset(bx, by, bz, p.sx, PS, CC);
+                // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
+                const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+                float* wr = wst + lane * kWStride;
+                *(f32x4*)(wr) = (f32x4){w00 * wz0, w10 * wz0, w01 * wz0, w11 * wz0};
+                *(f32x4*)(wr + 4) = (f32x4){w00 * wz1, w10 * wz1, w01 * wz1, w11 * wz1};
+                float* fr = fst + lane * kFStride;
+                if (symmetric) {
+#pragma unroll
+                    for (int u = 0; u < CC; ++u) f[u] += fi[u];
+                }
+#pragma unroll
+                for (int u = 0; u < CC; u += 4)
+                    *(f32x4*)(fr + u) = (f32x4){f[u] * a, f[u + 1] * a, f[u + 2] * a, f[u + 3] * a};
+            }
+            // The staging area is private to this wave and LDS operations of one wave are processed in
+            // order, so no barrier is needed between the phases.
+            // ---- phase 2: per half-wave lanes = (corner, channel group); both points advance together.
+            // Plain read-modify-write instead of ds_add_f32: the LDS float atomic retires ~1 lane per
+            // 3 clocks on gfx950 (measured ~200 clk per 64-lane instruction).  Race free: a row of B
+            // belongs to one half-wave, the active lanes of a half hit distinct addresses (8 distinct
+            // cells x channels; lanes whose "+1" cell collapses onto the base cell because that filter
+            // axis has size 1 carry weight 0 and are masked off), and the two halves work on two rows.
+            const int nq = max(__builtin_amdgcn_readlane(np_h, 0), __builtin_amdgcn_readlane(np_h, 32));
+            const float* wsrc = wst + (32 * h) * kWStride + t;
+            const float* fsrc = fst + (32 * h) * kFStride + c4 * CPL;
+            // Branch-free body so that it can be unrolled and its LDS reads hoisted: slots beyond a half's
+            // pair count hold zero features (phase 1 wrote f*a = 0 and a valid base cell for them), so they
+            // add 0; dead lanes (size-1 axes) read-modify-write a private spare slot of the staging row.
+            float* dead = fst + lane * kFStride + 8;
+#pragma unroll 4
+            for (int q = 0; q < nq; ++q) {
+                const int b0 = __builtin_amdgcn_readlane(base, q);
+                const int b1 = __builtin_amdgcn_readlane(base, 32 + q);
+                const int bq = h ? b1 : b0;
+                const float w = wsrc[q * kWStride];
+                if constexpr (CPL == 2) {
+                    const f32x2 fv = *(const f32x2*)(fsrc + q * kFStride);
+                    f32x2* dst = (f32x2*)(lane_live ? Brow + bq + lane_off : dead);
+                    f32x2 o = *dst;
+                    o.x += w * fv.x;
+                    o.y += w * fv.y;
+                    *dst = o;
+                } else {
+                    const float fv = fsrc[q * kFStride];
+                    float* dst = lane_live ? Brow + bq + lane_off : dead;
+                    *dst = *dst + w * fv;
                 }
             }
-            if (chunk == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
+        }
+        if (chunk == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
 #pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) nsum += __shfl_xor(nsum, d, 64);
-                if (lane == 0) norm[pt] = nsum;
-            }
+            for (int d = 16; d >= 1; d >>= 1) nsum += __shfl_xor(nsum, d, 64);
+            if (pl == 0 && pt_valid) norm[pt] = nsum;
         }
         __syncthreads();
         // ---------------- contraction of this channel chunk on the matrix cores ----------------
@@ -378,30 +404,31 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     }
     __syncthreads();
     for (int e = tid; e < TM * cout; e += kThreads) {
-        const int pt = e / cout, o = e % cout;
-        const int64_t i = pt0 + pt;
-        if (i >= p.n_out) continue;
+        const int ptt = e / cout, o = e % cout;
+        const int64_t ii = pt0 + ptt;
+        if (ii >= p.n_out) continue;
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < kWaves; ++w) v += red[((size_t)w * TM + pt) * ncol + o];
+        for (int w = 0; w < kWaves; ++w) v += red[((size_t)w * TM + ptt) * ncol + o];
         if (p.flags & DMCF_FLAG_NORMALIZE) {
-            const float nv = norm[pt];
+            const float nv = norm[ptt];
             if (nv != 0.0f) v /= nv;
         }
         if (p.bias) v += p.bias[o];
-        float* dst = p.out + i * cout + o;
+        float* dst = p.out + ii * cout + o;
         if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
         *dst = v;
     }
 }
 
 // Packs [K][cin][cout] (optionally mirrored: ASCC, utils/convolutions.py:410-412) into the B-fragment
-// order of v_mfma_f32_16x16x4_f32 per channel chunk:
-//   Wp[chunk][blk][g][n][j][q] = W[cell][c0 + cc][16 n + j],  kc = 16 blk + 4 g + q = cell*CC + cc
-// zero where kc >= K*CC, c0+cc >= cin or 16n+j >= cout.
+// order of v_mfma_f32_16x16x4_f32 per channel chunk, following the padded row layout of B:
+//   Wp[chunk][blk][g][n][j][q] = W[cell][c0 + cc][16 n + j],  kc' = 16 blk + 4 g + q,
+//   plane z = kc' / PS, r = kc' % PS, cell = z*sx*sy + r / CC, cc = r % CC   (r < sx*sy*CC)
+// zero for padding entries, c0+cc >= cin or 16n+j >= cout.
 __global__ void pack_filter(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2, int cin,
-                            int cout, int CC, int nchunks, int nblocks, int NT, int symmetric, int sym_axis) {
-    const int K = d0 * d1 * d2;
+                            int cout, int CC, int PS, int nchunks, int nblocks, int NT, int symmetric, int sym_axis) {
+    const int PR = d1 * d2 * CC;
     const int64_t total = (int64_t)nchunks * nblocks * 4 * NT * 16 * 4;
     const int hd[3] = {(symmetric && sym_axis == 0) ? d0 / 2 : d0, (symmetric && sym_axis == 1) ? d1 / 2 : d1,
                        (symmetric && sym_axis == 2) ? d2 / 2 : d2};
@@ -413,16 +440,17 @@ __global__ void pack_filter(const float* __restrict__ src, float* __restrict__ d
         const int g = (int)(s & 3); s >>= 2;
         const int blk = (int)(s % nblocks); s /= nblocks;
         const int chunk = (int)s;
-        const int kc = 16 * blk + 4 * g + q, cell = kc / CC, ci = chunk * CC + kc % CC, o = 16 * n + j;
+        const int kc = 16 * blk + 4 * g + q, cz = kc / PS, r = kc % PS;
+        const int ci = chunk * CC + r % CC, o = 16 * n + j;
         float v = 0.0f;
-        if (cell < K && ci < cin && o < cout) {
-            int cz = cell / (d1 * d2), cy = (cell / d2) % d1, cx = cell % d2;
-            int c3[3] = {cz, cy, cx};
+        if (cz < d0 && r < PR && ci < cin && o < cout) {
+            const int cp = r / CC;
+            int c3[3] = {cz, cp / d2, cp % d2};
             float sign = 1.0f;
             if (symmetric) {
-                const int h = hd[sym_axis];
-                if (c3[sym_axis] >= h) {
-                    c3[sym_axis] -= h;
+                const int hh = hd[sym_axis];
+                if (c3[sym_axis] >= hh) {
+                    c3[sym_axis] -= hh;
                 } else {
                     sign = -1.0f;
                     for (int a = 0; a < 3; ++a) c3[a] = hd[a] - 1 - c3[a];
@@ -435,17 +463,20 @@ __global__ void pack_filter(const float* __restrict__ src, float* __restrict__ d
 }
 
 struct LaunchCfg {
-    int CC, KCp, nblocks, NT, nchunks;
+    int CC, PS, KCp, nblocks, NT, nchunks;
     size_t lds, packed_floats, bfloats;
 };
 
-static LaunchCfg make_cfg(int K, int cin, int cout) {
+static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
     LaunchCfg c;
     c.CC = cin <= 4 ? 4 : 8;
-    const int KC = K * c.CC;
-    const int KCpad = (KC + 15) / 16 * 16;
-    c.KCp = KCpad + 4;
-    c.nblocks = KCpad / 16;
+    const int PR = sx * sy * c.CC;
+    c.PS = (PR + 15) / 16 * 16;
+    if (sz >= 2 && c.PS % 64 == 0) c.PS += 16;  // put the +z corners on other banks than the -z corners
+    const int KC = sz * c.PS;                    // multiple of 16
+    c.nblocks = KC / 16;
+    // row stride == 4 (mod 64) floats: the 16 rows read by one ds_read_b128 of the contraction spread over all banks
+    c.KCp = KC + ((4 - KC % 64) + 64) % 64;
     c.NT = (cout + 15) / 16;
     c.nchunks = (cin + c.CC - 1) / c.CC;
     size_t b_floats = (size_t)TM * c.KCp;
@@ -497,7 +528,7 @@ size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
     if (!a || validate(a) != DMCF_OK) return 256;
     int dz, dy, dx;
     full_dims(a, dz, dy, dx);
-    const LaunchCfg cfg = make_cfg(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
+    const LaunchCfg cfg = make_cfg(dx, dy, dz, a->filter_dims[3], a->filter_dims[4]);
     return 256 + align_up(cfg.packed_floats * sizeof(float), 256);
 }
 
@@ -516,14 +547,14 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.cout = a->filter_dims[4];
     p.sx = dx; p.sy = dy; p.sz = dz;
     p.K = dx * dy * dz;
-    const LaunchCfg cfg = make_cfg(p.K, p.cin, p.cout);
+    const LaunchCfg cfg = make_cfg(dx, dy, dz, p.cin, p.cout);
     if (cfg.lds > 160 * 1024) return DMCF_EUNSUPPORTED;
     {
         float* packed = (float*)workspace;
         const int64_t total = (int64_t)cfg.packed_floats;
         const unsigned g = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
-                           p.cin, p.cout, cfg.CC, cfg.nchunks, cfg.nblocks, cfg.NT,
+                           p.cin, p.cout, cfg.CC, cfg.PS, cfg.nchunks, cfg.nblocks, cfg.NT,
                            (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
         p.Wp = packed;
     }
@@ -546,6 +577,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.bias = a->bias;
     p.out = a->out;
     p.KCp = cfg.KCp;
+    p.PS = cfg.PS;
     p.nblocks = cfg.nblocks;
     p.NT = cfg.NT;
     p.nchunks = cfg.nchunks;
