@@ -82,12 +82,17 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1):
     scaled = pos / vs
     dpos = torch.cat([torch.floor(scaled - h).to(torch.int32), torch.floor(scaled + h).to(torch.int32)], dim=0)  # :142-150
     active_host = (vs_host >= 1e-5).tolist()
-    ranges = [torch.arange(-pad, 2 + pad, device=pos.device) if a else torch.arange(0, 1, device=pos.device)
-              for a in active_host]  # :151-161
+    ranges_host = [list(range(-pad, 2 + pad)) if a else [0] for a in active_host]  # :151-161
+    ranges = [torch.tensor(r, device=pos.device) for r in ranges_host]
     offset = torch.stack(torch.meshgrid(*ranges, indexing="ij"), dim=-1).reshape(1, -1, 3).to(torch.int32)
     dpos = (dpos.unsqueeze(1) + offset).reshape(-1, 3)
-    minp = dpos.min(dim=0).values  # :167-170
-    maxp = dpos.max(dim=0).values - minp + 1
+    # :167-170 -- floor is monotone, so the extrema of the 16N candidate cells follow from the extrema of the N
+    # scaled positions (a [16N,3] column reduction is ~8 ms per call on 18M rows; this one is ~0.5 ms)
+    smin, smax = scaled.min(dim=0).values, scaled.max(dim=0).values
+    off_lo = torch.tensor([r[0] for r in ranges_host], dtype=torch.int32, device=pos.device)
+    off_hi = torch.tensor([r[-1] for r in ranges_host], dtype=torch.int32, device=pos.device)
+    minp = torch.floor(smin - h).to(torch.int32) + off_lo
+    maxp = torch.floor(smax + h).to(torch.int32) + off_hi - minp + 1
     maxp64 = maxp.to(torch.int64)
     mult = torch.stack([torch.ones_like(maxp64[0]), maxp64[0], maxp64[0] * maxp64[1]])
     idx = ((dpos - minp).to(torch.int64) * mult).sum(dim=-1)
