@@ -86,11 +86,24 @@ def main():
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, weights, device=dev)
-    sim = Simulator(model, device=f"cuda:{local_rank}")
-
-    scene = scenes.box_scene(args.side, seed=2 * rank)
-    n_fluid = scene["pos"].shape[0]
-    state = scenes.model_inputs(scene, device=dev)
+    if world == 1:
+        sim = Simulator(model, device=f"cuda:{local_rank}")
+        scene = scenes.box_scene(args.side)
+        n_fluid = scene["pos"].shape[0]
+        state = scenes.model_inputs(scene, device=dev)
+        step = lambda st: sim.step([st])[0]  # noqa: E731
+    else:
+        # weak scaling: a (side*N) x side x side box, rank r owns the r-th cube (slab along x); every layer
+        # refreshes its ghost features with one all-to-all-v over RCCL (dmcf_amd/parallel.py)
+        from dmcf_amd import parallel
+        comm = parallel.TorchDistComm()
+        decomp = parallel.SlabDecomposition.uniform(0, 0.0, world * args.side * 0.05, world)
+        ssim = parallel.ShardedSimulator(model, comm, decomp)
+        scene = scenes.box_slab_scene(args.side, world, rank)
+        n_fluid = scene["pos"].shape[0]
+        state = parallel.shard_scene(scene, decomp, rank, dev)
+        state["gid"] = state["gid"] + rank * n_fluid
+        step = ssim.step
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -99,16 +112,17 @@ def main():
         torch.cuda.synchronize(dev)
 
     for _ in range(args.warmup):
-        state = sim.step([state])[0]
-    ops.timer = ops.LaunchTimer()
+        state = step(state)
+    if rank == 0:
+        ops.timer = ops.LaunchTimer()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        state = sim.step([state])[0]
+        state = step(state)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.timer = ops.timer, None
-    assert torch.isfinite(state[0]).all()
+    assert torch.isfinite(state["pos"] if isinstance(state, dict) else state[0]).all()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -134,7 +148,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic 3-D box, {n_fluid} fluid + {scene['box'].shape[0]} boundary particles per GPU, "
                                    f"Liquid3d SymNet (18 CConv/ASCC layers, reference checkpoint weights), one rollout step",
-                       "parallelism": "1 process per GPU, independent boxes (no halo exchange yet)" if world > 1 else "single GPU",
+                       "parallelism": (f"{world} slabs along x of one {world * args.side}x{args.side}x{args.side} box, 1 process per GPU, "
+                                       "per-layer ghost all-to-all-v over RCCL") if world > 1 else "single GPU",
                        "particles_per_gpu": n_fluid},
             "roofline": {"bound": "hbm", "kernel": "dmcf::cconv_kernel (all CConv/ASCC launches of the timed steps)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

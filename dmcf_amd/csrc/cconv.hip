@@ -505,7 +505,7 @@ static int validate(const dmcf_cconv_args* a) {
     if (a->interpolation < 0 || a->interpolation > 2) return DMCF_EINVAL;
     if (a->flags & DMCF_FLAG_SYMMETRIC) {
         if (a->sym_axis < 0 || a->sym_axis > 2) return DMCF_EINVAL;
-        if (a->n_inp != a->n_out) return DMCF_EINVAL;
+        if (a->n_inp < a->n_out) return DMCF_EINVAL;  // out points are inp points 0..n_out-1
     }
     if (a->filter_dims[4] > 16 * kMaxNT) return DMCF_EUNSUPPORTED;
     if (a->n_out > 0) {

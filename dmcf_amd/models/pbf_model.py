@@ -16,7 +16,7 @@ Everything particle-sized goes through the HIP library (ContinuousConv -> dmcf_a
 import numpy as np
 import torch
 
-from .. import _lib, ops
+from .. import ops
 from ..utils.convolutions import ContinuousConv
 from ..utils.tools.losses import get_dilated_pos, get_window_func
 from .base_model import BaseModel, Dense
@@ -230,10 +230,7 @@ class PBFNet(BaseModel):
         pos, vel, acc = data[:3]
         pcnt = pos.shape[0]
         # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
-        nns = self.fluid_convs.nns
-        counts = torch.empty(nns.neighbors_row_splits.shape[0] - 1, dtype=torch.float32, device=pos.device)
-        _lib.check(_lib.lib().dmcf_reduce_subarrays_sum(None, ops._ptr(nns.neighbors_row_splits), counts.shape[0],
-                                                        ops._ptr(counts), ops._stream()), "dmcf_reduce_subarrays_sum")
+        counts = ops.neighbor_counts(self.fluid_convs.nns.neighbors_row_splits)
         self.num_fluid_neighbors = counts[:pcnt]
 
         out = prev

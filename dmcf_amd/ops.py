@@ -290,3 +290,16 @@ def reduce_subarrays_sum(values, row_splits):
     _lib.check(L.dmcf_reduce_subarrays_sum(_ptr(values), _ptr(row_splits.contiguous()), n_rows, _ptr(out), _stream()),
                "dmcf_reduce_subarrays_sum")
     return out
+
+
+def neighbor_counts(row_splits):
+    """``reduce_subarrays_sum(ones_like(neighbors_index), row_splits)`` without materialising the ones
+    (models/pbf_model.py:450-453): float32 neighbour count per row."""
+    L = _lib.lib()
+    if row_splits.dtype != torch.int64 or not row_splits.is_cuda:
+        raise _lib.DmcfError("row_splits must be an int64 GPU tensor")
+    n_rows = row_splits.shape[0] - 1
+    out = torch.empty(n_rows, dtype=torch.float32, device=row_splits.device)
+    _lib.check(L.dmcf_reduce_subarrays_sum(None, _ptr(row_splits.contiguous()), n_rows, _ptr(out), _stream()),
+               "dmcf_reduce_subarrays_sum")
+    return out

@@ -64,17 +64,19 @@ def _unique_first_occurrence(idx):
     return uniq[torch.argsort(first)]
 
 
-def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1):
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     """losses.py:136-181: lattice corners of the voxels (edge ``voxel_size``) that contain a particle,
-    with +-``hyst`` hysteresis; axes with voxel_size < 1e-5 collapse (2-D / 1-D scenes)."""
+    with +-``hyst`` hysteresis; axes with voxel_size < 1e-5 collapse (2-D / 1-D scenes).
+    ``center`` (extension used by the sharded path): the lattice origin to use instead of this call's own
+    mean when ``centralize`` -- every rank passes the global mean so all ranks build the same lattice."""
     # voxel_size is kept on the host (list / numpy float32) so that the axis collapse test does not
     # force a device round trip; values are float32 like the reference's tf.constant
     vs_host = np.asarray(voxel_size.detach().cpu() if isinstance(voxel_size, torch.Tensor) else voxel_size,
                          dtype=np.float32).reshape(3)
     voxel_size = torch.from_numpy(vs_host.copy()).to(pos.device)
-    center = None
     if centralize:
-        center = pos.mean(dim=0)  # :138
+        if center is None:
+            center = pos.mean(dim=0)  # :138
         pos = pos - center
     active = voxel_size >= 1e-5
     vs = torch.clamp(voxel_size, min=1e-5)

@@ -94,7 +94,8 @@ int dmcf_frs_write(const float* queries, int64_t n_queries, int64_t n_points, fl
  * (utils/convolutions.py:410-412 and 433-458) in one pass:
  *     g = concat([-flip_zyx(filters), filters], axis=sym_axis);
  *     out[i,:] = sum_p a_p * sum_c (f_j[c] + f_i[c]) * g(Lambda(x_j - x_i))[c,:]
- * which requires inp == out point sets (n_inp == n_out).
+ * which requires the output points to be the input points 0..n_out-1 (the reference passes the same set
+ * for both, models/sym_net.py:66; n_inp > n_out is the sharded case: owned points first, ghosts after).
  * ---------------------------------------------------------------------------------------------- */
 enum dmcf_mapping {
     DMCF_MAP_BALL_TO_CUBE_RADIAL = 0,

@@ -1,0 +1,54 @@
+"""TEST-ONLY backend: routes dmcf_amd.ops through the CPU oracle so that host logic which normally needs a
+GPU (the sharded driver, the model plumbing) can be exercised on CPU with gloo.  Never imported by the
+product; installing it is an explicit act of a test."""
+import numpy as np
+import torch
+
+import oracle as O
+from dmcf_amd import ops
+
+
+def install(monkeypatch):
+    def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True, hash_table=None):
+        idx, rs, d = O.fixed_radius_search(points.numpy(), queries.numpy(), radius, ignore_query_point)
+        return ops.NeighborSearchResult(torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d))
+
+    def build_spatial_hash_table(points, radius, n_queries=None, **kw):
+        return ops.SpatialHashTable(points, radius, None, 1 << 60)
+
+    def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
+                      neighbors_value=None, window=None, window_fac=1.0, inp_importance=None, align_corners=True,
+                      coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear", normalize=False,
+                      symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False):
+        radius = np.float32(0.5) * np.float32(extent)
+        imp = None
+        if window == "explicit":
+            imp = neighbors_value.numpy()
+        elif window is not None:
+            imp = O.window(window, neighbors_value.numpy() / (radius * radius), fac=window_fac)
+        k = filters.numpy()
+        f = inp_features.numpy()
+        n_out = out_positions.shape[0]
+        kw = dict(out_positions=out_positions.numpy(), extents=extent, inp_positions=inp_positions.numpy(),
+                  neighbors_index=neighbors_index.numpy(), neighbors_row_splits=neighbors_row_splits.numpy(),
+                  neighbors_importance=imp, align_corners=align_corners, coordinate_mapping=coordinate_mapping,
+                  interpolation=interpolation, normalize=normalize)
+        if symmetric:
+            k = O.mirror_kernel(k, sym_axis)
+            y = O.continuous_conv(k, inp_features=f, **kw)
+            g = O.continuous_conv(k.reshape(*k.shape[:3], 1, -1), inp_features=np.ones_like(f[:, :1]), **kw)
+            y = y + np.einsum("nc,nco->no", f[:n_out], g.reshape(-1, k.shape[-2], k.shape[-1])).astype(np.float32)
+        else:
+            y = O.continuous_conv(k, inp_features=f, **kw)
+        if bias is not None:
+            y = y + bias.numpy()
+        y = torch.from_numpy(y.astype(np.float32))
+        if out is not None:
+            out.copy_(out + y if accumulate else y)
+            return out
+        return y
+
+    monkeypatch.setattr(ops, "fixed_radius_search", fixed_radius_search)
+    monkeypatch.setattr(ops, "build_spatial_hash_table", build_spatial_hash_table)
+    monkeypatch.setattr(ops, "cconv_forward", cconv_forward)
+    monkeypatch.setattr(ops, "neighbor_counts", lambda rs: torch.diff(rs).to(torch.float32))

@@ -1,0 +1,145 @@
+"""CPU tests of the multi-GPU path: world_size-2 gloo processes and N virtual ranks.
+
+The GPU kernels cannot run here, so the operators are routed through the CPU oracle by a TEST-ONLY shim
+(tests/shims.py); what is under test is the product's host logic: slab ownership, ghost plans, the per-layer
+all-to-all-v, the distributed lattice construction, particle migration -- and that the sharded step equals
+the unsharded one."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def _scene():
+    from tools import scenes
+    s = scenes.box_scene(6, seed=4)  # 216 fluid particles + shell
+    s2 = scenes.box_scene(6, seed=5, origin=(0.3, 0.0, 0.0))  # a second cube next to it along x
+    pos = np.concatenate([s["pos"], s2["pos"]])
+    vel = np.concatenate([s["vel"], s2["vel"]])
+    box = np.concatenate([s["box"][s["box"][:, 0] < 0.3], s2["box"][s2["box"][:, 0] > 0.3]])
+    nrm = np.concatenate([s["box_normals"][s["box"][:, 0] < 0.3], s2["box_normals"][s2["box"][:, 0] > 0.3]])
+    return dict(pos=pos, vel=vel, box=box, box_normals=nrm)
+
+
+def _build_model():
+    from dmcf_amd import models
+    from dmcf_amd.utils import tf_checkpoint as tc
+    from tools import configs
+    cfg = configs.LIQUID3D
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    model = getattr(models, cfg["name"])(**cfg)
+    tc.load_into_model(model, w, device="cpu")
+    return model
+
+
+def _run_rank(comm, decomp, scene, steps):
+    from dmcf_amd import parallel
+    model = _build_model()
+    sim = parallel.ShardedSimulator(model, comm, decomp)
+    state = parallel.shard_scene(scene, decomp, comm.rank, "cpu")
+    for _ in range(steps):
+        state = sim.step(state)
+    return dict(gid=state["gid"].numpy(), pos=state["pos"].numpy(), vel=state["vel"].numpy(),
+                exchanged=sim.exchanged_rows)
+
+
+def _assemble(parts, n):
+    pos = np.zeros((n, 3), np.float32)
+    vel = np.zeros((n, 3), np.float32)
+    seen = np.zeros(n, bool)
+    for p in parts:
+        assert not seen[p["gid"]].any(), "a particle is owned by two ranks"
+        seen[p["gid"]] = True
+        pos[p["gid"]], vel[p["gid"]] = p["pos"], p["vel"]
+    assert seen.all(), "a particle was lost in migration"
+    return pos, vel
+
+
+def _close(a, b, tol=1e-5):
+    assert np.abs(a - b).max() <= tol * np.abs(b).max(), np.abs(a - b).max() / np.abs(b).max()
+
+
+def test_slab_ownership_and_halo():
+    from dmcf_amd.parallel import SlabDecomposition
+    d = SlabDecomposition.uniform(0, 0.0, 4.0, 4)
+    pos = torch.tensor([[-5.0, 0, 0], [0.5, 0, 0], [1.0, 0, 0], [1.99, 0, 0], [2.0, 0, 0], [3.9, 0, 0], [40.0, 0, 0]])
+    assert d.owner(pos).tolist() == [0, 0, 1, 1, 2, 3, 3]
+    assert d.within(pos, 1, 0.25).tolist() == [False, False, True, True, True, False, False]
+    assert d.within(pos, 1, 0.6).tolist() == [False, True, True, True, True, False, False]
+
+
+def test_virtual_ranks_equal_single_rank(monkeypatch):
+    """2 and 3 virtual ranks (threads, LocalComm) against 1 rank, two steps, oracle backend."""
+    import shims
+    from dmcf_amd import parallel
+    shims.install(monkeypatch)
+    scene = _scene()
+    n = scene["pos"].shape[0]
+    ref = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2))
+    pos1, vel1 = _assemble(ref, n)
+    for world in (2, 3):
+        decomp = parallel.SlabDecomposition.uniform(0, 0.0, 0.6, world)
+        parts = parallel.run_local_ranks(world, lambda comm: _run_rank(comm, decomp, scene, 2))
+        assert all(p["exchanged"] > 0 for p in parts)
+        pos, vel = _assemble(parts, n)
+        _close(pos, pos1)
+        _close(vel, vel1, 2e-4)  # finite difference of positions (see tests/test_gpu_model.py)
+
+
+def test_single_rank_runner_equals_plain_model(monkeypatch):
+    import shims
+    from dmcf_amd import parallel
+    from dmcf_amd.utils.convolutions import neighbor_cache
+    shims.install(monkeypatch)
+    scene = _scene()
+    part = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 1))[0]
+    model = _build_model()
+    data = [torch.from_numpy(scene[k]) if k else None for k in ("pos", "vel", None, None, "box", "box_normals")]
+    with neighbor_cache():
+        pos, vel = model(data, training=False)
+    order = np.argsort(part["gid"])
+    _close(part["pos"][order], pos.numpy())
+
+
+def _gloo_worker(rank, world, port, scene, steps, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    import shims
+    from dmcf_amd import parallel
+
+    class MP:  # minimal monkeypatch stand-in inside the worker process
+        def setattr(self, obj, name, val):
+            setattr(obj, name, val)
+    shims.install(MP())
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        comm = parallel.TorchDistComm()
+        decomp = parallel.SlabDecomposition.uniform(0, 0.0, 0.6, world)
+        res = _run_rank(comm, decomp, scene, steps)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v for k, v in res.items() if k != "exchanged"})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gloo_world2_equals_single_rank(monkeypatch, tmp_path):
+    """Two real processes over torch.distributed (gloo) -- the production communicator class."""
+    import torch.multiprocessing as mp
+    import shims
+    from dmcf_amd import parallel
+    scene = _scene()
+    n = scene["pos"].shape[0]
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_gloo_worker, args=(2, port, scene, 2, str(tmp_path)), nprocs=2, join=True)
+    parts = [dict(np.load(os.path.join(tmp_path, f"rank{r}.npz"))) for r in range(2)]
+    pos, vel = _assemble(parts, n)
+    shims.install(monkeypatch)
+    ref = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2))
+    pos1, vel1 = _assemble(ref, n)
+    _close(pos, pos1)
+    _close(vel, vel1, 2e-4)

@@ -115,3 +115,31 @@ def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
             conv(f"model/sym_convs/{i}", cin, ch, kernel=sk, bias=False)
             cin = ch
     return w
+
+
+def box_slab_scene(side, world, rank, h=0.05, jitter=0.1, vel_std=0.1, shell_layers=2, seed=0):
+    """The part of a (side*world) x side x side box (cubes stacked along x, closed 2-layer shell around the
+    whole box) that lies in the slab of ``rank``: x index in [side*rank, side*(rank+1)), plus the end caps for
+    the first / last rank.  Used by ``bench.py --gpus N`` (weak scaling: side^3 fluid particles per GPU);
+    each rank generates only its own part."""
+    L = shell_layers
+    rng = np.random.default_rng(seed + 2 * rank)
+    ix = np.arange(side * rank, side * (rank + 1))
+    ax = (np.arange(side, dtype=np.float64) + 0.5) * h
+    pos = np.stack(np.meshgrid((ix + 0.5) * h, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    pos = pos + rng.uniform(-jitter * h, jitter * h, size=pos.shape)
+    vel = np.random.default_rng(seed + 2 * rank + 1).normal(0.0, vel_std, size=pos.shape)
+    lo = side * rank - (L if rank == 0 else 0)
+    hi = side * (rank + 1) + (L if rank == world - 1 else 0)
+    gx = np.arange(lo, hi)
+    gyz = np.arange(-L, side + L)
+    gi = np.stack(np.meshgrid(gx, gyz, gyz, indexing="ij"), -1).reshape(-1, 3)
+    total = np.array([side * world, side, side])
+    outside_lo = gi < 0
+    outside_hi = gi >= total
+    is_shell = (outside_lo | outside_hi).any(axis=1)
+    box = (gi[is_shell] + 0.5) * h
+    normals = outside_lo[is_shell].astype(np.float64) - outside_hi[is_shell].astype(np.float64)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    return dict(pos=pos.astype(np.float32), vel=vel.astype(np.float32), box=box.astype(np.float32),
+                box_normals=normals.astype(np.float32))
