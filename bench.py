@@ -119,6 +119,9 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         state = step(state)
+        if os.environ.get("DMCF_BENCH_DEBUG"):
+            torch.cuda.synchronize(dev)
+            print(f"[debug] step done at {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.timer = ops.timer, None

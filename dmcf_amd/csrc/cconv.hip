@@ -27,6 +27,8 @@
 //   * ASCC is the same kernel with pair features (f_j + f_i) and the mirrored kernel, i.e. the fused
 //     single-pass form of the reference's two continuous_conv calls + batched matmul.
 //   * consecutive tiles go to the same XCD (blockIdx swizzle) so neighbouring outputs share one L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace dmcf {
@@ -36,7 +38,7 @@ constexpr int kWaves = kThreads / 64;
 constexpr int TM = 16;           // output points per workgroup (MFMA M)
 constexpr int kMaxNT = 4;        // N tiles of 16 output channels (Cout <= 64)
 constexpr int kWStride = 8;      // staged corner weights per pair
-constexpr int kFStride = 12;     // staged features per pair (8 used; 12 keeps ds_write_b128 conflict-free)
+constexpr int kFStride = 8;      // staged features per pair
 
 struct CconvParams {
     const float* Wp;  // packed filter, see pack_filter
@@ -49,7 +51,7 @@ struct CconvParams {
     const int64_t* rs;
     const float* nval;
     int64_t n_out;
-    float inv_extent, r2, window_fac;
+    float inv_extent, inv_r2, window_fac;
     int window, mapping, interp, flags;
     const float* bias;
     float* out;
@@ -62,65 +64,79 @@ struct CconvParams {
     int ntiles, tiles_per_xcd;
 };
 
-// ---- per-pair math (float restatement of Open3D's CoordinateTransformation.h, see oracle/dmcf_oracle.c)
+// ---- per-pair math (float restatement of Open3D's CoordinateTransformation.h, see oracle/dmcf_oracle.c).
+// The splat's phase 1 is VALU-issue bound (measured: ~47 % of the kernel), so divisions and square roots
+// use the 1-ulp hardware approximations (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32) instead of the IEEE
+// sequences (~10 instructions each) and atan -- only ever called with |t| <= 1 -- is a degree-17 odd
+// polynomial (max error 1.1e-7).  Filter coordinates move by ~1e-7 relative against libm; the parity bar on
+// CConv outputs is 1e-5 and the neighbour SETS are decided elsewhere (frs.hip, exact arithmetic).
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+
+__device__ __forceinline__ float atan_unit(float t) {  // |t| <= 1
+    const float u = t * t;
+    float p = 0.0024567211512476206f;
+    p = fmaf(p, u, -0.01440134271979332f);
+    p = fmaf(p, u, 0.039781197905540466f);
+    p = fmaf(p, u, -0.07234854996204376f);
+    p = fmaf(p, u, 0.1049894466996193f);
+    p = fmaf(p, u, -0.14161229133605957f);
+    p = fmaf(p, u, 0.19985906779766083f);
+    p = fmaf(p, u, -0.33332598209381104f);
+    p = fmaf(p, u, 0.9999998807907104f);
+    return t * p;
+}
+
 __device__ __forceinline__ void sphere_to_cyl(float& x, float& y, float& z) {
-    const float sq_norm = x * x + y * y + z * z;
-    const float norm = sqrtf(sq_norm);
-    if (sq_norm < 1e-12f) {
-        x = y = z = 0.0f;
-    } else if (1.25f * z * z > (x * x + y * y)) {
-        const float s = sqrtf(3.0f * norm / (norm + fabsf(z)));
-        x *= s;
-        y *= s;
-        z = copysignf(norm, z);
-    } else {
-        const float s = norm / sqrtf(x * x + y * y);
-        x *= s;
-        y *= s;
-        z *= 1.5f;
-    }
+    const float rho2 = x * x + y * y;
+    const float sq_norm = rho2 + z * z;
+    const float norm = fast_sqrt(sq_norm);
+    const bool polar = 1.25f * z * z > rho2;
+    // polar cap: s = sqrt(3 norm / (norm + |z|)), z' = sign(z) norm;  belt: s = norm / rho, z' = 3/2 z
+    const float s_cap = fast_sqrt(3.0f * norm * fast_rcp(norm + fabsf(z)));
+    const float s_belt = norm * fast_rsq(rho2);
+    const float s = polar ? s_cap : s_belt;
+    const float zz = polar ? copysignf(norm, z) : 1.5f * z;
+    const bool tiny = sq_norm < 1e-12f;
+    x = tiny ? 0.0f : x * s;
+    y = tiny ? 0.0f : y * s;
+    z = tiny ? 0.0f : zz;
 }
 
 __device__ __forceinline__ void cyl_to_cube(float& x, float& y) {
     const float sq_norm = x * x + y * y;
-    const float norm = sqrtf(sq_norm);
+    const float norm = fast_sqrt(sq_norm);
     const float four_over_pi = 1.2732395447351628f;
-    if (sq_norm < 1e-12f) {
-        x = y = 0.0f;
-    } else if (fabsf(y) <= fabsf(x)) {
-        const float tmp = copysignf(norm, x);
-        y = tmp * four_over_pi * atanf(y / x);
-        x = tmp;
-    } else {
-        const float tmp = copysignf(norm, y);
-        x = tmp * four_over_pi * atanf(x / y);
-        y = tmp;
-    }
+    const bool xmajor = fabsf(y) <= fabsf(x);
+    const float num = xmajor ? y : x, den = xmajor ? x : y;
+    const float tmp = copysignf(norm, den);
+    const float other = tmp * four_over_pi * atan_unit(num * fast_rcp(den));
+    const bool tiny = sq_norm < 1e-12f;
+    const float nx = xmajor ? tmp : other, ny = xmajor ? other : tmp;
+    x = tiny ? 0.0f : nx;
+    y = tiny ? 0.0f : ny;
 }
 
+template <bool GENERIC>
 __device__ __forceinline__ void filter_coords(float& x, float& y, float& z, const CconvParams& p) {
-    if (p.mapping == DMCF_MAP_BALL_TO_CUBE_RADIAL) {
-        const float s = 2.0f * p.inv_extent;
-        x *= s; y *= s; z *= s;
-        const float radius = sqrtf(x * x + y * y + z * z);
-        const float abs_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-        if (abs_max < 1e-8f) {
-            x = y = z = 0.0f;
-        } else {
-            x *= 0.5f * radius / abs_max;
-            y *= 0.5f * radius / abs_max;
-            z *= 0.5f * radius / abs_max;
-        }
-    } else if (p.mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING) {
+    if (!GENERIC || p.mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING) {
         const float s = 2.0f * p.inv_extent;
         x *= s; y *= s; z *= s;
         sphere_to_cyl(x, y, z);
         cyl_to_cube(x, y);
         x *= 0.5f; y *= 0.5f; z *= 0.5f;
+    } else if (p.mapping == DMCF_MAP_BALL_TO_CUBE_RADIAL) {
+        const float s = 2.0f * p.inv_extent;
+        x *= s; y *= s; z *= s;
+        const float radius = fast_sqrt(x * x + y * y + z * z);
+        const float abs_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
+        const float k = abs_max < 1e-8f ? 0.0f : 0.5f * radius * fast_rcp(abs_max);
+        x *= k; y *= k; z *= k;
     } else {
         x *= p.inv_extent; y *= p.inv_extent; z *= p.inv_extent;
     }
-    if (p.flags & DMCF_FLAG_ALIGN_CORNERS) {
+    if (!GENERIC || (p.flags & DMCF_FLAG_ALIGN_CORNERS)) {
         x = (x + 0.5f) * (float)(p.sx - 1);
         y = (y + 0.5f) * (float)(p.sy - 1);
         z = (z + 0.5f) * (float)(p.sz - 1);
@@ -135,28 +151,28 @@ __device__ __forceinline__ void filter_coords(float& x, float& y, float& z, cons
 }
 
 // window functions of utils/tools/losses.py:8-44 on q = d^2 / R^2
-__device__ __forceinline__ float window_value(int window, float v, float r2, float fac) {
+__device__ __forceinline__ float window_value(int window, float v, float inv_r2, float fac) {
     if (window == DMCF_WINDOW_NONE) return 1.0f;
     if (window == DMCF_WINDOW_EXPLICIT) return v;
-    const float q = v / r2;
+    const float q = v * inv_r2;
     switch (window) {
         case DMCF_WINDOW_POLY6: {
             const float t = 1.0f - q;
             return fac * fminf(fmaxf(t * t * t, 0.0f), 1.0f);
         }
         case DMCF_WINDOW_CUBIC: {
-            const float s = sqrtf(q);
+            const float s = fast_sqrt(q);
             float r = 0.0f;
             if (q <= 1.0f) r = (s <= 0.5f) ? 6.0f * (s * s * s - q) + 1.0f : 2.0f * (1.0f - s) * (1.0f - s) * (1.0f - s);
-            return fac * 4.0f / 3.0f * r;
+            return fac * (4.0f / 3.0f) * r;
         }
-        case DMCF_WINDOW_LINEAR: return fac * (1.0f - sqrtf(q));
-        case DMCF_WINDOW_PEAK: return fac * (1.0f - 2.0f * sqrtf(q) + q);
+        case DMCF_WINDOW_LINEAR: return fac * (1.0f - fast_sqrt(q));
+        case DMCF_WINDOW_PEAK: return fac * (1.0f - 2.0f * fast_sqrt(q) + q);
         case DMCF_WINDOW_CUBIC_GRAD: {
-            const float s = sqrtf(q);
+            const float s = fast_sqrt(q);
             float r = 0.0f;
             if (q <= 1.0f) r = (s <= 0.5f) ? 18.0f * q - 12.0f * s : -6.0f * (1.0f - s) * (1.0f - s);
-            return fac * 4.0f / 3.0f * r;
+            return fac * (4.0f / 3.0f) * r;
         }
     }
     return 1.0f;
@@ -202,17 +218,27 @@ __device__ __forceinline__ void axis_weights(float x, int s, int interp, int& b,
     b = 0; w0 = v1; w1 = 0.0f;
 }
 
+// INTERP_LINEAR only, branch free (the non-GENERIC instantiation)
+__device__ __forceinline__ void axis_weights_linear(float x, int s, int& b, float& w0, float& w1) {
+    const float bmax = (float)(s >= 2 ? s - 2 : 0);
+    x = fminf((float)(s - 1), fmaxf(0.0f, x));
+    const float xf = fminf(floorf(x), bmax);
+    b = (int)xf;
+    const float a = x - xf;
+    w0 = 1.0f - a;
+    w1 = a;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// float offset of filter cell (bx,by,bz) inside a row of B.  z planes are padded to a multiple of 16
-// floats (+16 when the plane is a multiple of 64 floats, so that the +z corners of a pair fall on
-// other LDS banks than the -z corners) -- "PS" = plane stride.
-__device__ __forceinline__ int cell_offset(int bx, int by, int bz, int sx, int PS, int CC) {
-    return bz * PS + (by * sx + bx) * CC;
-}
+// Layout of one row of B (floats): [z plane][y row][x cell][channel].  z planes are padded to "PS" floats so
+// that the +z corners of a pair fall on other LDS banks than the -z corners (make_cfg picks the padding with a
+// small bank model).  A rotation of odd y rows that also separates the +-y corners in the 32-bank write
+// model was tried and removed: the extra v_readlane / bit-field work in the splat loop, which is co-limited
+// by instruction issue and the LDS pipe, cost more (+48 % kernel time) than the conflicts it removed.
 
-template <int CC>
+template <int CC, bool GENERIC>
 __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -223,6 +249,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     float* stage = norm + TM + (size_t)wave * 64 * (kWStride + kFStride);
     float* wst = stage;                                 // [64][kWStride]
     float* fst = stage + 64 * kWStride;                 // [64][kFStride]
+    float* deadbase = norm + TM + (size_t)kWaves * 64 * (kWStride + kFStride);  // [kThreads][2], only if a filter axis is 1
     // XCD-aware tile order: blocks b, b+8, b+16.. (same XCD) take consecutive tiles
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
@@ -249,8 +276,8 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     // phase-2 lane role inside a half-wave: corner t (bit0 x, bit1 y, bit2 z) x 4 channel groups
     constexpr int CPL = CC / 4;  // channels per lane (2 -> 64-bit read-modify-write, 1 -> 32-bit)
     const int t = pl >> 2, c4 = pl & 3;
-    const int lane_off = cell_offset((t & 1) && p.sx >= 2, ((t >> 1) & 1) && p.sy >= 2, ((t >> 2) & 1) && p.sz >= 2,
-                                     p.sx, PS, CC) + c4 * CPL;
+    const int tx = (t & 1) && p.sx >= 2, ty = ((t >> 1) & 1) && p.sy >= 2, tz = ((t >> 2) & 1) && p.sz >= 2;
+    const int lane_off = tz * PS + (ty * p.sx + tx) * CC + c4 * CPL;  // this corner's offset from the base cell
     // a "+1" corner along an axis of size 1 has weight 0 and would alias the base cell: such lanes stay idle
     const bool lane_live = !(((t & 1) && p.sx < 2) || ((t & 2) && p.sy < 2) || ((t & 4) && p.sz < 2));
 
@@ -271,63 +298,100 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         for (int u = 0; u < CC; ++u)
             fi[u] = (symmetric && pt_valid && c0 + u < cin) ? p.inp_feat[i * cin + c0 + u] : 0.0f;
         float nsum = 0.0f;
+        // Software pipeline over batches of 32 neighbours per half-wave: the (index, distance) loads run two
+        // batches ahead and the dependent (position, feature) gathers one batch ahead of the splat that
+        // consumes them, so the ~2 us index -> gather latency chain overlaps the LDS-bound phase 2.
+        auto load_idx = [&](int bi, int& j, float& nv, bool& valid) {
+            const int64_t pp = rb + 32 * (int64_t)bi + pl;
+            valid = pp < re;
+            j = 0;
+            nv = 0.0f;
+            if (valid) {
+                j = p.idx[pp];
+                if (p.nval) nv = p.nval[pp];
+            }
+        };
+        auto gather = [&](int j, bool valid, float& px, float& py, float& pz, float (&f)[CC]) {
+            px = py = pz = 0.0f;
+#pragma unroll
+            for (int u = 0; u < CC; ++u) f[u] = 0.0f;
+            if (valid) {
+                const float* fp = p.inp_feat + (int64_t)j * cin + c0;
+                if ((cin & 3) == 0) {  // rows are 16-byte aligned: vector gathers
+#pragma unroll
+                    for (int u = 0; u < CC; u += 4) {
+                        if (c0 + u < cin) {
+                            const f32x4 v = *(const f32x4*)(fp + u);
+                            f[u] = v.x; f[u + 1] = v.y; f[u + 2] = v.z; f[u + 3] = v.w;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int u = 0; u < CC; ++u)
+                        if (c0 + u < cin) f[u] = fp[u];
+                }
+                px = p.inp_pos[3 * (int64_t)j];
+                py = p.inp_pos[3 * (int64_t)j + 1];
+                pz = p.inp_pos[3 * (int64_t)j + 2];
+            }
+        };
+        int jA, jB;
+        float nvA, nvB;
+        bool vA, vB;
+        load_idx(0, jA, nvA, vA);
+        load_idx(1, jB, nvB, vB);
+        float gx, gy, gz, gf[CC];
+        gather(jA, vA, gx, gy, gz, gf);
         for (int bi = 0; bi < nbatch; ++bi) {
+            // issue the loads of the following batches first
+            float nx, ny, nz, nf[CC];
+            gather(jB, vB, nx, ny, nz, nf);
+            int jC;
+            float nvC;
+            bool vC;
+            load_idx(bi + 2, jC, nvC, vC);
             // ---- phase 1: one lane per neighbour, 32 neighbours of each of the wave's two points
-            const int64_t pp = rb + 32 * bi + pl;
-            const bool pvalid = pp < re;
             int np_h = cnt - 32 * bi;  // pairs of this half in the batch (may be <= 0)
             np_h = min(max(np_h, 0), 32);
             int base = 0;
             {
-                int j = 0;
                 float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
-                float f[CC];
-#pragma unroll
-                for (int u = 0; u < CC; ++u) f[u] = 0.0f;
-                if (pvalid) {
-                    j = p.idx[pp];
-                    const float nv = p.nval ? p.nval[pp] : 0.0f;
-                    const float* fp = p.inp_feat + (int64_t)j * cin + c0;
-                    if ((cin & 3) == 0) {  // rows are 16-byte aligned: vector gathers
-#pragma unroll
-                        for (int u = 0; u < CC; u += 4) {
-                            if (c0 + u < cin) {
-                                const f32x4 v = *(const f32x4*)(fp + u);
-                                f[u] = v.x; f[u + 1] = v.y; f[u + 2] = v.z; f[u + 3] = v.w;
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < CC; ++u)
-                            if (c0 + u < cin) f[u] = fp[u];
-                    }
-                    x = p.inp_pos[3 * (int64_t)j] - ox;
-                    y = p.inp_pos[3 * (int64_t)j + 1] - oy;
-                    z = p.inp_pos[3 * (int64_t)j + 2] - oz;
-                    a = window_value(p.window, nv, p.r2, p.window_fac);
+                if (vA) {
+                    x = gx - ox;
+                    y = gy - oy;
+                    z = gz - oz;
+                    a = window_value(p.window, nvA, p.inv_r2, p.window_fac);
                     nsum += a;
-                    if (p.inp_imp) a *= p.inp_imp[j];
-                    filter_coords(x, y, z, p);
+                    if (p.inp_imp) a *= p.inp_imp[jA];
+                    filter_coords<GENERIC>(x, y, z, p);
                 }
                 int bx, by, bz;
                 float wx0, wx1, wy0, wy1, wz0, wz1;
-                axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
-                axis_weights(y, p.sy, p.interp, by, wy0, wy1);
-                axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
-                base = cell_offset(bx, by, bz, p.sx, PS, CC);
+                if (GENERIC) {
+                    axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
+                    axis_weights(y, p.sy, p.interp, by, wy0, wy1);
+                    axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                } else {
+                    axis_weights_linear(x, p.sx, bx, wx0, wx1);
+                    axis_weights_linear(y, p.sy, by, wy0, wy1);
+                    axis_weights_linear(z, p.sz, bz, wz0, wz1);
+                }
+                base = bz * PS + (by * p.sx + bx) * CC;
                 // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
                 const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
+                // the two float4 halves of a pair's weights swap places every 4 lanes: conflict-free b128 stores
                 float* wr = wst + lane * kWStride;
-                *(f32x4*)(wr) = (f32x4){w00 * wz0, w10 * wz0, w01 * wz0, w11 * wz0};
-                *(f32x4*)(wr + 4) = (f32x4){w00 * wz1, w10 * wz1, w01 * wz1, w11 * wz1};
+                const int wsw = (lane >> 2) & 1;
+                *(f32x4*)(wr + 4 * wsw) = (f32x4){w00 * wz0, w10 * wz0, w01 * wz0, w11 * wz0};
+                *(f32x4*)(wr + 4 * (wsw ^ 1)) = (f32x4){w00 * wz1, w10 * wz1, w01 * wz1, w11 * wz1};
                 float* fr = fst + lane * kFStride;
-                if (symmetric) {
+                if (symmetric && vA) {
 #pragma unroll
-                    for (int u = 0; u < CC; ++u) f[u] += fi[u];
+                    for (int u = 0; u < CC; ++u) gf[u] += fi[u];
                 }
 #pragma unroll
-                for (int u = 0; u < CC; u += 4)
-                    *(f32x4*)(fr + u) = (f32x4){f[u] * a, f[u + 1] * a, f[u + 2] * a, f[u + 3] * a};
+                for (int u = 0; u < CC; u += 4)  // same half swap as the weights (CC = 8): conflict-free b128 stores
+                    *(f32x4*)(fr + (CC == 8 ? (u ^ (4 * wsw)) : u)) = (f32x4){gf[u] * a, gf[u + 1] * a, gf[u + 2] * a, gf[u + 3] * a};
             }
             // The staging area is private to this wave and LDS operations of one wave are processed in
             // order, so no barrier is needed between the phases.
@@ -336,33 +400,38 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
             // 3 clocks on gfx950 (measured ~200 clk per 64-lane instruction).  Race free: a row of B
             // belongs to one half-wave, the active lanes of a half hit distinct addresses (8 distinct
             // cells x channels; lanes whose "+1" cell collapses onto the base cell because that filter
-            // axis has size 1 carry weight 0 and are masked off), and the two halves work on two rows.
+            // axis has size 1 carry weight 0 and are parked on a private slot), and the two halves work
+            // on two rows.  Branch-free body: slots beyond a half's pair count hold zero features
+            // (phase 1 wrote f*a = 0 and a valid base cell for them), so they add 0.
             const int nq = max(__builtin_amdgcn_readlane(np_h, 0), __builtin_amdgcn_readlane(np_h, 32));
-            const float* wsrc = wst + (32 * h) * kWStride + t;
-            const float* fsrc = fst + (32 * h) * kFStride + c4 * CPL;
-            // Branch-free body so that it can be unrolled and its LDS reads hoisted: slots beyond a half's
-            // pair count hold zero features (phase 1 wrote f*a = 0 and a valid base cell for them), so they
-            // add 0; dead lanes (size-1 axes) read-modify-write a private spare slot of the staging row.
-            float* dead = fst + lane * kFStride + 8;
+            const float* wsrc = wst + (32 * h) * kWStride;
+            const float* fsrc = fst + (32 * h) * kFStride;
+            float* dead = deadbase + 2 * tid;
 #pragma unroll 4
             for (int q = 0; q < nq; ++q) {
                 const int b0 = __builtin_amdgcn_readlane(base, q);
                 const int b1 = __builtin_amdgcn_readlane(base, 32 + q);
-                const int bq = h ? b1 : b0;
-                const float w = wsrc[q * kWStride];
+                const int off = (h ? b1 : b0) + lane_off;
+                const float w = wsrc[q * kWStride + (t ^ (((q >> 2) & 1) << 2))];
                 if constexpr (CPL == 2) {
-                    const f32x2 fv = *(const f32x2*)(fsrc + q * kFStride);
-                    f32x2* dst = (f32x2*)(lane_live ? Brow + bq + lane_off : dead);
+                    const f32x2 fv = *(const f32x2*)(fsrc + q * kFStride + ((c4 * 2) ^ (((q >> 2) & 1) << 2)));
+                    f32x2* dst = (f32x2*)(lane_live ? Brow + off : dead);
                     f32x2 o = *dst;
                     o.x += w * fv.x;
                     o.y += w * fv.y;
                     *dst = o;
                 } else {
-                    const float fv = fsrc[q * kFStride];
-                    float* dst = lane_live ? Brow + bq + lane_off : dead;
+                    const float fv = fsrc[q * kFStride + c4];
+                    float* dst = lane_live ? Brow + off : dead;
                     *dst = *dst + w * fv;
                 }
             }
+            // rotate the pipeline registers
+            jA = jB; nvA = nvB; vA = vB;
+            jB = jC; nvB = nvC; vB = vC;
+            gx = nx; gy = ny; gz = nz;
+#pragma unroll
+            for (int u = 0; u < CC; ++u) gf[u] = nf[u];
         }
         if (chunk == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
 #pragma unroll
@@ -471,9 +540,50 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
     LaunchCfg c;
     c.CC = cin <= 4 ? 4 : 8;
     const int PR = sx * sy * c.CC;
-    c.PS = (PR + 15) / 16 * 16;
-    if (sz >= 2 && c.PS % 64 == 0) c.PS += 16;  // put the +z corners on other banks than the -z corners
-    const int KC = sz * c.PS;                    // multiple of 16
+    // Plane stride: the smallest padding of the z plane for which the 8 corners of a pair are conflict free
+    // in the LDS bank models of the splat's accesses (CC = 8: 64-bit reads see 64 banks over the 8 corners of
+    // a half-wave, 64-bit writes 32 banks over 4 corners at a time; CC = 4: 32-bit accesses, 32 banks over all
+    // 8 corners), while one workgroup's B tile still fits.
+    auto conflicts = [&](int PS) {
+        int bad = 0;
+        for (int by = 0; by < 2; ++by)
+            for (int bx = 0; bx < 2; ++bx) {
+                int off[8];
+                for (int t = 0; t < 8; ++t) {
+                    const int tx = (t & 1) && sx >= 2, ty = ((t >> 1) & 1) && sy >= 2, tz = ((t >> 2) & 1) && sz >= 2;
+                    off[t] = tz * PS + ((by + ty) * sx + bx + tx) * c.CC;
+                }
+                for (int a = 0; a < 8; ++a)
+                    for (int b = a + 1; b < 8; ++b) {
+                        if (off[a] == off[b]) continue;  // collapsed corners are masked off in the kernel
+                        const int rd = c.CC == 8 ? 64 : 32;
+                        if ((off[a] % rd) / c.CC == (off[b] % rd) / c.CC) ++bad;                        // read model
+                        if ((a < 4) == (b < 4) && (off[a] % 32) / c.CC == (off[b] % 32) / c.CC) ++bad;  // write model
+                    }
+            }
+        return bad;
+    };
+    const bool has_dead = sx < 2 || sy < 2 || sz < 2;
+    auto lds_bytes = [&](int PS) {
+        const int KCx = (sz * PS + 15) / 16 * 16;
+        const size_t kcp = KCx + ((4 - KCx % 64) + 64) % 64;
+        size_t bf = (size_t)TM * kcp;
+        const size_t rf = (size_t)kWaves * TM * 16 * ((cout + 15) / 16);
+        if (bf < rf) bf = rf;
+        return (bf + TM + (size_t)kWaves * 64 * (kWStride + kFStride) + (has_dead ? 2 * kThreads : 0)) * sizeof(float);
+    };
+    const int PS0 = (PR + 7) / 8 * 8;
+    const size_t step = lds_bytes(PS0) <= 80 * 1024 ? 80 * 1024 : 160 * 1024;  // keep the occupancy step of the unpadded tile
+    int best = PS0, best_bad = 1 << 30;
+    for (int k = 0; k < 12; ++k) {
+        const int PS = PS0 + 8 * k;
+        if (k > 0 && (sz < 2 || lds_bytes(PS) > step)) break;
+        const int bad = conflicts(PS);
+        if (bad < best_bad) { best_bad = bad; best = PS; }
+        if (bad == 0) break;
+    }
+    c.PS = best;
+    const int KC = (sz * c.PS + 15) / 16 * 16;  // multiple of 16 (k blocks of the contraction)
     c.nblocks = KC / 16;
     // row stride == 4 (mod 64) floats: the 16 rows read by one ds_read_b128 of the contraction spread over all banks
     c.KCp = KC + ((4 - KC % 64) + 64) % 64;
@@ -483,7 +593,7 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
     const size_t red_floats = (size_t)kWaves * TM * 16 * c.NT;
     if (b_floats < red_floats) b_floats = red_floats;  // the reduction buffer reuses B
     c.bfloats = b_floats;
-    c.lds = (b_floats + TM + (size_t)kWaves * 64 * (kWStride + kFStride)) * sizeof(float);
+    c.lds = lds_bytes(c.PS);
     c.packed_floats = (size_t)c.nchunks * c.nblocks * 4 * c.NT * 16 * 4;
     return c;
 }
@@ -568,7 +678,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.n_out = a->n_out;
     p.inv_extent = 1.0f / a->extent;
     const float radius = 0.5f * a->extent;
-    p.r2 = radius * radius;
+    p.inv_r2 = 1.0f / (radius * radius);
     p.window_fac = a->window_fac;
     p.window = a->window;
     p.mapping = a->coordinate_mapping;
@@ -587,16 +697,16 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
-    hipError_t e;
-    if (cfg.CC == 8) {
-        e = hipFuncSetAttribute((const void*)cconv_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
-        hipLaunchKernelGGL((cconv_kernel<8>), dim3(grid), dim3(kThreads), cfg.lds, stream, p);
-    } else {
-        e = hipFuncSetAttribute((const void*)cconv_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
-        if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
-        hipLaunchKernelGGL((cconv_kernel<4>), dim3(grid), dim3(kThreads), cfg.lds, stream, p);
-    }
+    // the flag set every DMCF model uses (models/pbf_model.py:210-221) gets a specialised instantiation
+    const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
+                           a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
+    const void* fn = cfg.CC == 8 ? (generic ? (const void*)cconv_kernel<8, true> : (const void*)cconv_kernel<8, false>)
+                                 : (generic ? (const void*)cconv_kernel<4, true> : (const void*)cconv_kernel<4, false>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
+    void* kargs[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(kThreads), kargs, cfg.lds, stream);
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
     return check_launch();
 }
 
