@@ -38,6 +38,8 @@ class CconvArgs(ctypes.Structure):
         ("flags", ctypes.c_int32),
         ("bias", ctypes.c_void_p),
         ("out", ctypes.c_void_p),
+        ("geometry", ctypes.c_void_p),
+        ("n_pairs", ctypes.c_int64),
     ]
 
 
@@ -45,7 +47,7 @@ class CconvArgs(ctypes.Structure):
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write",
-    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward",
+    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
     "dmcf_reduce_subarrays_sum",
 ]
 
@@ -88,6 +90,10 @@ def lib():
     L.dmcf_cconv_workspace_bytes.argtypes = [c.POINTER(CconvArgs)]
     L.dmcf_cconv_forward.restype = c.c_int
     L.dmcf_cconv_forward.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_cconv_geometry_bytes.restype = c.c_size_t
+    L.dmcf_cconv_geometry_bytes.argtypes = [c.c_int64]
+    L.dmcf_cconv_geometry.restype = c.c_int
+    L.dmcf_cconv_geometry.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_reduce_subarrays_sum.restype = c.c_int
     L.dmcf_reduce_subarrays_sum.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
     _lib = L

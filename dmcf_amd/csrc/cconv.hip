@@ -29,7 +29,7 @@
 //   * consecutive tiles go to the same XCD (blockIdx swizzle) so neighbouring outputs share one L2.
 #include <stdlib.h>
 
-#include "common.h"
+#include "cconv_common.h"
 
 namespace dmcf {
 
@@ -40,205 +40,13 @@ constexpr int kMaxNT = 4;        // N tiles of 16 output channels (Cout <= 64)
 constexpr int kWStride = 8;      // staged corner weights per pair
 constexpr int kFStride = 8;      // staged features per pair
 
-struct CconvParams {
-    const float* Wp;  // packed filter, see pack_filter
-    int sx, sy, sz, K, cin, cout;
-    const float* out_pos;
-    const float* inp_pos;
-    const float* inp_feat;
-    const float* inp_imp;
-    const int32_t* idx;
-    const int64_t* rs;
-    const float* nval;
-    int64_t n_out;
-    float inv_extent, inv_r2, window_fac;
-    int window, mapping, interp, flags;
-    const float* bias;
-    float* out;
-    int PS;        // plane stride of B in floats (see cell_offset)
-    int KCp;       // row stride of B in floats: sz*PS padded to 4 (mod 64)
-    int nblocks;   // sz*PS/16 : 16-wide k blocks per chunk
-    int NT;        // ceil(cout/16)
-    int nchunks;   // ceil(cin/CC)
-    int bfloats;   // floats reserved for B / the reduction buffer (whichever is larger)
-    int ntiles, tiles_per_xcd;
-};
-
-// ---- per-pair math (float restatement of Open3D's CoordinateTransformation.h, see oracle/dmcf_oracle.c).
-// The splat's phase 1 is VALU-issue bound (measured: ~47 % of the kernel), so divisions and square roots
-// use the 1-ulp hardware approximations (v_rcp_f32 / v_sqrt_f32 / v_rsq_f32) instead of the IEEE
-// sequences (~10 instructions each) and atan -- only ever called with |t| <= 1 -- is a degree-17 odd
-// polynomial (max error 1.1e-7).  Filter coordinates move by ~1e-7 relative against libm; the parity bar on
-// CConv outputs is 1e-5 and the neighbour SETS are decided elsewhere (frs.hip, exact arithmetic).
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
-
-__device__ __forceinline__ float atan_unit(float t) {  // |t| <= 1
-    const float u = t * t;
-    float p = 0.0024567211512476206f;
-    p = fmaf(p, u, -0.01440134271979332f);
-    p = fmaf(p, u, 0.039781197905540466f);
-    p = fmaf(p, u, -0.07234854996204376f);
-    p = fmaf(p, u, 0.1049894466996193f);
-    p = fmaf(p, u, -0.14161229133605957f);
-    p = fmaf(p, u, 0.19985906779766083f);
-    p = fmaf(p, u, -0.33332598209381104f);
-    p = fmaf(p, u, 0.9999998807907104f);
-    return t * p;
-}
-
-__device__ __forceinline__ void sphere_to_cyl(float& x, float& y, float& z) {
-    const float rho2 = x * x + y * y;
-    const float sq_norm = rho2 + z * z;
-    const float norm = fast_sqrt(sq_norm);
-    const bool polar = 1.25f * z * z > rho2;
-    // polar cap: s = sqrt(3 norm / (norm + |z|)), z' = sign(z) norm;  belt: s = norm / rho, z' = 3/2 z
-    const float s_cap = fast_sqrt(3.0f * norm * fast_rcp(norm + fabsf(z)));
-    const float s_belt = norm * fast_rsq(rho2);
-    const float s = polar ? s_cap : s_belt;
-    const float zz = polar ? copysignf(norm, z) : 1.5f * z;
-    const bool tiny = sq_norm < 1e-12f;
-    x = tiny ? 0.0f : x * s;
-    y = tiny ? 0.0f : y * s;
-    z = tiny ? 0.0f : zz;
-}
-
-__device__ __forceinline__ void cyl_to_cube(float& x, float& y) {
-    const float sq_norm = x * x + y * y;
-    const float norm = fast_sqrt(sq_norm);
-    const float four_over_pi = 1.2732395447351628f;
-    const bool xmajor = fabsf(y) <= fabsf(x);
-    const float num = xmajor ? y : x, den = xmajor ? x : y;
-    const float tmp = copysignf(norm, den);
-    const float other = tmp * four_over_pi * atan_unit(num * fast_rcp(den));
-    const bool tiny = sq_norm < 1e-12f;
-    const float nx = xmajor ? tmp : other, ny = xmajor ? other : tmp;
-    x = tiny ? 0.0f : nx;
-    y = tiny ? 0.0f : ny;
-}
-
-template <bool GENERIC>
-__device__ __forceinline__ void filter_coords(float& x, float& y, float& z, const CconvParams& p) {
-    if (!GENERIC || p.mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING) {
-        const float s = 2.0f * p.inv_extent;
-        x *= s; y *= s; z *= s;
-        sphere_to_cyl(x, y, z);
-        cyl_to_cube(x, y);
-        x *= 0.5f; y *= 0.5f; z *= 0.5f;
-    } else if (p.mapping == DMCF_MAP_BALL_TO_CUBE_RADIAL) {
-        const float s = 2.0f * p.inv_extent;
-        x *= s; y *= s; z *= s;
-        const float radius = fast_sqrt(x * x + y * y + z * z);
-        const float abs_max = fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z)));
-        const float k = abs_max < 1e-8f ? 0.0f : 0.5f * radius * fast_rcp(abs_max);
-        x *= k; y *= k; z *= k;
-    } else {
-        x *= p.inv_extent; y *= p.inv_extent; z *= p.inv_extent;
-    }
-    if (!GENERIC || (p.flags & DMCF_FLAG_ALIGN_CORNERS)) {
-        x = (x + 0.5f) * (float)(p.sx - 1);
-        y = (y + 0.5f) * (float)(p.sy - 1);
-        z = (z + 0.5f) * (float)(p.sz - 1);
-    } else {
-        x = x * (float)p.sx + (float)(p.sx / 2);
-        y = y * (float)p.sy + (float)(p.sy / 2);
-        z = z * (float)p.sz + (float)(p.sz / 2);
-        if (p.sx % 2 == 0) x -= 0.5f;
-        if (p.sy % 2 == 0) y -= 0.5f;
-        if (p.sz % 2 == 0) z -= 0.5f;
-    }
-}
-
-// window functions of utils/tools/losses.py:8-44 on q = d^2 / R^2
-__device__ __forceinline__ float window_value(int window, float v, float inv_r2, float fac) {
-    if (window == DMCF_WINDOW_NONE) return 1.0f;
-    if (window == DMCF_WINDOW_EXPLICIT) return v;
-    const float q = v * inv_r2;
-    switch (window) {
-        case DMCF_WINDOW_POLY6: {
-            const float t = 1.0f - q;
-            return fac * fminf(fmaxf(t * t * t, 0.0f), 1.0f);
-        }
-        case DMCF_WINDOW_CUBIC: {
-            const float s = fast_sqrt(q);
-            float r = 0.0f;
-            if (q <= 1.0f) r = (s <= 0.5f) ? 6.0f * (s * s * s - q) + 1.0f : 2.0f * (1.0f - s) * (1.0f - s) * (1.0f - s);
-            return fac * (4.0f / 3.0f) * r;
-        }
-        case DMCF_WINDOW_LINEAR: return fac * (1.0f - fast_sqrt(q));
-        case DMCF_WINDOW_PEAK: return fac * (1.0f - 2.0f * fast_sqrt(q) + q);
-        case DMCF_WINDOW_CUBIC_GRAD: {
-            const float s = fast_sqrt(q);
-            float r = 0.0f;
-            if (q <= 1.0f) r = (s <= 0.5f) ? 18.0f * q - 12.0f * s : -6.0f * (1.0f - s) * (1.0f - s);
-            return fac * (4.0f / 3.0f) * r;
-        }
-    }
-    return 1.0f;
-}
-
-// Interpolation along one axis as (base cell b, weight of b, weight of b+1) with 0 <= b <= max(s-2, 0),
-// so that the two cells are always inside the filter array (for s == 1 the second weight is 0 and
-// the lane offsets of "b+1" collapse onto b).  Equivalent to Open3D's clamped / bordered / nearest
-// lookups: weights that the library would put on a clamped duplicate or outside cell are 0 here.
-__device__ __forceinline__ void axis_weights(float x, int s, int interp, int& b, float& w0, float& w1) {
-    const int bmax = s >= 2 ? s - 2 : 0;
-    if (interp == DMCF_INTERP_NEAREST) {
-        int c = (int)roundf(x);
-        c = min(max(c, 0), s - 1);
-        b = min(c, bmax);
-        w0 = (c == b) ? 1.0f : 0.0f;
-        w1 = 1.0f - w0;
-        return;
-    }
-    if (interp == DMCF_INTERP_LINEAR) {  // coordinate clamping
-        x = fminf((float)(s - 1), fmaxf(0.0f, x));
-        const float xf = fminf(floorf(x), (float)bmax);
-        b = (int)xf;
-        const float a = x - xf;  // in [0,1]; == 1 exactly when x == s-1 (then all weight on cell s-1)
-        w0 = 1.0f - a;
-        w1 = a;
-        if (s == 1) { w0 = 1.0f; w1 = 0.0f; }
-        return;
-    }
-    // LINEAR_BORDER: cells xf and xf+1 with weights (1-a, a); cells outside [0, s-1] contribute nothing
-    const float xf = floorf(x);
-    const float a = x - xf;
-    const float c0 = xf, c1 = xf + 1.0f;
-    const bool in0 = c0 >= 0.0f && c0 <= (float)(s - 1), in1 = c1 >= 0.0f && c1 <= (float)(s - 1);
-    const float v0 = in0 ? 1.0f - a : 0.0f, v1 = in1 ? a : 0.0f;
-    if (!in0 && !in1) { b = 0; w0 = w1 = 0.0f; return; }
-    if (in0 && in1) { b = (int)c0; w0 = v0; w1 = v1; return; }  // then c0 <= s-2
-    if (in0) {  // c0 == s-1, c1 outside
-        if (s >= 2) { b = s - 2; w0 = 0.0f; w1 = v0; } else { b = 0; w0 = v0; w1 = 0.0f; }
-        return;
-    }
-    // in1 only: c1 == 0, c0 == -1
-    b = 0; w0 = v1; w1 = 0.0f;
-}
-
-// INTERP_LINEAR only, branch free (the non-GENERIC instantiation)
-__device__ __forceinline__ void axis_weights_linear(float x, int s, int& b, float& w0, float& w1) {
-    const float bmax = (float)(s >= 2 ? s - 2 : 0);
-    x = fminf((float)(s - 1), fmaxf(0.0f, x));
-    const float xf = fminf(floorf(x), bmax);
-    b = (int)xf;
-    const float a = x - xf;
-    w0 = 1.0f - a;
-    w1 = a;
-}
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-
 // Layout of one row of B (floats): [z plane][y row][x cell][channel].  z planes are padded to "PS" floats so
 // that the +z corners of a pair fall on other LDS banks than the -z corners (make_cfg picks the padding with a
 // small bank model).  A rotation of odd y rows that also separates the +-y corners in the 32-bank write
 // model was tried and removed: the extra v_readlane / bit-field work in the splat loop, which is co-limited
 // by instruction issue and the LDS pipe, cost more (+48 % kernel time) than the conflicts it removed.
 
-template <int CC, bool GENERIC>
+template <int CC, bool GENERIC, bool GEO>
 __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -301,14 +109,23 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         // Software pipeline over batches of 32 neighbours per half-wave: the (index, distance) loads run two
         // batches ahead and the dependent (position, feature) gathers one batch ahead of the splat that
         // consumes them, so the ~2 us index -> gather latency chain overlaps the LDS-bound phase 2.
-        auto load_idx = [&](int bi, int& j, float& nv, bool& valid) {
+        // GEO: the per-pair geometry (window value, base cell, the three "+1" axis weights) comes from a cache
+        // built once per (neighbour search, filter geometry) by cconv_geometry_kernel and shared by every layer
+        // and channel chunk that uses the same search -- no position gather, no ball->cube map here.
+        auto load_idx = [&](int bi, int& j, f32x4& g, int& gb, bool& valid) {
             const int64_t pp = rb + 32 * (int64_t)bi + pl;
             valid = pp < re;
             j = 0;
-            nv = 0.0f;
+            gb = 0;
+            g = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (valid) {
                 j = p.idx[pp];
-                if (p.nval) nv = p.nval[pp];
+                if constexpr (GEO) {
+                    g = p.geo4[pp];
+                    gb = p.geob[pp];
+                } else {
+                    if (p.nval) g.w = p.nval[pp];
+                }
             }
         };
         auto gather = [&](int j, bool valid, float& px, float& py, float& pz, float (&f)[CC]) {
@@ -330,51 +147,63 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                     for (int u = 0; u < CC; ++u)
                         if (c0 + u < cin) f[u] = fp[u];
                 }
-                px = p.inp_pos[3 * (int64_t)j];
-                py = p.inp_pos[3 * (int64_t)j + 1];
-                pz = p.inp_pos[3 * (int64_t)j + 2];
+                if constexpr (!GEO) {
+                    px = p.inp_pos[3 * (int64_t)j];
+                    py = p.inp_pos[3 * (int64_t)j + 1];
+                    pz = p.inp_pos[3 * (int64_t)j + 2];
+                }
             }
         };
-        int jA, jB;
-        float nvA, nvB;
+        int jA, jB, gbA, gbB;
+        f32x4 gA, gB;
         bool vA, vB;
-        load_idx(0, jA, nvA, vA);
-        load_idx(1, jB, nvB, vB);
+        load_idx(0, jA, gA, gbA, vA);
+        load_idx(1, jB, gB, gbB, vB);
         float gx, gy, gz, gf[CC];
         gather(jA, vA, gx, gy, gz, gf);
         for (int bi = 0; bi < nbatch; ++bi) {
             // issue the loads of the following batches first
             float nx, ny, nz, nf[CC];
             gather(jB, vB, nx, ny, nz, nf);
-            int jC;
-            float nvC;
+            int jC, gbC;
+            f32x4 gC;
             bool vC;
-            load_idx(bi + 2, jC, nvC, vC);
+            load_idx(bi + 2, jC, gC, gbC, vC);
             // ---- phase 1: one lane per neighbour, 32 neighbours of each of the wave's two points
             int np_h = cnt - 32 * bi;  // pairs of this half in the batch (may be <= 0)
             np_h = min(max(np_h, 0), 32);
             int base = 0;
             {
-                float a = 0.0f, x = 0.0f, y = 0.0f, z = 0.0f;
-                if (vA) {
-                    x = gx - ox;
-                    y = gy - oy;
-                    z = gz - oz;
-                    a = window_value(p.window, nvA, p.inv_r2, p.window_fac);
-                    nsum += a;
-                    if (p.inp_imp) a *= p.inp_imp[jA];
-                    filter_coords<GENERIC>(x, y, z, p);
-                }
-                int bx, by, bz;
-                float wx0, wx1, wy0, wy1, wz0, wz1;
-                if (GENERIC) {
-                    axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
-                    axis_weights(y, p.sy, p.interp, by, wy0, wy1);
-                    axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                float a = 0.0f;
+                int bx = 0, by = 0, bz = 0;
+                float wx0 = 1.0f, wx1 = 0.0f, wy0 = 1.0f, wy1 = 0.0f, wz0 = 1.0f, wz1 = 0.0f;
+                if constexpr (GEO) {
+                    a = gA.w;  // 0 for invalid lanes
+                    if (vA) nsum += a;
+                    if (p.inp_imp && vA) a *= p.inp_imp[jA];
+                    wx1 = gA.x; wy1 = gA.y; wz1 = gA.z;
+                    wx0 = 1.0f - wx1; wy0 = 1.0f - wy1; wz0 = 1.0f - wz1;
+                    bx = gbA & 255; by = (gbA >> 8) & 255; bz = (gbA >> 16) & 255;
                 } else {
-                    axis_weights_linear(x, p.sx, bx, wx0, wx1);
-                    axis_weights_linear(y, p.sy, by, wy0, wy1);
-                    axis_weights_linear(z, p.sz, bz, wz0, wz1);
+                    float x = 0.0f, y = 0.0f, z = 0.0f;
+                    if (vA) {
+                        x = gx - ox;
+                        y = gy - oy;
+                        z = gz - oz;
+                        a = window_value(p.window, gA.w, p.inv_r2, p.window_fac);
+                        nsum += a;
+                        if (p.inp_imp) a *= p.inp_imp[jA];
+                        filter_coords<GENERIC>(x, y, z, p);
+                    }
+                    if (GENERIC) {
+                        axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
+                        axis_weights(y, p.sy, p.interp, by, wy0, wy1);
+                        axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                    } else {
+                        axis_weights_linear(x, p.sx, bx, wx0, wx1);
+                        axis_weights_linear(y, p.sy, by, wy0, wy1);
+                        axis_weights_linear(z, p.sz, bz, wz0, wz1);
+                    }
                 }
                 base = bz * PS + (by * p.sx + bx) * CC;
                 // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
@@ -427,8 +256,8 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                 }
             }
             // rotate the pipeline registers
-            jA = jB; nvA = nvB; vA = vB;
-            jB = jC; nvB = nvC; vB = vC;
+            jA = jB; gA = gB; gbA = gbB; vA = vB;
+            jB = jC; gB = gC; gbB = gbC; vB = vC;
             gx = nx; gy = ny; gz = nz;
 #pragma unroll
             for (int u = 0; u < CC; ++u) gf[u] = nf[u];
@@ -487,6 +316,31 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         float* dst = p.out + ii * cout + o;
         if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
         *dst = v;
+    }
+}
+
+// Per-pair geometry of one (neighbour search, filter geometry): window value, base cell and the three "+1"
+// axis weights of the trilinear lookup (flag set of every DMCF model: volume preserving map, linear
+// interpolation, align_corners).  One wavefront per output row, lanes stride the row.
+__global__ __launch_bounds__(256) void cconv_geometry_kernel(const CconvParams p, f32x4* __restrict__ geo4,
+                                                             int32_t* __restrict__ geob) {
+    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (i >= p.n_out) return;
+    const int lane = lane_id();
+    const int64_t rb = p.rs[i], re = p.rs[i + 1];
+    const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
+    for (int64_t pp = rb + lane; pp < re; pp += 64) {
+        const int j = p.idx[pp];
+        float x = p.inp_pos[3 * (int64_t)j] - ox, y = p.inp_pos[3 * (int64_t)j + 1] - oy, z = p.inp_pos[3 * (int64_t)j + 2] - oz;
+        const float a = window_value(p.window, p.nval ? p.nval[pp] : 0.0f, p.inv_r2, p.window_fac);
+        filter_coords<false>(x, y, z, p);
+        int bx, by, bz;
+        float w0, wx1, wy1, wz1;
+        axis_weights_linear(x, p.sx, bx, w0, wx1);
+        axis_weights_linear(y, p.sy, by, w0, wy1);
+        axis_weights_linear(z, p.sz, bz, w0, wz1);
+        geo4[pp] = (f32x4){wx1, wy1, wz1, a};
+        geob[pp] = bx | (by << 8) | (bz << 16);
     }
 }
 
@@ -604,7 +458,7 @@ using namespace dmcf;
 
 extern "C" {
 
-static int validate(const dmcf_cconv_args* a) {
+static int validate(const dmcf_cconv_args* a, bool forward = true) {
     if (!a) return DMCF_EINVAL;
     for (int d = 0; d < 5; ++d)
         if (a->filter_dims[d] < 1) return DMCF_EINVAL;
@@ -619,10 +473,16 @@ static int validate(const dmcf_cconv_args* a) {
     }
     if (a->filter_dims[4] > 16 * kMaxNT) return DMCF_EUNSUPPORTED;
     if (a->n_out > 0) {
-        if (!a->filters || !a->out_positions || !a->neighbors_row_splits || !a->out) return DMCF_EINVAL;
+        if (!a->out_positions || !a->neighbors_row_splits) return DMCF_EINVAL;
+        if (forward && (!a->filters || !a->out || !a->inp_features)) return DMCF_EINVAL;
         if (a->window != DMCF_WINDOW_NONE && !a->neighbors_value) return DMCF_EINVAL;
     }
     return DMCF_OK;
+}
+
+static bool specialised(const dmcf_cconv_args* a) {
+    return a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING && a->interpolation == DMCF_INTERP_LINEAR &&
+           (a->flags & DMCF_FLAG_ALIGN_CORNERS);
 }
 
 static void full_dims(const dmcf_cconv_args* a, int& dz, int& dy, int& dx) {
@@ -639,7 +499,10 @@ size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
     int dz, dy, dx;
     full_dims(a, dz, dy, dx);
     const LaunchCfg cfg = make_cfg(dx, dy, dz, a->filter_dims[3], a->filter_dims[4]);
-    return 256 + align_up(cfg.packed_floats * sizeof(float), 256);
+    size_t floats = cfg.packed_floats;
+    const size_t mf = cconv_mfma_packed_floats(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
+    if (floats < mf) floats = mf;
+    return 256 + align_up(floats * sizeof(float), 256);
 }
 
 int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspace_bytes, dmcf_stream_t stream_) {
@@ -675,6 +538,8 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.idx = a->neighbors_index;
     p.rs = a->neighbors_row_splits;
     p.nval = a->neighbors_value;
+    p.geo4 = nullptr;
+    p.geob = nullptr;
     p.n_out = a->n_out;
     p.inv_extent = 1.0f / a->extent;
     const float radius = 0.5f * a->extent;
@@ -686,6 +551,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.flags = a->flags;
     p.bias = a->bias;
     p.out = a->out;
+    if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
     p.KCp = cfg.KCp;
     p.PS = cfg.PS;
     p.nblocks = cfg.nblocks;
@@ -698,15 +564,66 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     // the flag set every DMCF model uses (models/pbf_model.py:210-221) gets a specialised instantiation
-    const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
-                           a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
-    const void* fn = cfg.CC == 8 ? (generic ? (const void*)cconv_kernel<8, true> : (const void*)cconv_kernel<8, false>)
-                                 : (generic ? (const void*)cconv_kernel<4, true> : (const void*)cconv_kernel<4, false>);
+    const bool generic = !specialised(a);
+    const bool geo = a->geometry != nullptr;
+    if (geo) {
+        if (generic || dx > 255 || dy > 255 || dz > 255) return DMCF_EINVAL;
+        const int64_t P = a->n_pairs;
+        if (P < 0 || ((uintptr_t)a->geometry & 15)) return DMCF_EINVAL;
+        p.geo4 = (const f32x4_t*)a->geometry;
+        p.geob = (const int32_t*)((const char*)a->geometry + (size_t)P * 16);
+    }
+    const void* fn;
+    if (cfg.CC == 8)
+        fn = generic ? (const void*)cconv_kernel<8, true, false>
+                     : (geo ? (const void*)cconv_kernel<8, false, true> : (const void*)cconv_kernel<8, false, false>);
+    else
+        fn = generic ? (const void*)cconv_kernel<4, true, false>
+                     : (geo ? (const void*)cconv_kernel<4, false, true> : (const void*)cconv_kernel<4, false, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
     void* kargs[] = {(void*)&p};
     e = hipLaunchKernel(fn, dim3(grid), dim3(kThreads), kargs, cfg.lds, stream);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
+    return check_launch();
+}
+
+size_t dmcf_cconv_geometry_bytes(int64_t n_pairs) {
+    if (n_pairs < 0) return 0;
+    return align_up((size_t)n_pairs * 20 + 16, 256);
+}
+
+int dmcf_cconv_geometry(const dmcf_cconv_args* a, void* geometry, size_t geometry_bytes, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = validate(a, false);
+    if (rc != DMCF_OK) return rc;
+    if (!specialised(a)) return DMCF_EUNSUPPORTED;
+    if (a->n_pairs < 0 || !geometry || ((uintptr_t)geometry & 15)) return DMCF_EINVAL;
+    if (geometry_bytes < dmcf_cconv_geometry_bytes(a->n_pairs)) return DMCF_EWORKSPACE;
+    if (a->n_out == 0 || a->n_pairs == 0) return DMCF_OK;
+    if (!a->inp_positions || !a->neighbors_index) return DMCF_EINVAL;
+    int dz, dy, dx;
+    full_dims(a, dz, dy, dx);
+    if (dx > 255 || dy > 255 || dz > 255) return DMCF_EUNSUPPORTED;
+    CconvParams p = {};
+    p.sx = dx; p.sy = dy; p.sz = dz;
+    p.out_pos = a->out_positions;
+    p.inp_pos = a->inp_positions;
+    p.idx = a->neighbors_index;
+    p.rs = a->neighbors_row_splits;
+    p.nval = a->neighbors_value;
+    p.n_out = a->n_out;
+    p.inv_extent = 1.0f / a->extent;
+    const float radius = 0.5f * a->extent;
+    p.inv_r2 = 1.0f / (radius * radius);
+    p.window_fac = a->window_fac;
+    p.window = a->window;
+    p.mapping = a->coordinate_mapping;
+    p.interp = a->interpolation;
+    p.flags = a->flags;
+    const unsigned grid = (unsigned)((a->n_out + 3) / 4);
+    hipLaunchKernelGGL(cconv_geometry_kernel, dim3(grid), dim3(256), 0, stream, p, (f32x4*)geometry,
+                       (int32_t*)((char*)geometry + (size_t)a->n_pairs * 16));
     return check_launch();
 }
 

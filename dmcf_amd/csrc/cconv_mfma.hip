@@ -1,0 +1,377 @@
+// CConv / ASCC with the SPLAT ON THE MATRIX CORES (filters of up to 64 cells: 4x4x4, 8x8, 8, 4x4 ...).
+//
+// cconv.hip accumulates B_i[cell, c] += w * f with read-modify-writes in LDS; measured on MI355X that loop is
+// co-limited by instruction issue and the LDS pipe at ~13 clocks per neighbour pair per 8 channels, while the
+// fp32 matrix pipe idles.  Here the same sum is written as a small dense GEMM per output point,
+//
+//     B_i[cell, c] = sum_j  S_i[cell, j] * F[j, c],      S_i[cell, j] = a_ij * hat(x_ij - cx) hat(y_ij - cy) hat(z_ij - cz)
+//
+// where (x_ij, y_ij, z_ij) are the pair's (clamped) filter coordinates and hat(d) = max(0, 1 - |d|): the trilinear
+// weights of the 8 corner cells are exactly the non-zero values of that product, every other cell gets 0.  It is
+// evaluated with v_mfma_f32_16x16x4_f32: M = 16 filter cells, N = 16 channels, K = 4 neighbour pairs.  That is 8x
+// more multiply-adds than the 8 corners need, but they run at the matrix rate with NO LDS traffic and no data
+// dependent addressing: per 4 pairs a wave issues five ds_bpermute (the pairs' index and coordinates, which live in
+// the registers of the lane that owns the pair), one coalesced feature load (4 rows x 64 B), about two dozen VALU
+// operations for the hat weights and K/16 MFMAs.  B accumulates in
+// registers (K/16 x 4 VGPRs) in exact fp32 (the MFMA is a k-ordered fmaf chain) and is written once per point to
+// the LDS tile the contraction reads -- the contraction itself is the one of cconv.hip.
+//
+// One workgroup = 8 waves = a tile of 16 output points (two points per wave, one after the other), 16 channels
+// per pass, two workgroups per CU.  Interpolation modes map onto the same product: 'linear' stores clamped
+// coordinates, 'linear_border' unclamped ones (the hat vanishes outside the array by itself), 'nearest_neighbor'
+// stores rounded coordinates (hat of an integer offset is the indicator).
+#include <stdlib.h>
+
+#include "cconv_common.h"
+
+namespace dmcf {
+
+constexpr int kMThreads = 512;
+constexpr int kMWaves = kMThreads / 64;
+constexpr int MTM = 16;    // output points per workgroup (MFMA M of the contraction)
+constexpr int MCH = 16;    // channels per pass (MFMA N of the splat)
+constexpr int kMaxKT = 4;  // 16-cell tiles: filters of up to 64 cells
+constexpr int kMMaxNT = 4;
+
+__device__ __forceinline__ float hat(float d) { return fmaxf(0.0f, 1.0f - fabsf(d)); }
+
+// GENERIC: runtime mapping / interpolation switches; PLANE16: sx*sy == 16 (the (x,y) hat product is shared by all
+// tiles, z = tile index); NTT: number of 16-channel output tiles the contraction accumulates (register budget);
+// KTT: number of 16-cell tiles when known at compile time (0 = runtime p.KT).
+template <bool GENERIC, bool PLANE16, int NTT, int KTT>
+__global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int KCp = p.KCp, cin = p.cin, cout = p.cout, KT = p.KT;
+    float* Bt = smem;              // [MTM][KCp]
+    float* norm = Bt + p.bfloats;  // [MTM]
+    const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
+    if (tile >= p.ntiles) return;
+    const int64_t pt0 = (int64_t)tile * MTM;
+    const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
+    const int mi = lane & 15, mg = lane >> 4;  // MFMA roles: A row (cell) / B column (channel); k index (pair)
+
+    // filter cell of this lane in each 16-cell tile (cells beyond K are parked far away: weight 0)
+    constexpr int NCT = PLANE16 ? 1 : kMaxKT;
+    float cxs[NCT], cys[NCT], czs[NCT];
+#pragma unroll
+    for (int mt = 0; mt < NCT; ++mt) {
+        const int cell = 16 * mt + mi;
+        const int plane = p.sx * p.sy;
+        const bool ok = cell < p.K;
+        const int r = cell % plane;
+        cxs[mt] = ok ? (float)(r % p.sx) : -100.0f;
+        cys[mt] = ok ? (float)(r / p.sx) : -100.0f;
+        czs[mt] = ok ? (float)(cell / plane) : -100.0f;
+    }
+
+    f32x4 acc[NTT];
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int c0 = chunk * MCH;
+        const bool ch_ok = c0 + mi < cin;
+        // ---------------- splat on the matrix cores: two points per wave ----------------
+        for (int pp = 0; pp < MTM / kMWaves; ++pp) {
+            const int pt = wave + kMWaves * pp;
+            const int64_t i = pt0 + pt;
+            f32x4 bacc[kMaxKT];
+#pragma unroll
+            for (int mt = 0; mt < kMaxKT; ++mt) bacc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            float nsum = 0.0f;
+            if (i < p.n_out) {
+                const int64_t rb = p.rs[i], re = p.rs[i + 1];
+                const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
+                const float fi = (symmetric && ch_ok) ? p.inp_feat[i * cin + c0 + mi] : 0.0f;
+                const int nb = (int)((re - rb + 63) >> 6);
+                // Everything per pair lives in registers of the lane that owns the pair (phase-1 layout: lane =
+                // pair); the (pair, channel) / (cell, pair) operand layouts of the MFMA fetch it with ds_bpermute.
+                // Software pipeline per batch of 64 pairs: (index, d^2) loads run two batches ahead, position
+                // gathers one batch ahead, the feature loads of one half batch are in flight while the MFMAs of
+                // the other half batch issue.
+                auto ld_idx = [&](int b, int& j, float& nv, bool& v) {
+                    const int64_t q = rb + 64 * (int64_t)b + lane;
+                    v = q < re;
+                    j = 0;
+                    nv = 0.0f;
+                    if (v) {
+                        j = p.idx[q];
+                        if (p.nval) nv = p.nval[q];
+                    }
+                };
+                auto ld_pos = [&](int j, bool v, float& x, float& y, float& z) {
+                    x = y = z = 0.0f;
+                    if (v) {
+                        x = p.inp_pos[3 * (int64_t)j];
+                        y = p.inp_pos[3 * (int64_t)j + 1];
+                        z = p.inp_pos[3 * (int64_t)j + 2];
+                    }
+                };
+                auto geom = [&](int j, float nv, bool v, float x, float y, float z) -> f32x4 {
+                    float a = 0.0f;
+                    if (v) {
+                        x -= ox;
+                        y -= oy;
+                        z -= oz;
+                        a = window_value(p.window, nv, p.inv_r2, p.window_fac);
+                        nsum += a;
+                        if (p.inp_imp) a *= p.inp_imp[j];
+                        filter_coords<GENERIC>(x, y, z, p);
+                        const float hx = (float)(p.sx - 1), hy = (float)(p.sy - 1), hz = (float)(p.sz - 1);
+                        if (!GENERIC || p.interp == DMCF_INTERP_LINEAR) {  // coordinate clamping
+                            x = fminf(hx, fmaxf(0.0f, x));
+                            y = fminf(hy, fmaxf(0.0f, y));
+                            z = fminf(hz, fmaxf(0.0f, z));
+                        } else if (p.interp == DMCF_INTERP_NEAREST) {
+                            x = fminf(hx, fmaxf(0.0f, roundf(x)));
+                            y = fminf(hy, fmaxf(0.0f, roundf(y)));
+                            z = fminf(hz, fmaxf(0.0f, roundf(z)));
+                        } else {  // LINEAR_BORDER: no clamping; keep the values finite and small
+                            if (!(x == x) || !(y == y) || !(z == z)) a = 0.0f;
+                            x = fminf(hx + 2.0f, fmaxf(-2.0f, x));
+                            y = fminf(hy + 2.0f, fmaxf(-2.0f, y));
+                            z = fminf(hz + 2.0f, fmaxf(-2.0f, z));
+                        }
+                    }
+                    return (f32x4){x, y, z, a};  // a == 0 for lanes without a pair
+                };
+                // Feature loads of one quarter batch (4 groups of 4 pairs): lane = (pair slot mg, channel mi).
+                // Branch free and never touched until the MFMAs consume them (a use would make the compiler wait
+                // for the load right here): out-of-range slots read row 0 / channel 0 and are masked at use.
+                const int ch_safe = ch_ok ? c0 + mi : 0;
+                auto issue = [&](int bj, int np, int g0, float (&f)[4]) {
+                    if (4 * g0 >= np) return;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int q = 4 * (g0 + g) + mg;
+                        const int jj = __shfl(bj, q, 64);  // 0 for slots beyond np
+                        f[g] = p.inp_feat[(int64_t)jj * cin + ch_safe];
+                    }
+                };
+                auto run = [&](const f32x4& c, int np, int g0, const float (&f)[4]) {
+                    if (4 * g0 >= np) return;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int q = 4 * (g0 + g) + mg;
+                        const float x = __shfl(c.x, q, 64), y = __shfl(c.y, q, 64), z = __shfl(c.z, q, 64),
+                                    a = __shfl(c.w, q, 64);  // a == 0 for slots beyond np
+                        const float fv = (q < np && ch_ok) ? f[g] + fi : 0.0f;
+                        if constexpr (PLANE16) {
+                            const float wxy = hat(x - cxs[0]) * hat(y - cys[0]);
+#pragma unroll
+                            for (int mt = 0; mt < kMaxKT; ++mt)
+                                if (mt < (KTT ? KTT : KT))
+                                    bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * (hat(z - (float)mt) * a), fv,
+                                                                                    bacc[mt], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int mt = 0; mt < kMaxKT; ++mt)
+                                if (mt < (KTT ? KTT : KT))
+                                    bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                                        (hat(x - cxs[mt]) * hat(y - cys[mt])) * (hat(z - czs[mt]) * a), fv, bacc[mt], 0, 0, 0);
+                        }
+                    }
+                };
+                int j0, j1;
+                float nv0, nv1, px, py, pz;
+                bool v0, v1;
+                ld_idx(0, j0, nv0, v0);
+                ld_idx(1, j1, nv1, v1);
+                ld_pos(j0, v0, px, py, pz);
+                f32x4 cur = geom(j0, nv0, v0, px, py, pz);
+                int curj = j0;
+                int np_cur = (int)min((int64_t)64, re - rb);
+                // three quarter-batch feature buffers rotate: a load has two quarters of MFMAs to land
+                float fA[4], fB[4], fC[4];
+                issue(curj, np_cur, 0, fA);
+                issue(curj, np_cur, 4, fB);
+                ld_pos(j1, v1, px, py, pz);
+                for (int b = 0; b < nb; ++b) {
+                    int j2;
+                    float nv2;
+                    bool v2;
+                    ld_idx(b + 2, j2, nv2, v2);
+                    issue(curj, np_cur, 8, fC);
+                    run(cur, np_cur, 0, fA);
+                    issue(curj, np_cur, 12, fA);
+                    run(cur, np_cur, 4, fB);
+                    const f32x4 nxt = geom(j1, nv1, v1, px, py, pz);
+                    const int nxtj = j1;
+                    const int np_nxt = (int)min((int64_t)64, max((int64_t)0, re - rb - 64 * (int64_t)(b + 1)));
+                    issue(nxtj, np_nxt, 0, fB);
+                    ld_pos(j2, v2, px, py, pz);
+                    run(cur, np_cur, 8, fC);
+                    issue(nxtj, np_nxt, 4, fC);
+                    run(cur, np_cur, 12, fA);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        fA[g] = fB[g];
+                        fB[g] = fC[g];
+                    }
+                    cur = nxt;
+                    curj = nxtj;
+                    np_cur = np_nxt;
+                    j1 = j2;
+                    nv1 = nv2;
+                    v1 = v2;
+                }
+            }
+            // D layout of 16x16x4: lane l, reg r -> row (cell in tile) 4*(l>>4)+r, column (channel) l&15
+            float* Brow = Bt + (size_t)pt * KCp;
+#pragma unroll
+            for (int mt = 0; mt < kMaxKT; ++mt)
+                if (mt < (KTT ? KTT : KT)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Brow[(16 * mt + 4 * mg + r) * MCH + mi] = bacc[mt][r];
+                }
+            if (chunk == 0 && (p.flags & DMCF_FLAG_NORMALIZE)) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) nsum += __shfl_xor(nsum, d, 64);
+                if (lane == 0) norm[pt] = nsum;
+            }
+        }
+        __syncthreads();
+        // ---------------- contraction of this channel chunk on the matrix cores ----------------
+        const float* Wc = p.Wp + (size_t)chunk * p.nblocks * (4 * p.NT * 16 * 4);
+        for (int blk = wave; blk < p.nblocks; blk += kMWaves) {
+            const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * KCp + blk * 16 + mg * 4);
+            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+#pragma unroll
+            for (int n = 0; n < NTT; ++n) {
+                if (n < p.NT) {
+                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- cross-wave reduction + epilogue ----------------
+    float* red = Bt;  // [kMWaves][MTM][16*NT]
+    const int ncol = 16 * p.NT;
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) {
+        if (n < p.NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * MTM + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < MTM * cout; e += kMThreads) {
+        const int ptt = e / cout, o = e % cout;
+        const int64_t ii = pt0 + ptt;
+        if (ii >= p.n_out) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kMWaves; ++w) v += red[((size_t)w * MTM + ptt) * ncol + o];
+        if (p.flags & DMCF_FLAG_NORMALIZE) {
+            const float nv = norm[ptt];
+            if (nv != 0.0f) v /= nv;
+        }
+        if (p.bias) v += p.bias[o];
+        float* dst = p.out + ii * cout + o;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        *dst = v;
+    }
+}
+
+struct MfmaCfg {
+    int KT, KCp, nblocks, NT, nchunks;
+    size_t lds, packed_floats, bfloats;
+};
+
+static MfmaCfg mfma_cfg(int K, int cin, int cout) {
+    MfmaCfg c;
+    c.KT = (K + 15) / 16;
+    const int KC = c.KT * 16 * MCH;  // multiple of 256
+    c.nblocks = KC / 16;
+    c.KCp = KC + 4;  // == 4 (mod 64): conflict-free ds_read_b128 of 16 rows in the contraction
+    c.NT = (cout + 15) / 16;
+    c.nchunks = (cin + MCH - 1) / MCH;
+    size_t b = (size_t)MTM * c.KCp;
+    const size_t r = (size_t)kMWaves * MTM * 16 * c.NT;
+    if (b < r) b = r;
+    c.bfloats = b;
+    c.lds = (b + MTM) * sizeof(float);
+    c.packed_floats = (size_t)c.nchunks * c.nblocks * 4 * c.NT * 16 * 4;
+    return c;
+}
+
+bool cconv_mfma_eligible(int K, int cin, int cout) {
+    const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma": force one implementation (A/B tests)
+    if (e && e[0] == 'l') return false;
+    if (K > 16 * kMaxKT || cout > 16 * kMMaxNT) return false;
+    if (e && e[0] == 'm') return true;
+    // Measured on MI355X at 3.07e8 pairs (profiles/): the LDS splat costs ~6.9 ms per 8-channel pass (5.7 ms for a
+    // 4-channel one), the matrix-core splat ~10.1 ms per 16-channel pass whatever the channel count.
+    const double lds = cin <= 4 ? 5.7 : 6.9 * ((cin + 7) / 8);
+    const double mfma = 10.1 * ((cin + 15) / 16);
+    return mfma < lds;
+}
+
+size_t cconv_mfma_packed_floats(int K, int cin, int cout) { return mfma_cfg(K, cin, cout).packed_floats; }
+
+int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, int dx, void* workspace,
+                      hipStream_t stream) {
+    const MfmaCfg cfg = mfma_cfg(p.K, p.cin, p.cout);
+    float* packed = (float*)workspace;
+    {
+        const int64_t total = (int64_t)cfg.packed_floats;
+        const unsigned g = (unsigned)((total + 255) / 256);
+        // same packer as the LDS path with 16 channels per chunk and an unpadded plane stride
+        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
+                           p.cin, p.cout, MCH, dy * dx * MCH, cfg.nchunks, cfg.nblocks, cfg.NT,
+                           (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
+    }
+    p.Wp = packed;
+    p.KT = cfg.KT;
+    p.KCp = cfg.KCp;
+    p.nblocks = cfg.nblocks;
+    p.NT = cfg.NT;
+    p.nchunks = cfg.nchunks;
+    p.bfloats = (int)cfg.bfloats;
+    const int64_t ntiles = (p.n_out + MTM - 1) / MTM;
+    if (ntiles > 0x7fffffff / 8) return DMCF_EUNSUPPORTED;
+    p.ntiles = (int)ntiles;
+    p.tiles_per_xcd = (int)((ntiles + 7) / 8);
+    const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
+                           a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
+    const bool plane16 = !generic && dx * dy == 16;
+    const int ntt = cfg.NT <= 1 ? 1 : (cfg.NT <= 2 ? 2 : 4);
+    const void* fn;
+#define DMCF_PICK(G, P16, KTT)                                                                          \
+    (ntt == 1 ? (const void*)cconv_mfma_kernel<G, P16, 1, KTT>                                         \
+              : (ntt == 2 ? (const void*)cconv_mfma_kernel<G, P16, 2, KTT> : (const void*)cconv_mfma_kernel<G, P16, 4, KTT>))
+    if (generic)
+        fn = DMCF_PICK(true, false, 0);
+    else if (plane16 && cfg.KT == 4)
+        fn = DMCF_PICK(false, true, 4);
+    else if (plane16)
+        fn = DMCF_PICK(false, true, 0);
+    else if (cfg.KT == 4)
+        fn = DMCF_PICK(false, false, 4);
+    else
+        fn = DMCF_PICK(false, false, 0);
+#undef DMCF_PICK
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    void* kargs[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(kMThreads), kargs, cfg.lds, stream);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    return check_launch();
+}
+
+}  // namespace dmcf

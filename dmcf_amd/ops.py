@@ -177,22 +177,20 @@ def _empty(t):
     return t is None or (isinstance(t, torch.Tensor) and t.numel() == 0)
 
 
-def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
-                  neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
-                  align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
-                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False):
-    """One call of dmcf_cconv_forward.  ``window``: None | 'explicit' (neighbors_value = importance) |
-    'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances)."""
-    L = _lib.lib()
+def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
+                neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
+                normalize, symmetric, sym_axis, bias, out, accumulate, geometry):
+    """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
         raise ValueError("filters must have shape [D,H,W,Cin,Cout]")
     out_positions = _dev_f32(out_positions, "out_positions", 3)
     inp_positions = _dev_f32(inp_positions, "inp_positions", 3)
     cin, cout = filters.shape[3], filters.shape[4]
-    inp_features = _dev_f32(inp_features, "inp_features", cin)
-    if inp_features.shape[0] != inp_positions.shape[0]:
-        raise ValueError("inp_features and inp_positions disagree on the number of points")
+    if inp_features is not None:
+        inp_features = _dev_f32(inp_features, "inp_features", cin)
+        if inp_features.shape[0] != inp_positions.shape[0]:
+            raise ValueError("inp_features and inp_positions disagree on the number of points")
     n_out = out_positions.shape[0]
     if neighbors_index.dtype != torch.int32 or neighbors_row_splits.dtype != torch.int64:
         raise TypeError("neighbors_index must be int32 and neighbors_row_splits int64")
@@ -208,19 +206,11 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         neighbors_value = _dev_f32(neighbors_value, "neighbors_value")
         if neighbors_value.shape[0] != neighbors_index.shape[0]:
             raise ValueError("neighbors_value and neighbors_index disagree on the number of pairs")
-    if _empty(inp_importance):
-        inp_importance = None
-    else:
-        inp_importance = _dev_f32(inp_importance, "inp_importance")
+    inp_importance = None if _empty(inp_importance) else _dev_f32(inp_importance, "inp_importance")
     if bias is not None:
         bias = _dev_f32(bias, "bias")
-    if out is None:
-        if accumulate:
-            raise ValueError("accumulate=True needs an out tensor")
-        out = torch.empty((n_out, cout), dtype=torch.float32, device=filters.device)
-    else:
-        if out.shape != (n_out, cout) or out.dtype != torch.float32 or not out.is_contiguous():
-            raise ValueError("out has the wrong shape / dtype / layout")
+    neighbors_index = neighbors_index.contiguous()
+    neighbors_row_splits = neighbors_row_splits.contiguous()
     a = _lib.CconvArgs()
     a.filters = filters.data_ptr()
     for d in range(5):
@@ -230,10 +220,10 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a.n_out = n_out
     a.inp_positions = inp_positions.data_ptr()
     a.n_inp = inp_positions.shape[0]
-    a.inp_features = inp_features.data_ptr()
+    a.inp_features = None if inp_features is None else inp_features.data_ptr()
     a.inp_importance = None if inp_importance is None else inp_importance.data_ptr()
-    a.neighbors_index = neighbors_index.contiguous().data_ptr()
-    a.neighbors_row_splits = neighbors_row_splits.contiguous().data_ptr()
+    a.neighbors_index = neighbors_index.data_ptr()
+    a.neighbors_row_splits = neighbors_row_splits.data_ptr()
     a.neighbors_value = None if window is None else neighbors_value.data_ptr()
     a.extent = float(extent)
     a.window_fac = float(window_fac)
@@ -243,7 +233,58 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a.flags = ((FLAG_ALIGN_CORNERS if align_corners else 0) | (FLAG_NORMALIZE if normalize else 0) |
                (FLAG_SYMMETRIC if symmetric else 0) | (FLAG_ACCUMULATE if accumulate else 0))
     a.bias = None if bias is None else bias.data_ptr()
-    a.out = out.data_ptr()
+    a.out = None if out is None else out.data_ptr()
+    a.geometry = None if geometry is None else geometry.data_ptr()
+    a.n_pairs = neighbors_index.shape[0]
+    keep = (filters, out_positions, inp_positions, inp_features, inp_importance, neighbors_index, neighbors_row_splits,
+            neighbors_value, bias, out, geometry)
+    return a, keep
+
+
+def geometry_supported(align_corners, coordinate_mapping, interpolation):
+    """The per-pair geometry cache exists for the flag set every DMCF model uses (models/pbf_model.py:210-221)."""
+    return bool(align_corners) and coordinate_mapping == "ball_to_cube_volume_preserving" and interpolation == "linear"
+
+
+def cconv_geometry(kernel_dims, out_positions, extent, inp_positions, neighbors_index, neighbors_row_splits,
+                   neighbors_value=None, window=None, window_fac=1.0, symmetric=False, sym_axis=2):
+    """dmcf_cconv_geometry: window value + mapped filter coordinates of every neighbour pair, once per
+    (neighbour list, filter geometry).  ``kernel_dims`` = (D, H, W) of the stored kernel.  Returns an opaque
+    uint8 tensor to pass as ``geometry=`` to :func:`cconv_forward` calls with the same operands."""
+    L = _lib.lib()
+    dev = out_positions.device
+    dummy = torch.empty((*[int(k) for k in kernel_dims], 1, 1), dtype=torch.float32, device=dev)
+    a, keep = _cconv_args(dummy, out_positions, extent, inp_positions, None, neighbors_index, neighbors_row_splits,
+                          neighbors_value, window, window_fac, None, True, "ball_to_cube_volume_preserving", "linear",
+                          False, symmetric, sym_axis, None, None, False, None)
+    nbytes = L.dmcf_cconv_geometry_bytes(a.n_pairs)
+    geo = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(L.dmcf_cconv_geometry(ctypes.byref(a), _ptr(geo), nbytes, _stream()), "dmcf_cconv_geometry")
+    if timer is not None:
+        timer.end("cconv_geometry", dict(pairs=int(a.n_pairs)), t0)
+    return geo
+
+
+def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
+                  neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
+                  align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
+                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None):
+    """One call of dmcf_cconv_forward.  ``window``: None | 'explicit' (neighbors_value = importance) |
+    'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
+    ``geometry``: optional result of :func:`cconv_geometry` for the same operands."""
+    L = _lib.lib()
+    n_out, cout = out_positions.shape[0], filters.shape[4]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an out tensor")
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=filters.device)
+    elif out.shape != (n_out, cout) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out has the wrong shape / dtype / layout")
+    a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
+                          neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
+                          coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
+                          geometry)
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None
@@ -252,7 +293,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         kdims = [int(d) for d in filters.shape[:3]]
         if symmetric:
             kdims[int(sym_axis)] *= 2
-        timer.end("cconv", dict(pairs=int(neighbors_index.shape[0]), n_out=n_out, cin=cin, cout=cout,
+        timer.end("cconv", dict(pairs=int(a.n_pairs), n_out=n_out, cin=int(filters.shape[3]), cout=cout,
                                 K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric)), t0)
     return out
 

@@ -35,6 +35,7 @@ class _NeighborCache:
         self.depth = 0
         self.lists = {}
         self.tables = {}
+        self.geometries = {}
         self.keepalive = []
 
     def __enter__(self):
@@ -46,6 +47,7 @@ class _NeighborCache:
         if self.depth == 0:
             self.lists.clear()
             self.tables.clear()
+            self.geometries.clear()
             self.keepalive.clear()
         return False
 
@@ -73,7 +75,25 @@ class _NeighborCache:
         return res
 
 
+    def geometry(self, nns, key, build):
+        """Per-pair geometry (dmcf_cconv_geometry) of one neighbour list for one filter geometry: computed by the
+        first layer that needs it, reused by every later layer / channel chunk of the step."""
+        if self.depth == 0:
+            return None  # outside a step nothing is cached; the kernel evaluates window + mapping itself
+        k = (nns.neighbors_index.data_ptr(), int(nns.neighbors_index.shape[0])) + key
+        geo = self.geometries.get(k)
+        if geo is None:
+            geo = build()
+            self.geometries[k] = geo
+        return geo
+
+
 _CACHE = _NeighborCache()
+
+# The per-pair geometry cache (dmcf_cconv_geometry) feeds the LDS-splat kernel; the matrix-core kernel that
+# handles every filter of up to 64 cells recomputes the geometry per 16-channel pass at ~15 % of its MFMA time,
+# which is cheaper than writing and re-reading 20 B per pair.  Kept as an opt-in for large filters.
+USE_GEOMETRY_CACHE = False
 
 
 def neighbor_cache():
@@ -248,13 +268,24 @@ class ContinuousConv(torch.nn.Module):
         if symmetric and self.normalize:
             raise NotImplementedError("symmetric=True with normalize=True (DMCF always uses normalize=False, "
                                       "models/pbf_model.py:203)")
+        geometry = None
+        if (USE_GEOMETRY_CACHE and self.nns is not None and neighbors_index is self.nns.neighbors_index
+                and window not in (None, "explicit")
+                and inp_importance is None and not self.circular
+                and ops.geometry_supported(self.align_corners, self.coordinate_mapping, self.interpolation)):
+            kdims = tuple(int(d) for d in kernel.shape[:3])
+            gkey = (kdims, float(extent), window, float(window_fac), bool(symmetric), int(self.sym_axis))
+            geometry = _CACHE.geometry(self.nns, gkey, lambda: ops.cconv_geometry(
+                kdims, out_positions, extent, inp_positions, neighbors_index, neighbors_row_splits,
+                neighbors_value=neighbors_value, window=window, window_fac=window_fac, symmetric=symmetric,
+                sym_axis=self.sym_axis))
         fuse_bias = self.use_bias and not self.use_dense_layer_for_center
         out_features = ops.cconv_forward(
             kernel, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
             neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
-            bias=self.bias if fuse_bias else None)
+            bias=self.bias if fuse_bias else None, geometry=geometry)
         self._conv_output = out_features
         if self.use_dense_layer_for_center:  # :462-464
             self._dense_output = inp_features @ self.dense

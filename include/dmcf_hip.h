@@ -141,9 +141,23 @@ typedef struct dmcf_cconv_args {
     int32_t flags;              /* DMCF_FLAG_* */
     const float* bias;          /* [Cout] or NULL; added after normalisation (convolutions.py:466-467) */
     float* out;                 /* [n_out,Cout] */
+    /* optional per-pair geometry cache filled by dmcf_cconv_geometry for the same positions / neighbour list /
+     * extent / filter dims / window; NULL = evaluate window + mapping inside the convolution */
+    const void* geometry;
+    int64_t n_pairs;            /* P = neighbors_row_splits[n_out]; only read when geometry != NULL or by dmcf_cconv_geometry */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);
+
+/* Per-pair geometry cache.  The window value and the ball->cube mapped filter coordinates of a neighbour pair
+ * depend only on (positions, neighbour list, extent, filter dims, window) -- not on features, filters or the
+ * channel chunk -- and the reference recomputes them in every one of its 18/27/43 continuous_conv calls per step
+ * although only 12/12/19 neighbour lists are distinct.  dmcf_cconv_geometry evaluates them once (20 bytes per
+ * pair: three axis weights, the window value, the base filter cell); dmcf_cconv_forward then reads them through
+ * args->geometry.  Available for the flag set DMCF uses (ball_to_cube_volume_preserving, linear, align_corners);
+ * otherwise DMCF_EUNSUPPORTED.  Results are bit-identical with and without the cache. */
+size_t dmcf_cconv_geometry_bytes(int64_t n_pairs);
+int dmcf_cconv_geometry(const dmcf_cconv_args* args, void* geometry, size_t geometry_bytes, dmcf_stream_t stream);
 int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t workspace_bytes,
                        dmcf_stream_t stream);
 

@@ -276,3 +276,41 @@ def test_scale_properties_200k(oracle, dev):
     a = ops.cconv_forward(W, P, 0.2, P, feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
     b = ops.cconv_forward(W, P, 0.2, P, 2 * feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
     assert torch.allclose(b, 2 * a, rtol=1e-4, atol=1e-4 * a.abs().max().item())
+
+
+@pytest.mark.parametrize("ks,sym,cin,cout,dim", [((4, 4, 4), False, 16, 16, 3), ((4, 4, 4), False, 4, 8, 3), ((6, 3, 6), True, 32, 3, 3),
+                                                  ((1, 8, 8), False, 24, 8, 2), ((1, 4, 8), True, 32, 2, 2)])
+def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, monkeypatch):
+    """dmcf_cconv_geometry + dmcf_cconv_forward(geometry=...) == dmcf_cconv_forward alone, bit for bit
+    (same kernel: the LDS splat, which is the one that consumes the cache)."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "lds")
+    rng = np.random.default_rng(3)
+    n, radius = 3000, 0.2 if dim == 3 else 0.06
+    pos = _t(_cloud(n, 31, dim), dev)
+    feat = _t(rng.normal(size=(n, cin)).astype(np.float32), dev)
+    k = _t(rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32), dev)
+    nns = ops.fixed_radius_search(pos, pos, radius, ignore_query_point=sym, return_distances=True)
+    win = "peak" if sym else "poly6"
+    kw = dict(neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
+    a = ops.cconv_forward(k, pos, 2 * radius, pos, feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
+    geo = ops.cconv_geometry(ks, pos, 2 * radius, pos, nns.neighbors_index, nns.neighbors_row_splits, **kw)
+    b = ops.cconv_forward(k, pos, 2 * radius, pos, feat, nns.neighbors_index, nns.neighbors_row_splits, geometry=geo, **kw)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("kernel", ["lds", "mfma"])
+@pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
+                                            (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
+def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, cout, ks, dim):
+    """The dispatcher picks the LDS or the matrix-core splat by a cost model; force each and check both."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
+    radius = 0.3 if dim == 3 else 0.12
+    inp, out, feat, filt = _conv_inputs(oracle, 77, 800, 500, cin, cout, ks, radius, dim)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2), f64=True)
+    y = ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6")
+    _close(y.cpu().numpy(), ref)

@@ -5,7 +5,7 @@ set -u
 OUT=${1:-gpurun_out/pmc}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "cconv_kernel" --output-format csv -d $OUT/$name -o p -- python tools/microbench.py > $OUT/$name.log 2>&1; }
+run() { name=$1; shift; timeout 600 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "cconv" --output-format csv -d $OUT/$name -o p -- python tools/microbench.py > $OUT/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
 run sq2 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM
 run fetch FETCH_SIZE GRBM_GUI_ACTIVE
