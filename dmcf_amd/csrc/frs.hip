@@ -4,9 +4,9 @@
 // utils/tools/losses.py:296-298).  The Open3D structure behind that layer (spatial hash with ~64
 // points per bin, 8 corner bins per query) is NOT what is built here; only its result contract is
 // kept (see include/dmcf_hip.h).  MI355X-first choices:
-//   * cell edge ~= radius (27-cell neighbourhood, ~15 % of candidates are hits, vs ~6.5 % for the
-//     reference's 2R cells) and points re-ordered by cell into one float4 {x,y,z,index} array, so a
-//     query reads <= 9 contiguous x-runs with coalesced 16-B loads instead of chasing indices;
+//   * cell edge ~= radius/2 (125-cell neighbourhood, ~27 % of candidates are hits, vs ~6.5 % for the
+//     reference's 2R cells; radius-sized or coarser cells when the grid would be too sparse or too big) and points re-ordered by cell into one float4 {x,y,z,index} array, so a
+//     query reads <= 25 contiguous x-runs with coalesced 16-B loads instead of chasing indices;
 //   * one 64-lane wavefront per query: lanes stride the flattened candidate list, hits are compacted
 //     with a ballot + mbcnt prefix (no atomics, no LDS), rows come out in a deterministic order;
 //   * everything that sizes the grid (bounding box, cell edge, dims) is computed on the device into a
@@ -119,8 +119,16 @@ __global__ void frs_finish_header(FrsHeader* h, int64_t table) {
         if (!(ext[a] >= 0.0f) || !isfinite(ext[a])) ext[a] = 0.0f;  // empty / non-finite input
         if (!isfinite(lo[a])) lo[a] = 0.0f;
     }
-    float cell = h->radius * 1.001f;
+    // Preferred cell edge R/2 (125-cell neighbourhood, ~27 % of the candidates are hits; R-sized cells give 15 %),
+    // unless the grid would be mostly empty (fewer than one point per two cells) or does not fit the table.
+    // Then R, then coarser.  "1.001": [q-R, q+R] spans at most 2s+1 cells of edge 1.001 R / s.
     int32_t d[3];
+    float cell = h->radius * 1.001f * 0.5f;
+    {
+        double prod = 1.0;
+        for (int a = 0; a < 3; ++a) prod *= floor((double)ext[a] / (double)cell) + 1.0;
+        if (prod > (double)table || (double)h->n_points < 0.5 * prod) cell = h->radius * 1.001f;
+    }
     for (int it = 0; it < 64; ++it) {
         double prod = 1.0;
         for (int a = 0; a < 3; ++a) {
@@ -239,12 +247,17 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
             }
             const int32_t total = __shfl(incl, kWave - 1, kWave);
             const int32_t rel = start - (incl - len);  // candidate c of this run sits at sorted[rel + flat]
-            const int nrows = min(ny * nz - row0, kWave);
             for (int32_t f0 = 0; f0 < total; f0 += kWave) {
                 const int32_t f = f0 + lane;
-                // which run does flat index f fall into: count runs whose inclusive end is <= f
+                // which run does flat index f fall into: the first r with incl[r] > f.  incl is non-decreasing over
+                // all 64 lanes (lanes past the last run hold the total), so a 6-step binary search finds it.
                 int run = 0;
-                for (int k = 0; k < nrows - 1; ++k) run += (f >= __builtin_amdgcn_readlane(incl, k)) ? 1 : 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int32_t v = __shfl(incl, run + step - 1, kWave);
+                    if (v <= f) run += step;
+                }
+                run = min(run, kWave - 1);
                 const int32_t src = __shfl(rel, run, kWave) + f;
                 bool hit = false;
                 float d2 = 0.0f;
