@@ -35,6 +35,15 @@ constexpr int kMMaxNT = 4;
 
 __device__ __forceinline__ float hat(float d) { return fmaxf(0.0f, 1.0f - fabsf(d)); }
 
+// Per-pair record kept in the registers of the lane that owns the pair.  PLANE16 (4x4xN filters): the four
+// plane weights a * hat(z - plane) are evaluated here, once per pair at full lane utilisation, because the fp32
+// MFMA and the VALU do not overlap on this chip (measured: kernel time ~ MFMA time + VALU time) and every VALU
+// instruction saved in the (cell, pair) layout -- where each value is computed 16 times over -- counts.
+struct PairRec {
+    float x, y, z, a;  // generic: clamped filter coordinates + importance
+    float w1, w2, w3;  // PLANE16: z = a*hat(z), a = unused, w1..w3 = a*hat(z-1..3)
+};
+
 // GENERIC: runtime mapping / interpolation switches; PLANE16: sx*sy == 16 (the (x,y) hat product is shared by all
 // tiles, z = tile index); NTT: number of 16-channel output tiles the contraction accumulates (register budget);
 // KTT: number of 16-cell tiles when known at compile time (0 = runtime p.KT).
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                         z = p.inp_pos[3 * (int64_t)j + 2];
                     }
                 };
-                auto geom = [&](int j, float nv, bool v, float x, float y, float z) -> f32x4 {
+                auto geom = [&](int j, float nv, bool v, float x, float y, float z) -> PairRec {
                     float a = 0.0f;
                     if (v) {
                         x -= ox;
@@ -135,7 +144,21 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                             z = fminf(hz + 2.0f, fmaxf(-2.0f, z));
                         }
                     }
-                    return (f32x4){x, y, z, a};  // a == 0 for lanes without a pair
+                    PairRec r;
+                    r.x = x;
+                    r.y = y;
+                    if constexpr (PLANE16) {
+                        r.z = hat(z) * a;
+                        r.a = 0.0f;
+                        r.w1 = hat(z - 1.0f) * a;
+                        r.w2 = hat(z - 2.0f) * a;
+                        r.w3 = hat(z - 3.0f) * a;
+                    } else {
+                        r.z = z;
+                        r.a = a;  // a == 0 for lanes without a pair
+                        r.w1 = r.w2 = r.w3 = 0.0f;
+                    }
+                    return r;
                 };
                 // Feature loads of one quarter batch (4 groups of 4 pairs): lane = (pair slot mg, channel mi).
                 // Branch free and never touched until the MFMAs consume them (a use would make the compiler wait
@@ -150,22 +173,25 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                         f[g] = p.inp_feat[(int64_t)jj * cin + ch_safe];
                     }
                 };
-                auto run = [&](const f32x4& c, int np, int g0, const float (&f)[4]) {
+                auto run = [&](const PairRec& c, int np, int g0, const float (&f)[4]) {
                     if (4 * g0 >= np) return;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int q = 4 * (g0 + g) + mg;
-                        const float x = __shfl(c.x, q, 64), y = __shfl(c.y, q, 64), z = __shfl(c.z, q, 64),
-                                    a = __shfl(c.w, q, 64);  // a == 0 for slots beyond np
                         const float fv = (q < np && ch_ok) ? f[g] + fi : 0.0f;
+                        const float x = __shfl(c.x, q, 64), y = __shfl(c.y, q, 64);
                         if constexpr (PLANE16) {
                             const float wxy = hat(x - cxs[0]) * hat(y - cys[0]);
-#pragma unroll
-                            for (int mt = 0; mt < kMaxKT; ++mt)
-                                if (mt < (KTT ? KTT : KT))
-                                    bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * (hat(z - (float)mt) * a), fv,
-                                                                                    bacc[mt], 0, 0, 0);
+                            const float w0 = __shfl(c.z, q, 64);  // a * hat(z - plane): 0 for slots beyond np
+                            bacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * w0, fv, bacc[0], 0, 0, 0);
+                            if ((KTT ? KTT : KT) > 1)
+                                bacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * __shfl(c.w1, q, 64), fv, bacc[1], 0, 0, 0);
+                            if ((KTT ? KTT : KT) > 2)
+                                bacc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * __shfl(c.w2, q, 64), fv, bacc[2], 0, 0, 0);
+                            if ((KTT ? KTT : KT) > 3)
+                                bacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * __shfl(c.w3, q, 64), fv, bacc[3], 0, 0, 0);
                         } else {
+                            const float z = __shfl(c.z, q, 64), a = __shfl(c.a, q, 64);  // a == 0 for slots beyond np
 #pragma unroll
                             for (int mt = 0; mt < kMaxKT; ++mt)
                                 if (mt < (KTT ? KTT : KT))
@@ -180,7 +206,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                 ld_idx(0, j0, nv0, v0);
                 ld_idx(1, j1, nv1, v1);
                 ld_pos(j0, v0, px, py, pz);
-                f32x4 cur = geom(j0, nv0, v0, px, py, pz);
+                PairRec cur = geom(j0, nv0, v0, px, py, pz);
                 int curj = j0;
                 int np_cur = (int)min((int64_t)64, re - rb);
                 // three quarter-batch feature buffers rotate: a load has two quarters of MFMAs to land
@@ -197,7 +223,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                     run(cur, np_cur, 0, fA);
                     issue(curj, np_cur, 12, fA);
                     run(cur, np_cur, 4, fB);
-                    const f32x4 nxt = geom(j1, nv1, v1, px, py, pz);
+                    const PairRec nxt = geom(j1, nv1, v1, px, py, pz);
                     const int nxtj = j1;
                     const int np_nxt = (int)min((int64_t)64, max((int64_t)0, re - rb - 64 * (int64_t)(b + 1)));
                     issue(nxtj, np_nxt, 0, fB);
@@ -309,9 +335,9 @@ bool cconv_mfma_eligible(int K, int cin, int cout) {
     if (K > 16 * kMaxKT || cout > 16 * kMMaxNT) return false;
     if (e && e[0] == 'm') return true;
     // Measured on MI355X at 3.07e8 pairs (profiles/): the LDS splat costs ~6.9 ms per 8-channel pass (5.7 ms for a
-    // 4-channel one), the matrix-core splat ~10.1 ms per 16-channel pass whatever the channel count.
+    // 4-channel one), the matrix-core splat ~9.4 ms per 16-channel pass whatever the channel count.
     const double lds = cin <= 4 ? 5.7 : 6.9 * ((cin + 7) / 8);
-    const double mfma = 10.1 * ((cin + 15) / 16);
+    const double mfma = 9.4 * ((cin + 15) / 16);
     return mfma < lds;
 }
 
