@@ -85,7 +85,7 @@ def lib():
                                  c.c_void_p, c.c_void_p]
     L.dmcf_frs_write.restype = c.c_int
     L.dmcf_frs_write.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_void_p, c.c_size_t,
-                                 c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
+                                 c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p]
     L.dmcf_cconv_workspace_bytes.restype = c.c_size_t
     L.dmcf_cconv_workspace_bytes.argtypes = [c.POINTER(CconvArgs)]
     L.dmcf_cconv_forward.restype = c.c_int

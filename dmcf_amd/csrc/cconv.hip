@@ -74,6 +74,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     if (pt_valid) {
         rb = p.rs[i];
         re = p.rs[i + 1];
+        if (re > p.pair_cap) re = rb;
         ox = p.out_pos[3 * i]; oy = p.out_pos[3 * i + 1]; oz = p.out_pos[3 * i + 2];
     }
     const int cnt = (int)(re - rb);
@@ -327,7 +328,9 @@ __global__ __launch_bounds__(256) void cconv_geometry_kernel(const CconvParams p
     const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (i >= p.n_out) return;
     const int lane = lane_id();
-    const int64_t rb = p.rs[i], re = p.rs[i + 1];
+    const int64_t rb = p.rs[i];
+    int64_t re = p.rs[i + 1];
+    if (re > p.pair_cap) re = rb;
     const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
     for (int64_t pp = rb + lane; pp < re; pp += 64) {
         const int j = p.idx[pp];
@@ -541,6 +544,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.geo4 = nullptr;
     p.geob = nullptr;
     p.n_out = a->n_out;
+    p.pair_cap = a->n_pairs;
     p.inv_extent = 1.0f / a->extent;
     const float radius = 0.5f * a->extent;
     p.inv_r2 = 1.0f / (radius * radius);
@@ -613,6 +617,7 @@ int dmcf_cconv_geometry(const dmcf_cconv_args* a, void* geometry, size_t geometr
     p.rs = a->neighbors_row_splits;
     p.nval = a->neighbors_value;
     p.n_out = a->n_out;
+    p.pair_cap = a->n_pairs;
     p.inv_extent = 1.0f / a->extent;
     const float radius = 0.5f * a->extent;
     p.inv_r2 = 1.0f / (radius * radius);

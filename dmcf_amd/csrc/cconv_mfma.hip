@@ -91,7 +91,9 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
             for (int mt = 0; mt < kMaxKT; ++mt) bacc[mt] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             float nsum = 0.0f;
             if (i < p.n_out) {
-                const int64_t rb = p.rs[i], re = p.rs[i + 1];
+                const int64_t rb = p.rs[i];
+                int64_t re = p.rs[i + 1];
+                if (re > p.pair_cap) re = rb;
                 const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
                 const float fi = (symmetric && ch_ok) ? p.inp_feat[i * cin + c0 + mi] : 0.0f;
                 const int nb = (int)((re - rb + 63) >> 6);

@@ -206,9 +206,13 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                                                  const uint32_t* __restrict__ cell_start,
                                                  const float4* __restrict__ sorted, float radius, int flags,
                                                  int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
-                                                 int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist) {
+                                                 int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
+                                                 int64_t capacity) {
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;  // whole wave leaves
+    // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
+    // row_splits[m] > capacity and repeats the search with exact buffers)
+    if (WRITE && row_splits[qi + 1] > capacity) return;
     const int lane = lane_id();
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     const float q[3] = {qx, qy, qz};
@@ -353,18 +357,18 @@ int dmcf_frs_count(const float* queries, int64_t m, int64_t n, float radius, int
     if (m > 0) {
         const unsigned g = (unsigned)((m + 3) / 4);
         hipLaunchKernelGGL((frs_query<false>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted,
-                           radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr);
+                           radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
     }
     return scan_counts_to_row_splits(counts, row_splits, m, ws + L.off_scan, L.scan_bytes, stream);
 }
 
 int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int flags, const void* workspace,
                    size_t workspace_bytes, const int64_t* row_splits, int32_t* neighbors_index,
-                   float* neighbors_distance, dmcf_stream_t stream_) {
+                   float* neighbors_distance, int64_t pair_capacity, dmcf_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_splits || (m > 0 && !queries)) return DMCF_EINVAL;
     if (m == 0) return DMCF_OK;
-    if (!neighbors_index) return DMCF_EINVAL;
+    if (!neighbors_index || pair_capacity < 0) return DMCF_EINVAL;
     const FrsLayout L = frs_layout(n, m);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
     const char* ws = (const char*)workspace;
@@ -373,7 +377,7 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
     const float4* sorted = (const float4*)(ws + L.off_sorted);
     const unsigned g = (unsigned)((m + 3) / 4);
     hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
-                       flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance);
+                       flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity);
     return check_launch();
 }
 

@@ -19,8 +19,66 @@ import torch
 
 from . import _lib
 
-NeighborSearchResult = collections.namedtuple(
-    "NeighborSearchResult", ["neighbors_index", "neighbors_row_splits", "neighbors_distance"])
+class NeighborCapacityExceeded(RuntimeError):
+    """A search enqueued with estimated buffer sizes produced more pairs than the buffers hold."""
+
+
+class NeighborSearchResult:
+    """(neighbors_index int32 [P], neighbors_row_splits int64 [m+1], neighbors_distance float32 [P]) as returned by
+    ``ml3d.layers.FixedRadiusSearch`` -- attribute access and tuple unpacking both work
+    (utils/convolutions.py:381-382, utils/tools/losses.py:297-298).
+
+    The index / distance buffers may be LARGER than P when the search was enqueued without a host round trip
+    (``capacity_hint``); the public attributes then synchronise once and return exact-length views.  Internal
+    consumers use :meth:`raw`, which never synchronises (the kernels only need row_splits)."""
+
+    def __init__(self, index_buf, row_splits, dist_buf, total=None, redo=None):
+        self._index_buf, self._dist_buf = index_buf, dist_buf
+        self.neighbors_row_splits = row_splits
+        self._total = total
+        self._redo = redo
+
+    def raw(self):
+        return self._index_buf, self.neighbors_row_splits, self._dist_buf
+
+    @property
+    def total_ref(self):
+        """0-dim device tensor holding P (no synchronisation)."""
+        return self.neighbors_row_splits[-1]
+
+    @property
+    def capacity(self):
+        return self._index_buf.shape[0]
+
+    def resolve(self):
+        """Make the result exact: one synchronisation; repeats the write pass if the estimate was too small."""
+        if self._total is None:
+            total = int(self.neighbors_row_splits[-1].item())
+            if total > self._index_buf.shape[0]:
+                self._index_buf, self._dist_buf = self._redo(total)
+            self._total = total
+        return self._total
+
+    def overflowed(self, total):
+        return self._total is None and total > self._index_buf.shape[0]
+
+    @property
+    def neighbors_index(self):
+        return self._index_buf[:self.resolve()]
+
+    @property
+    def neighbors_distance(self):
+        n = self.resolve()
+        return self._dist_buf[:n] if self._dist_buf.shape[0] >= n else self._dist_buf
+
+    def __iter__(self):
+        return iter((self.neighbors_index, self.neighbors_row_splits, self.neighbors_distance))
+
+    def __getitem__(self, i):
+        return tuple(self)[i]
+
+    def __len__(self):
+        return 3
 
 MAPPINGS = {"ball_to_cube_radial": 0, "ball_to_cube_volume_preserving": 1, "identity": 2}
 INTERPOLATIONS = {"linear": 0, "linear_border": 1, "nearest_neighbor": 2}
@@ -49,7 +107,11 @@ class LaunchTimer:
 
     def results(self):
         """-> list of (kind, meta, milliseconds); call after a device synchronise."""
-        return [(k, m, s.elapsed_time(e)) for k, m, s, e in self.records]
+        out = []
+        for k, m, s, e in self.records:
+            m = {a: (int(b.item()) if isinstance(b, torch.Tensor) else b) for a, b in m.items()}
+            out.append((k, m, s.elapsed_time(e)))
+        return out
 
 
 timer = None
@@ -109,9 +171,12 @@ def build_spatial_hash_table(points, radius, n_queries=None, **_ignored):
 
 
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
-                        hash_table=None):
+                        hash_table=None, capacity_hint=None):
     """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
-    neighbors_distance float32 [P] (squared L2; empty if not return_distances))."""
+    neighbors_distance float32 [P] (squared L2; empty if not return_distances)).
+
+    ``capacity_hint``: an estimate of P.  With it count, scan and write are enqueued back to back with buffers of
+    that size and NO host synchronisation; the result is validated later (see NeighborSearchResult)."""
     L = _lib.lib()
     points = _dev_f32(points, "points", 3)
     queries = _dev_f32(queries, "queries", 3)
@@ -125,24 +190,37 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     ws = hash_table.workspace
     nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
     flags = 1 if ignore_query_point else 0
-    row_splits = torch.empty(m + 1, dtype=torch.int64, device=points.device)
+    dev = points.device
+    row_splits = torch.empty(m + 1, dtype=torch.int64, device=dev)
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
     if timer is not None:
         timer.end("frs_count", dict(n_points=n, n_queries=m), t0)
-    total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
-    index = torch.empty(total, dtype=torch.int32, device=points.device)
-    dist = torch.empty(total if return_distances else 0, dtype=torch.float32, device=points.device)
-    t1 = timer.begin() if timer is not None else None
-    if total > 0:
-        _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits),
-                                    _ptr(index), _ptr(dist) if return_distances else None, _stream()),
-                   "dmcf_frs_write")
+
+    def write(capacity):
+        index = torch.empty(capacity, dtype=torch.int32, device=dev)
+        dist = torch.empty(capacity if return_distances else 0, dtype=torch.float32, device=dev)
+        if capacity > 0 and m > 0:
+            _lib.check(L.dmcf_frs_write(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits),
+                                        _ptr(index), _ptr(dist) if return_distances else None, capacity, _stream()),
+                       "dmcf_frs_write")
+        return index, dist
+
+    if capacity_hint is None:
+        total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
+        t1 = timer.begin() if timer is not None else None
+        index, dist = write(total)
+        res = NeighborSearchResult(index, row_splits, dist, total=total)
+    else:
+        t1 = timer.begin() if timer is not None else None
+        index, dist = write(max(int(capacity_hint), 1))
+        keep = (points, queries, ws)  # noqa: F841  (the closure keeps the operands alive for a possible redo)
+        res = NeighborSearchResult(index, row_splits, dist, total=None, redo=write)
     if timer is not None:
-        timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=total), t1)
-        timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=total), t0)
-    return NeighborSearchResult(index, row_splits, dist)
+        timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=res.total_ref), t1)
+        timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
+    return res
 
 
 class FixedRadiusSearch:
@@ -161,14 +239,14 @@ class FixedRadiusSearch:
         self.max_hash_table_size = max_hash_table_size
 
     def __call__(self, points, queries, radius, points_row_splits=None, queries_row_splits=None,
-                 hash_table_size_factor=1 / 64, hash_table=None):
+                 hash_table_size_factor=1 / 64, hash_table=None, capacity_hint=None):
         if points_row_splits is not None or queries_row_splits is not None:
             raise NotImplementedError("batched row_splits are not used by DMCF (batch items are looped, "
                                       "pipelines/simulator.py:68-70)")
         if isinstance(radius, torch.Tensor):
             radius = float(radius)
         return fixed_radius_search(points, queries, radius, self.ignore_query_point, self.return_distances,
-                                   hash_table=hash_table)
+                                   hash_table=hash_table, capacity_hint=capacity_hint)
 
     call = __call__
 
@@ -269,7 +347,8 @@ def cconv_geometry(kernel_dims, out_positions, extent, inp_positions, neighbors_
 def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
-                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None):
+                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None,
+                  n_pairs_ref=None):
     """One call of dmcf_cconv_forward.  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
     ``geometry``: optional result of :func:`cconv_geometry` for the same operands."""
@@ -293,7 +372,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         kdims = [int(d) for d in filters.shape[:3]]
         if symmetric:
             kdims[int(sym_axis)] *= 2
-        timer.end("cconv", dict(pairs=int(a.n_pairs), n_out=n_out, cin=int(filters.shape[3]), cout=cout,
+        timer.end("cconv", dict(pairs=n_pairs_ref if n_pairs_ref is not None else int(a.n_pairs), n_out=n_out, cin=int(filters.shape[3]), cout=cout,
                                 K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric)), t0)
     return out
 

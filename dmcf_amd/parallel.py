@@ -244,7 +244,10 @@ class ShardedSimulator:
     # -- one step ----------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, state):
-        with neighbor_cache():
+        # Estimated neighbour-buffer sizes are NOT used here: an overflow would have to be agreed on by all ranks
+        # before anyone repeats the step (an extra all-reduce per step); the host round trips they save are hidden
+        # by the all-to-all synchronisation points this path has anyway.
+        with neighbor_cache(estimate=False):
             return self._step(state)
 
     def _step(self, state):

@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from ..utils.config import Config
+from .. import ops
 from ..utils.convolutions import neighbor_cache
 
 log = logging.getLogger(__name__)
@@ -46,8 +47,13 @@ class Simulator:
         """simulator.py:57-71."""
         results = []
         for bi in range(len(inputs)):
-            with neighbor_cache():
-                pos, vel = self.model(inputs[bi], training=False)
+            try:
+                with neighbor_cache(estimate=True):
+                    pos, vel = self.model(inputs[bi], training=False)
+            except ops.NeighborCapacityExceeded:
+                # a neighbour list grew by more than the slack since the previous step: repeat with exact sizes
+                with neighbor_cache(estimate=False):
+                    pos, vel = self.model(inputs[bi], training=False)
             results.append([pos, vel] + list(inputs[bi][2:]))
         return results
 

@@ -11,6 +11,7 @@ Inference only: the layer does not record autograd history (training is out of s
 section 2 row 16).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -33,22 +34,43 @@ class _NeighborCache:
 
     def __init__(self):
         self.depth = 0
+        # pair-count estimates from the previous step, by position in the step's sequence of distinct searches:
+        # with them a step enqueues all its searches without a single host round trip (see search())
+        self.hints = []
+        self.use_hints = False
+        self.order = 0
+        self.pending = []
         self.lists = {}
         self.tables = {}
         self.geometries = {}
         self.keepalive = []
 
     def __enter__(self):
+        if self.depth == 0:
+            self.order = 0
+            self.pending = []
         self.depth += 1
         return self
 
-    def __exit__(self, *exc):
+    def __exit__(self, exc_type, exc, tb):
         self.depth -= 1
         if self.depth == 0:
+            pending, self.pending = self.pending, []
             self.lists.clear()
             self.tables.clear()
             self.geometries.clear()
             self.keepalive.clear()
+            if exc_type is None and pending:
+                # one synchronisation per step: validate the estimated buffer sizes, refresh the estimates
+                totals = torch.stack([r.total_ref for _, r in pending]).tolist()
+                bad = False
+                for (slot, r), total in zip(pending, totals):
+                    bad |= r.overflowed(total)
+                    while len(self.hints) <= slot:
+                        self.hints.append(None)
+                    self.hints[slot] = total
+                if bad:
+                    raise ops.NeighborCapacityExceeded("a neighbour list outgrew its estimated buffer; repeat the step")
         return False
 
     @staticmethod
@@ -69,7 +91,16 @@ class _NeighborCache:
         if table is None or table.n_queries_capacity < queries.shape[0]:
             table = ops.build_spatial_hash_table(points, radius, n_queries=max(points.shape[0], queries.shape[0]))
             self.tables[tkey] = table
-        res = frs(points, queries, radius, hash_table=table)
+        slot, self.order = self.order, self.order + 1
+        hint = self.hints[slot] if (self.use_hints and slot < len(self.hints)) else None
+        if hint is not None:
+            # 1/8 + 64 Ki pairs of slack over the previous step's count (HBM is plentiful: 288 GB); an overflow is
+            # detected at the end of the step (one sync) and the step is repeated with exact sizes.  Measured on the
+            # 1M-particle box: neighbour counts can grow by 2-3 % per step while the initial lattice relaxes.
+            res = frs(points, queries, radius, hash_table=table, capacity_hint=hint + hint // 8 + 65536)
+        else:
+            res = frs(points, queries, radius, hash_table=table)
+        self.pending.append((slot, res))
         self.lists[key] = res
         self.keepalive.append((points, queries))  # keep storage alive so data_ptr keys stay unique
         return res
@@ -96,9 +127,39 @@ _CACHE = _NeighborCache()
 USE_GEOMETRY_CACHE = False
 
 
-def neighbor_cache():
+class _CacheScope:
+    """``with neighbor_cache(estimate=...)``: enters the process-wide cache; ``estimate`` (outermost scope only)
+    turns on buffer sizes estimated from the previous step -- the caller must then be prepared to repeat the step
+    on :class:`dmcf_amd.ops.NeighborCapacityExceeded` (Simulator.run_inference does)."""
+
+    def __init__(self, estimate):
+        self.estimate = estimate
+
+    def __enter__(self):
+        if _CACHE.depth == 0:
+            self.prev = _CACHE.use_hints
+            _CACHE.use_hints = bool(self.estimate) and os.environ.get("DMCF_NO_ESTIMATE") != "1"
+            self.outer = True
+        else:
+            self.outer = False
+        return _CACHE.__enter__()
+
+    def __exit__(self, *exc):
+        try:
+            return _CACHE.__exit__(*exc)
+        finally:
+            if self.outer:
+                _CACHE.use_hints = self.prev
+
+
+def neighbor_cache(estimate=False):
     """Context manager enabling per-step neighbour-list reuse (see :class:`_NeighborCache`)."""
-    return _CACHE
+    return _CacheScope(estimate)
+
+
+def neighbor_hints():
+    """The per-slot pair-count estimates of the process-wide cache (tests / diagnostics)."""
+    return _CACHE.hints
 
 
 def _init_tensor(name, shape, device):
@@ -225,7 +286,7 @@ class ContinuousConv(torch.nn.Module):
             extent = float(extents)
         else:
             extent = float(np.float32(extents))
-        window, window_fac, neighbors_value = None, 1.0, None
+        window, window_fac, neighbors_value, n_pairs_ref = None, 1.0, None, None
         if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :341-349
             neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
             if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
@@ -237,17 +298,20 @@ class ContinuousConv(torch.nn.Module):
                                                     hash_table=fixed_radius_search_hash_table)
             else:
                 self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
-            neighbors_index, neighbors_row_splits = self.nns.neighbors_index, self.nns.neighbors_row_splits
+            # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
+            neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
+            n_pairs_ref = self.nns.total_ref
             if self.window_function is not None:  # :359-379
                 if isinstance(self.window_function, WindowFunction):
                     window, window_fac = self.window_function.name, self.window_function.fac
-                    neighbors_value = self.nns.neighbors_distance  # d^2; q = d^2/R^2 is formed in the kernel
+                    neighbors_value = raw_dist  # d^2; q = d^2/R^2 is formed in the kernel
                 else:
                     q = self.nns.neighbors_distance / (np.float32(radius) * np.float32(radius))
+                    neighbors_index = self.nns.neighbors_index
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
-        # stats (convolutions.py:385-388); a 0-dim device tensor, no host sync
-        n_out = out_positions.shape[0]
-        self._avg_neighbors = neighbors_index.shape[0] / max(n_out, 1)
+        # stats (convolutions.py:385-388) are formed lazily (property _avg_neighbors): no host sync here
+        self._n_out_last = out_positions.shape[0]
+        self._pairs_last = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
 
         kernel = self.kernel
         symmetric = self.symmetric
@@ -269,10 +333,13 @@ class ContinuousConv(torch.nn.Module):
             raise NotImplementedError("symmetric=True with normalize=True (DMCF always uses normalize=False, "
                                       "models/pbf_model.py:203)")
         geometry = None
-        if (USE_GEOMETRY_CACHE and self.nns is not None and neighbors_index is self.nns.neighbors_index
+        if (USE_GEOMETRY_CACHE and self.nns is not None and user_neighbors_index is None
                 and window not in (None, "explicit")
                 and inp_importance is None and not self.circular
                 and ops.geometry_supported(self.align_corners, self.coordinate_mapping, self.interpolation)):
+            neighbors_index = self.nns.neighbors_index  # exact length: the cache is sized by P
+            if neighbors_value is raw_dist:
+                neighbors_value = self.nns.neighbors_distance
             kdims = tuple(int(d) for d in kernel.shape[:3])
             gkey = (kdims, float(extent), window, float(window_fac), bool(symmetric), int(self.sym_axis))
             geometry = _CACHE.geometry(self.nns, gkey, lambda: ops.cconv_geometry(
@@ -285,7 +352,7 @@ class ContinuousConv(torch.nn.Module):
             neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
-            bias=self.bias if fuse_bias else None, geometry=geometry)
+            bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref)
         self._conv_output = out_features
         if self.use_dense_layer_for_center:  # :462-464
             self._dense_output = inp_features @ self.dense
@@ -297,6 +364,13 @@ class ContinuousConv(torch.nn.Module):
         return out_features
 
     call = forward
+
+    @property
+    def _avg_neighbors(self):
+        """pairs / outputs of the last call (convolutions.py:385-388); synchronises when read."""
+        pairs = self._pairs_last
+        pairs = int(pairs.item()) if isinstance(pairs, torch.Tensor) else pairs
+        return pairs / max(self._n_out_last, 1)
 
     def compute_output_shape(self, inp_features_shape):
         return (None, self.filters)

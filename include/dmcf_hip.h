@@ -77,10 +77,15 @@ int dmcf_frs_build(const float* points, int64_t n_points, float radius, void* wo
 int dmcf_frs_count(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags,
                    void* workspace, size_t workspace_bytes, int64_t* row_splits, dmcf_stream_t stream);
 
-/* write neighbors_index[P] (int32) and, if not NULL, neighbors_distance[P] (squared L2) */
+/* write neighbors_index[P] (int32) and, if not NULL, neighbors_distance[P] (squared L2).  pair_capacity = number
+ * of entries the two output buffers hold.  A caller that read row_splits[m] passes exactly that.  A caller that
+ * wants NO host round trip allocates from an estimate (e.g. the previous time step's count plus slack), enqueues
+ * count + write back to back and checks row_splits[m] <= pair_capacity later: rows that would not fit are skipped
+ * as a whole, never written out of bounds. */
 int dmcf_frs_write(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags,
                    const void* workspace, size_t workspace_bytes, const int64_t* row_splits,
-                   int32_t* neighbors_index, float* neighbors_distance, dmcf_stream_t stream);
+                   int32_t* neighbors_index, float* neighbors_distance, int64_t pair_capacity,
+                   dmcf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Continuous convolution (CConv) and its antisymmetric variant (ASCC).
@@ -144,7 +149,8 @@ typedef struct dmcf_cconv_args {
     /* optional per-pair geometry cache filled by dmcf_cconv_geometry for the same positions / neighbour list /
      * extent / filter dims / window; NULL = evaluate window + mapping inside the convolution */
     const void* geometry;
-    int64_t n_pairs;            /* P = neighbors_row_splits[n_out]; only read when geometry != NULL or by dmcf_cconv_geometry */
+    int64_t n_pairs;            /* entries in neighbors_index / neighbors_value (>= P = neighbors_row_splits[n_out]);
+                                 * rows reaching past it are treated as empty (see dmcf_frs_write pair_capacity) */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);

@@ -9,9 +9,10 @@ from dmcf_amd import ops
 
 
 def install(monkeypatch):
-    def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True, hash_table=None):
+    def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True, hash_table=None,
+                            capacity_hint=None):
         idx, rs, d = O.fixed_radius_search(points.numpy(), queries.numpy(), radius, ignore_query_point)
-        return ops.NeighborSearchResult(torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d))
+        return ops.NeighborSearchResult(torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d), total=len(idx))
 
     def build_spatial_hash_table(points, radius, n_queries=None, **kw):
         return ops.SpatialHashTable(points, radius, None, 1 << 60)
@@ -19,7 +20,7 @@ def install(monkeypatch):
     def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                       neighbors_value=None, window=None, window_fac=1.0, inp_importance=None, align_corners=True,
                       coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear", normalize=False,
-                      symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None):
+                      symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None, n_pairs_ref=None):
         radius = np.float32(0.5) * np.float32(extent)
         imp = None
         if window == "explicit":

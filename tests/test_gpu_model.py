@@ -139,3 +139,29 @@ def test_rollout_with_changing_particle_count(dev):
     state = [torch.cat([state[0], extra]), torch.cat([state[1], torch.zeros_like(extra)])] + list(state[2:])
     out = sim.step([state])[0]
     assert out[0].shape == (512 + 64, 3) and torch.isfinite(out[0]).all()
+
+
+def test_estimated_neighbour_buffers_recover_from_overflow(dev):
+    """Steps after the first enqueue their searches with buffer sizes estimated from the previous step (no host
+    round trip).  Feeding a much larger scene next must be detected and the step repeated exactly."""
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.utils.convolutions import neighbor_hints
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    model = _build(configs.LIQUID3D, w, dev)
+    sim = Simulator(model, device="cuda")
+    small = scenes.model_inputs(scenes.box_scene(6, seed=1), device=dev)
+    big = scenes.model_inputs(scenes.box_scene(12, seed=2), device=dev)
+    sim.step([small])
+    sim.step([small])  # now running on estimates
+    assert any(h is not None for h in neighbor_hints())
+    out = sim.step([big])[0]  # every list overflows its estimate -> repeated with exact sizes
+    fresh = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+    neighbor_hints().clear()
+    ref = fresh.step([big])[0]
+    assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+    # and the estimate path itself is exact when nothing overflows
+    a = sim.step([big])[0]
+    neighbor_hints().clear()
+    b = fresh.step([big])[0]
+    assert torch.equal(a[0], b[0])
