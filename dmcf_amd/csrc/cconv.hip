@@ -505,6 +505,8 @@ size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
     size_t floats = cfg.packed_floats;
     const size_t mf = cconv_mfma_packed_floats(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
     if (floats < mf) floats = mf;
+    const size_t bf = cconv_blk_packed_floats(a->filter_dims[3], a->filter_dims[4]);
+    if (floats < bf) floats = bf;
     return 256 + align_up(floats * sizeof(float), 256);
 }
 
@@ -555,6 +557,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.flags = a->flags;
     p.bias = a->bias;
     p.out = a->out;
+    if (cconv_blk_eligible(a, dz, dy, dx)) return cconv_blk_launch(p, a, workspace, stream);
     if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
     p.KCp = cfg.KCp;
     p.PS = cfg.PS;

@@ -215,4 +215,10 @@ bool cconv_mfma_eligible(int K, int cin, int cout);
 size_t cconv_mfma_packed_floats(int K, int cin, int cout);
 int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, int dx, void* workspace, hipStream_t stream);
 
+
+// cconv_blk.hip
+bool cconv_blk_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+size_t cconv_blk_packed_floats(int cin, int cout);
+int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+
 }  // namespace dmcf

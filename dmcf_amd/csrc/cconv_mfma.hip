@@ -333,7 +333,7 @@ static MfmaCfg mfma_cfg(int K, int cin, int cout) {
 
 bool cconv_mfma_eligible(int K, int cin, int cout) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma": force one implementation (A/B tests)
-    if (e && e[0] == 'l') return false;
+    if (e && e[0] != 'm') return false;
     if (K > 16 * kMaxKT || cout > 16 * kMMaxNT) return false;
     if (e && e[0] == 'm') return true;
     // Measured on MI355X at 3.07e8 pairs (profiles/): the LDS splat costs ~6.9 ms per 8-channel pass (5.7 ms for a

@@ -98,12 +98,23 @@ __global__ __launch_bounds__(256) void frs_bbox(const float* __restrict__ pts, i
             mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, kWave));
         }
     }
+    // one atomic per block and component: same-address atomics serialise in L2 (measured: 24k of them = 240 us)
+    __shared__ float red[2][3][4];
+    const int w = threadIdx.x >> 6;
     if (lane_id() == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            atomicMin(&h->bb_min[a], f2ord(mn[a]));
-            atomicMax(&h->bb_max[a], f2ord(mx[a]));
+            red[0][a][w] = mn[a];
+            red[1][a][w] = mx[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        const float lo = fminf(fminf(red[0][a][0], red[0][a][1]), fminf(red[0][a][2], red[0][a][3]));
+        const float hi = fmaxf(fmaxf(red[1][a][0], red[1][a][1]), fmaxf(red[1][a][2], red[1][a][3]));
+        atomicMin(&h->bb_min[a], f2ord(lo));
+        atomicMax(&h->bb_max[a], f2ord(hi));
     }
 }
 
@@ -318,7 +329,7 @@ int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace
     hipLaunchKernelGGL(frs_init_header, dim3(1), dim3(64), 0, stream, h, radius, (int32_t)n);
     if (n > 0) {
         const unsigned g = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(frs_bbox, dim3(g < 1024u ? g : 1024u), dim3(256), 0, stream, points, n, h);
+        hipLaunchKernelGGL(frs_bbox, dim3(g < 512u ? g : 512u), dim3(256), 0, stream, points, n, h);
     }
     hipLaunchKernelGGL(frs_finish_header, dim3(1), dim3(64), 0, stream, h, L.table);
     // cell_fill doubles as the histogram: count -> scan into cell_start -> clear -> scatter cursors

@@ -55,7 +55,7 @@ class NeighborSearchResult:
         if self._total is None:
             total = int(self.neighbors_row_splits[-1].item())
             if total > self._index_buf.shape[0]:
-                self._index_buf, self._dist_buf = self._redo(total)
+                self._index_buf, self._dist_buf = self._redo(pair_capacity(total))
             self._total = total
         return self._total
 
@@ -170,6 +170,16 @@ def build_spatial_hash_table(points, radius, n_queries=None, **_ignored):
     return SpatialHashTable(points, radius, ws, m)
 
 
+def pair_capacity(total):
+    """Entries to allocate for a neighbour list of ``total`` pairs: 1/8 slack (the list of the next time step fits
+    the same buffer) rounded up to 1/8 of the enclosing power of two, so that a rollout asks the caching allocator
+    for the same few block sizes every step instead of a slightly different one each time (each new size is a
+    hipMalloc of hundreds of MB: measured 12-18 GB of fresh allocations per step until sizes happened to repeat)."""
+    x = int(total) + int(total) // 8 + 65536
+    g = max(1 << 16, 1 << max(x.bit_length() - 4, 0))
+    return (x + g - 1) // g * g
+
+
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
                         hash_table=None, capacity_hint=None):
     """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
@@ -210,11 +220,11 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     if capacity_hint is None:
         total = int(row_splits[-1].item())  # the one host round trip of the two-phase search
         t1 = timer.begin() if timer is not None else None
-        index, dist = write(total)
+        index, dist = write(pair_capacity(total) if total else 0)
         res = NeighborSearchResult(index, row_splits, dist, total=total)
     else:
         t1 = timer.begin() if timer is not None else None
-        index, dist = write(max(int(capacity_hint), 1))
+        index, dist = write(pair_capacity(capacity_hint))
         keep = (points, queries, ws)  # noqa: F841  (the closure keeps the operands alive for a possible redo)
         res = NeighborSearchResult(index, row_splits, dist, total=None, redo=write)
     if timer is not None:
@@ -422,4 +432,44 @@ def neighbor_counts(row_splits):
     out = torch.empty(n_rows, dtype=torch.float32, device=row_splits.device)
     _lib.check(L.dmcf_reduce_subarrays_sum(None, _ptr(row_splits.contiguous()), n_rows, _ptr(out), _stream()),
                "dmcf_reduce_subarrays_sum")
+    return out
+
+
+GRID_MAX_CELLS = 1 << 31  # dense cell table of the lattice bounding box: 4 bytes per cell, at most 8 GiB
+
+
+class GridTooSparse(RuntimeError):
+    """The bounding box of the candidate cells has more than GRID_MAX_CELLS cells (a few particles very far apart):
+    the caller uses the sort-based device formulation instead."""
+
+
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
+    """Lattice points of ``grid_pos`` (utils/tools/losses.py:136-181) via dmcf_grid_pos_bounds/_count/_write.
+    ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean)."""
+    import numpy as np
+    L = _lib.lib()
+    pos = _dev_f32(pos, "pos", 3)
+    n = pos.shape[0]
+    vs = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(voxel_size, dtype=np.float32).reshape(3)])
+    cen = None
+    if center is not None:
+        cen = _dev_f32(center.reshape(3), "center")
+    ws_bytes = L.dmcf_grid_pos_workspace_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+    common = (1 if centralize else 0,)
+    _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, common[0], _ptr(cen) if cen is not None else None, int(pad),
+                                      float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
+    cells = int(ws[24:32].view(torch.int64).item())  # header.cells (host round trip 1 of 2)
+    if cells < 0:
+        raise _lib.DmcfError("grid_pos: positions are not finite")
+    if cells > GRID_MAX_CELLS:
+        raise GridTooSparse(f"{cells} lattice cells in the bounding box")
+    table = torch.empty(max(cells, 1), dtype=torch.int32, device=pos.device)
+    _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes, _ptr(table),
+                                     cells, _stream()), "dmcf_grid_pos_count")
+    total = int(ws[32:40].view(torch.int64).item())  # header.total (host round trip 2 of 2)
+    out = torch.empty((total, 3), dtype=torch.float32, device=pos.device)
+    if total:
+        _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
+                                         _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
     return out

@@ -97,7 +97,7 @@ class _NeighborCache:
             # 1/8 + 64 Ki pairs of slack over the previous step's count (HBM is plentiful: 288 GB); an overflow is
             # detected at the end of the step (one sync) and the step is repeated with exact sizes.  Measured on the
             # 1M-particle box: neighbour counts can grow by 2-3 % per step while the initial lattice relaxes.
-            res = frs(points, queries, radius, hash_table=table, capacity_hint=hint + hint // 8 + 65536)
+            res = frs(points, queries, radius, hash_table=table, capacity_hint=hint)
         else:
             res = frs(points, queries, radius, hash_table=table)
         self.pending.append((slot, res))

@@ -73,6 +73,12 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     # force a device round trip; values are float32 like the reference's tf.constant
     vs_host = np.asarray(voxel_size.detach().cpu() if isinstance(voxel_size, torch.Tensor) else voxel_size,
                          dtype=np.float32).reshape(3)
+    if pos.is_cuda:  # product path: the HIP kernels (csrc/grid.hip); below is the host-side form of the same
+        from ... import ops
+        try:
+            return ops.grid_pos(pos, vs_host, centralize=centralize, pad=pad, hyst=hyst, center=center)
+        except ops.GridTooSparse:
+            pass  # bounding box too large for a dense cell table: sort-based form, still on the device
     voxel_size = torch.from_numpy(vs_host.copy()).to(pos.device)
     if centralize:
         if center is None:

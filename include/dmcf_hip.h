@@ -14,7 +14,8 @@
  *   ml3d.ops.continuous_conv (utils/convolutions.py:414-431)     dmcf_cconv_forward
  *   ASCC: mirror :410-412 + second continuous_conv :433-458      dmcf_cconv_forward(DMCF_FLAG_SYMMETRIC)
  *   o3dml.ops.reduce_subarrays_sum (models/pbf_model.py:450-453) dmcf_reduce_subarrays_sum
- *   grid_pos / tf.unique (utils/tools/losses.py:136-181)         dmcf_grid_pos_*
+ *   grid_pos: candidate cells + tf.unique + decode               dmcf_grid_pos_bounds / _count / _write
+ *     (utils/tools/losses.py:136-181, called from :266-272)
  *
  * Conventions
  *   - plain C: raw DEVICE pointers, sizes, a stream handle (hipStream_t passed as void*); no
@@ -173,6 +174,34 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
  * ---------------------------------------------------------------------------------------------- */
 int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
                               dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * grid_pos(pos, voxel_size, centralize, pad, hyst) (utils/tools/losses.py:136-181; the coarse point sets of the
+ * multi-scale models, called through get_dilated_pos :249-284): the corners of every voxel a particle touches
+ * (with +-hyst hysteresis), de-duplicated in tf.unique order (first appearance in the candidate list), decoded to
+ * positions.  Three phases because two sizes are data dependent:
+ *   bounds : lattice origin (mean of the positions when `centralize` and `center` == NULL, else *center), integer
+ *            bounding box of the candidates -> 64-byte header at the start of `workspace`:
+ *              int32 minp[3], int32 dims[3], int64 cells (= dims product, -1 if a position is not finite),
+ *              int64 total, float center[3]
+ *            the caller reads `cells` and provides a table of that many uint32
+ *   count  : fills the table, counts the lattice points -> header.total; the caller reads it and allocates out
+ *   write  : out[total,3] float32
+ * `voxel_size` is a HOST pointer to 3 floats (axes below 1e-5 collapse, :139-141); `center` a DEVICE pointer to 3
+ * floats or NULL.  The same (positions, voxel_size, centralize, pad, hyst, workspace) must be passed to all
+ * three calls.  Candidate ranks are 32-bit: 2 * n_points * (2 + 2 pad)^3 must stay below 2^32
+ * (DMCF_EUNSUPPORTED otherwise).
+ * ---------------------------------------------------------------------------------------------- */
+size_t dmcf_grid_pos_workspace_bytes(int64_t n_points);
+int dmcf_grid_pos_bounds(const float* positions, int64_t n_points, const float* voxel_size, int centralize,
+                         const float* center, int pad, float hyst, void* workspace, size_t workspace_bytes,
+                         dmcf_stream_t stream);
+int dmcf_grid_pos_count(const float* positions, int64_t n_points, const float* voxel_size, int centralize, int pad,
+                        float hyst, void* workspace, size_t workspace_bytes, void* cell_table, int64_t table_cells,
+                        dmcf_stream_t stream);
+int dmcf_grid_pos_write(const float* positions, int64_t n_points, const float* voxel_size, int centralize, int pad,
+                        float hyst, void* workspace, size_t workspace_bytes, const void* cell_table, int64_t table_cells,
+                        float* out, int64_t out_capacity, dmcf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -284,7 +284,7 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1):
     off = np.stack(np.meshgrid(*ranges, indexing="ij"), axis=-1).reshape(1, -1, 3).astype(np.int32)
     dpos = (dpos[:, None, :] + off).reshape(-1, 3)
     minp = dpos.min(axis=0)
-    maxp = dpos.max(axis=0) - minp + 1
+    maxp = (dpos.max(axis=0) - minp + 1).astype(np.int64)  # int64: the index space of a sparse scene exceeds 2^31
     idx = ((dpos - minp).astype(np.int64) * np.array([1, maxp[0], maxp[0] * maxp[1]], dtype=np.int64)).sum(-1)
     uniq, first = np.unique(idx, return_index=True)
     idx = uniq[np.argsort(first, kind="stable")]  # tf.unique keeps first-occurrence order

@@ -299,11 +299,12 @@ def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, m
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
 def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, cout, ks, dim):
-    """The dispatcher picks the LDS or the matrix-core splat by a cost model; force each and check both."""
+    """The dispatcher picks one of the three splat kernels; force each and check it ("blk" only exists for 4x4x4
+    filters, the other shapes then exercise the fallback order)."""
     from dmcf_amd import ops
     monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
     radius = 0.3 if dim == 3 else 0.12
@@ -314,3 +315,106 @@ def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, 
     y = ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
                           nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6")
     _close(y.cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("cin,cout,sym,radius", [(4, 8, False, 0.3), (8, 32, False, 0.45), (16, 16, False, 0.6), (24, 8, False, 0.3),
+                                                 (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45)])
+def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, cin, cout, sym, radius):
+    """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA): rows from empty to several 62-pair batches, every
+    channel-chunk count, bias + accumulate, and the antisymmetric form."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "blk")
+    rng = np.random.default_rng(5)
+    if sym:
+        n = 2500
+        pos = _cloud(n, 41, 3)
+        feat = np.maximum(rng.normal(size=(n, cin)), 0).astype(np.float32)
+        k = rng.uniform(-1, 1, size=(4, 2, 4, cin, cout)).astype(np.float32)
+        nns = ops.fixed_radius_search(_t(pos, dev), _t(pos, dev), radius, ignore_query_point=True, return_distances=True)
+        conv = oracle.ContinuousConvRef(k, window_function="peak", ignore_query_points=True, symmetric=True, sym_axis=1, f64=True)
+        ref = conv(feat, pos, pos, 2 * radius, nns=tuple(x.cpu().numpy() for x in nns))
+        y = ops.cconv_forward(_t(k, dev), _t(pos, dev), 2 * radius, _t(pos, dev), _t(feat, dev), nns.neighbors_index,
+                              nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="peak",
+                              symmetric=True, sym_axis=1).cpu().numpy()
+        _close(y, ref, 2e-5)
+        assert np.all(np.abs(y.astype(np.float64).sum(axis=0)) <= 2e-5 * np.abs(y).sum(axis=0) + 1e-6)
+        return
+    inp, out, feat, filt = _conv_inputs(oracle, 91, 6000, 333, cin, cout, (4, 4, 4), radius)
+    out = np.concatenate([out, np.float32([[9, 9, 9]])])  # a row without neighbours
+    bias = rng.normal(size=cout).astype(np.float32)
+    pimp = rng.uniform(0.5, 1.5, size=inp.shape[0]).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    counts = np.diff(rs)
+    assert counts.min() == 0 and counts.max() > 62
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2),
+                                 inp_importance=pimp, f64=True)
+    acc = torch.full((out.shape[0], cout), 0.5, device=dev)
+    ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                      nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
+                      inp_importance=_t(pimp, dev), bias=_t(bias, dev), out=acc, accumulate=True)
+    _close(acc.cpu().numpy(), ref + bias + 0.5)
+
+
+@pytest.mark.parametrize("vs,cen,pad", [([0.1, 0.1, 0.1], True, 0), ([0.1, 0.1, 0.1], False, 0), ([0.05, 0.05, 0.0], True, 0),
+                                        ([0.0, 0.02, 0.0], True, 0), ([0.2, 0.1, 0.15], True, 1), ([0.07, 0.07, 0.07], False, 1)])
+def test_grid_pos_matches_oracle(oracle, dev, vs, cen, pad):
+    """csrc/grid.hip against the oracle's sort-based restatement of losses.py:136-181: same lattice points in the
+    same (tf.unique) order, bit for bit (the lattice origin is the float64 mean rounded once in both)."""
+    from dmcf_amd.utils.tools.losses import grid_pos
+    rng = np.random.default_rng(11)
+    p = rng.uniform(-1, 1, size=(5000, 3)).astype(np.float32)
+    for a in range(3):
+        if vs[a] == 0:
+            p[:, a] = 0
+    g = grid_pos(_t(p, dev), vs, centralize=cen, pad=pad).cpu().numpy()
+    ref = oracle.grid_pos(p, vs, centralize=cen, pad=pad)
+    assert g.shape == ref.shape
+    assert np.array_equal(g, ref)
+
+
+def test_grid_pos_edge_cases(oracle, dev):
+    from dmcf_amd import ops
+    from dmcf_amd.utils.tools.losses import grid_pos
+    vs = [0.1, 0.1, 0.1]
+    # empty input
+    assert grid_pos(torch.zeros((0, 3), device=dev), vs, centralize=True).shape == (0, 3)
+    # one particle: 8 corners (16 with hysteresis straddling a face)
+    one = grid_pos(_t(np.float32([[0.234, -0.51, 0.049]]), dev), vs, centralize=False).cpu().numpy()
+    assert np.array_equal(one, oracle.grid_pos(np.float32([[0.234, -0.51, 0.049]]), vs))
+    # explicit lattice origin (the sharded path passes the global mean): identical to the host form of the same code
+    rng = np.random.default_rng(5)
+    p = rng.uniform(-2, 2, size=(20000, 3)).astype(np.float32)
+    c = np.float32([0.01, -0.02, 0.03])
+    a = grid_pos(_t(p, dev), vs, centralize=True, center=_t(c, dev)).cpu().numpy()
+    b = grid_pos(torch.from_numpy(p), vs, centralize=True, center=torch.from_numpy(c)).numpy()
+    assert np.array_equal(a, b)
+    # two clusters very far apart: the dense cell table would be huge -> sort-based device form, same result
+    far = np.concatenate([p[:500], p[:500] + np.float32([4000, 4000, 4000])])
+    with pytest.raises(ops.GridTooSparse):
+        ops.grid_pos(_t(far, dev), np.float32([0.01, 0.01, 0.01]))
+    g = grid_pos(_t(far, dev), [0.01, 0.01, 0.01], centralize=False).cpu().numpy()
+    assert np.array_equal(g, oracle.grid_pos(far, [0.01, 0.01, 0.01]))
+    # non-finite positions are an error, not a crash
+    bad = p[:10].copy()
+    bad[3, 1] = np.nan
+    with pytest.raises(Exception):
+        ops.grid_pos(_t(bad, dev), np.float32(vs))
+
+
+def test_grid_pos_200k_matches_sort_formulation(dev):
+    """Size the oracle would not finish quickly: HIP kernels against the torch sort/unique formulation on the
+    device (forced through GRID_MAX_CELLS = 0), bit for bit."""
+    from dmcf_amd import ops
+    from dmcf_amd.utils.tools.losses import grid_pos
+    g = torch.Generator(device=dev).manual_seed(0)
+    p = torch.rand(200000, 3, device=dev, generator=g) * 3.0
+    c = p.mean(dim=0)
+    a = grid_pos(p, [0.05, 0.05, 0.05], centralize=True, center=c)
+    old = ops.GRID_MAX_CELLS
+    ops.GRID_MAX_CELLS = 0
+    try:
+        b = grid_pos(p, [0.05, 0.05, 0.05], centralize=True, center=c)
+    finally:
+        ops.GRID_MAX_CELLS = old
+    assert a.shape == b.shape and torch.equal(a, b)
