@@ -221,4 +221,10 @@ bool cconv_blk_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_blk_packed_floats(int cin, int cout);
 int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
+
+// cconv_direct.hip
+bool cconv_direct_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+size_t cconv_direct_packed_floats(int dz, int dy, int dx, int cin);
+int cconv_direct_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, int dx, void* workspace, hipStream_t stream);
+
 }  // namespace dmcf

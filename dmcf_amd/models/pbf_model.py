@@ -179,8 +179,9 @@ class PBFNet(BaseModel):
             pos, vel = self.integrate_pos_vel(_pos, _vel, acc)  # :318
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in self.particle_radii]  # :328
         # boundary particles outside the fluid AABB +- 2 r_max are dropped every step (:330-336)
-        lo = pos.min(dim=0).values - filter_extent[-1]
-        hi = pos.max(dim=0).values + filter_extent[-1]
+        pt = pos.t().contiguous()  # [3, N]: row reductions (a strided column reduction of [N, 3] is ~0.6 ms each)
+        lo = pt.amin(dim=1) - filter_extent[-1]
+        hi = pt.amax(dim=1) + filter_extent[-1]
         fltr = ((box >= lo) & (box <= hi)).all(dim=1)
         box = box[fltr]
         bfeats = bfeats[fltr]

@@ -418,3 +418,56 @@ def test_grid_pos_200k_matches_sort_formulation(dev):
     finally:
         ops.GRID_MAX_CELLS = old
     assert a.shape == b.shape and torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mapping,interp,align,normalize", [
+    ("ball_to_cube_volume_preserving", "linear", True, False), ("ball_to_cube_radial", "linear_border", False, True),
+    ("identity", "nearest_neighbor", True, True), ("ball_to_cube_volume_preserving", "linear_border", False, False)])
+@pytest.mark.parametrize("cin,cout,ks,dim", [(32, 3, (6, 6, 6), 3), (24, 4, (4, 4, 4), 3), (5, 1, (3, 5, 2), 3), (17, 2, (1, 8, 8), 2),
+                                            (9, 4, (1, 7, 1), 1)])
+def test_direct_kernel_option_matrix(oracle, dev, monkeypatch, mapping, interp, align, normalize, cin, cout, ks, dim):
+    """cconv_direct.hip (filter in LDS, lane = input channel, <= 4 outputs) forced for every mapping / interpolation
+    family, odd filter shapes, 1-D / 2-D scenes, bias + accumulate, rows from empty to several 32-pair batches."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "direct")
+    radius = 0.3 if dim == 3 else 0.12
+    inp, out, feat, filt = _conv_inputs(oracle, 3 * cin + cout, 3000, 400, cin, cout, ks, radius, dim)
+    out = np.concatenate([out, np.float32([[9, 9, 9]])])
+    rng = np.random.default_rng(8)
+    pimp = rng.uniform(0.5, 1.5, size=inp.shape[0]).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    assert np.diff(rs).max() > 32
+    imp = oracle.window("poly6", d / np.float32(radius) ** 2)
+    kw = dict(align_corners=align, coordinate_mapping=mapping, interpolation=interp, normalize=normalize)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, imp, inp_importance=pimp, f64=True, **kw)
+    acc = torch.full((out.shape[0], cout), 0.25, device=dev)
+    ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                      nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
+                      inp_importance=_t(pimp, dev), bias=_t(bias, dev), out=acc, accumulate=True, **kw)
+    y = acc.cpu().numpy()
+    if interp == "nearest_neighbor":
+        scale = np.abs(ref).max()
+        assert (np.abs(y - (ref + bias + 0.25)).max(axis=1) > 2e-5 * scale).mean() < 0.02
+    else:
+        _close(y, ref + bias + 0.25, 2e-5)
+
+
+@pytest.mark.parametrize("ks,sym_axis,cin,cout", [((6, 3, 6), 1, 32, 3), ((2, 4, 4), 0, 24, 4), ((4, 4, 2), 2, 7, 1)])
+def test_direct_kernel_ascc(oracle, dev, monkeypatch, ks, sym_axis, cin, cout):
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "direct")
+    rng = np.random.default_rng(19)
+    n, radius = 2500, 0.25
+    pos = _cloud(n, 29, 3)
+    feat = np.maximum(rng.normal(size=(n, cin)), 0).astype(np.float32)
+    k = rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(pos, dev), _t(pos, dev), radius, ignore_query_point=True, return_distances=True)
+    conv = oracle.ContinuousConvRef(k, window_function="peak", ignore_query_points=True, symmetric=True, sym_axis=sym_axis, f64=True)
+    ref = conv(feat, pos, pos, 2 * radius, nns=tuple(x.cpu().numpy() for x in nns))
+    y = ops.cconv_forward(_t(k, dev), _t(pos, dev), 2 * radius, _t(pos, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="peak",
+                          symmetric=True, sym_axis=sym_axis).cpu().numpy()
+    _close(y, ref, 2e-5)
+    assert np.all(np.abs(y.astype(np.float64).sum(axis=0)) <= 2e-5 * np.abs(y).sum(axis=0) + 1e-6)
