@@ -471,3 +471,24 @@ def test_direct_kernel_ascc(oracle, dev, monkeypatch, ks, sym_axis, cin, cout):
                           symmetric=True, sym_axis=sym_axis).cpu().numpy()
     _close(y, ref, 2e-5)
     assert np.all(np.abs(y.astype(np.float64).sum(axis=0)) <= 2e-5 * np.abs(y).sum(axis=0) + 1e-6)
+
+
+@pytest.mark.parametrize("n,m,radius,ignore", [(5000, 3001, 0.15, False), (20000, 20000, 0.1, True), (3000, 7, 0.9, False),
+                                               (4000, 1, 0.5, False), (100, 1000, 0.05, False)])
+def test_estimated_search_equals_exact(dev, n, m, radius, ignore):
+    """A search enqueued with estimated buffer sizes (no host round trip, as inside a rollout) == the exact two-phase
+    search bit for bit, including the too-small-buffer protocol (rows skipped, exact repeat) and empty query sets."""
+    from dmcf_amd import ops
+    pts = _t(_cloud(n, 3), dev)
+    qs = pts if ignore else _t(_cloud(m, 4), dev)
+    a = ops.fixed_radius_search(pts, qs, radius, ignore_query_point=ignore, return_distances=True)
+    total = a.neighbors_index.shape[0]
+    b = ops.fixed_radius_search(pts, qs, radius, ignore_query_point=ignore, return_distances=True, capacity_hint=total)
+    assert torch.equal(a.neighbors_row_splits, b.neighbors_row_splits)
+    assert torch.equal(a.neighbors_index, b.neighbors_index) and torch.equal(a.neighbors_distance, b.neighbors_distance)
+    if total > 200000:
+        c = ops.fixed_radius_search(pts, qs, radius, ignore_query_point=ignore, return_distances=True, capacity_hint=total // 3)
+        assert c.overflowed(total)
+        assert torch.equal(a.neighbors_index, c.neighbors_index) and torch.equal(a.neighbors_distance, c.neighbors_distance)
+    e = ops.fixed_radius_search(pts, qs[:0], radius, return_distances=True, capacity_hint=10)
+    assert e.neighbors_row_splits.tolist() == [0] and e.neighbors_index.shape[0] == 0
