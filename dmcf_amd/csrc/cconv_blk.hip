@@ -29,9 +29,17 @@
 
 namespace dmcf {
 
-constexpr int kBThreads = 512;
-constexpr int kBWaves = kBThreads / 64;
-constexpr int BTM = 16;        // output points per workgroup
+#ifndef BLK_WAVES
+#define BLK_WAVES 4
+#endif
+constexpr int kBWaves = BLK_WAVES;
+#ifndef BLK_OCC
+#define BLK_OCC 4  // waves per SIMD the register budget is set for.  Measured (L8, 3.07e8 pairs): 4 waves x 4 WGs with
+                   // ~40 spilled VGPRs outside the inner loop 8.2 ms; 3 per SIMD without spills 8.7 ms; 8-wave WGs 8.5 ms
+#endif
+constexpr int kBThreads = 64 * kBWaves;
+constexpr int BTM = 2 * kBWaves;   // output points per workgroup = rows of the B tile
+constexpr int kBRows = 16;         // M of the contraction MFMA (rows >= BTM alias rows < BTM; their results are dropped)
 constexpr int BCH = 16;        // channels per pass
 constexpr int kRow = 1024;     // floats per B row: 64 cells x 16 channels
 constexpr int kHalf = 31;      // pairs per half batch (A staging: 8 chunks x 31 pairs x 4 floats <= one B row)
@@ -75,7 +83,7 @@ struct Compact {  // per pair, in the registers of the owner lane
 };
 
 template <int NTT>
-__global__ __launch_bounds__(kBThreads, 4) void cconv_blk_kernel(const CconvParams p) {
+__global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(kBThreads, 4) void cconv_blk_kernel(const CconvPara
         // ---------------- contraction of this channel chunk on the matrix cores (as cconv_mfma.hip) ----------------
         const float* Wc = p.Wp + (size_t)chunk * p.nblocks * (4 * p.NT * 16 * 4);
         for (int blk = wave; blk < p.nblocks; blk += kBWaves) {
-            const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+            const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % BTM) * kRow + ((blk * 16 + mg * 4) ^ ((mi % BTM) << 2)));
             const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
 #pragma unroll
             for (int n = 0; n < NTT; ++n) {
@@ -369,13 +377,13 @@ __global__ __launch_bounds__(kBThreads, 4) void cconv_blk_kernel(const CconvPara
     }
 
     // ---------------- cross-wave reduction + epilogue ----------------
-    float* red = Bt;  // [kBWaves][BTM][16*NT]
+    float* red = Bt;  // [kBWaves][kBRows][16*NT]
     const int ncol = 16 * p.NT;
 #pragma unroll
     for (int n = 0; n < NTT; ++n) {
         if (n < p.NT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[((size_t)wave * BTM + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * kBRows + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
         }
     }
     __syncthreads();
@@ -385,7 +393,7 @@ __global__ __launch_bounds__(kBThreads, 4) void cconv_blk_kernel(const CconvPara
         if (ii >= p.n_out) continue;
         float v = 0.0f;
 #pragma unroll
-        for (int w = 0; w < kBWaves; ++w) v += red[((size_t)w * BTM + ptt) * ncol + o];
+        for (int w = 0; w < kBWaves; ++w) v += red[((size_t)w * kBRows + ptt) * ncol + o];
         if (p.bias) v += p.bias[o];
         float* dst = p.out + ii * cout + o;
         if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
@@ -393,7 +401,7 @@ __global__ __launch_bounds__(kBThreads, 4) void cconv_blk_kernel(const CconvPara
     }
 }
 
-static constexpr size_t kBlkLds = (size_t)(BTM * kRow + kBWaves * kFst) * sizeof(float);  // 80 KB
+static constexpr size_t kBlkLds = (size_t)(BTM * kRow + kBWaves * kFst) * sizeof(float);
 
 size_t cconv_blk_packed_floats(int cin, int cout) {
     const int nchunks = (cin + BCH - 1) / BCH, NT = (cout + 15) / 16;
