@@ -11,7 +11,7 @@
 //     with a ballot + mbcnt prefix (no atomics, no LDS), rows come out in a deterministic order;
 //   * everything that sizes the grid (bounding box, cell edge, dims) is computed on the device into a
 //     header inside the workspace, so the build needs no host round trip.
-#include "common.h"
+#include "cconv_common.h"  // window_value
 
 namespace dmcf {
 
@@ -210,22 +210,15 @@ __global__ __launch_bounds__(256) void frs_rank_and_place(const float* __restric
     sorted[b + rank] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int32_t)i));
 }
 
-// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queries, int64_t m,
-                                                 const FrsHeader* __restrict__ h,
-                                                 const uint32_t* __restrict__ cell_start,
-                                                 const float4* __restrict__ sorted, float radius, int flags,
-                                                 int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
-                                                 int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
-                                                 int64_t capacity) {
-    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (qi >= m) return;  // whole wave leaves
-    // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
-    // row_splits[m] > capacity and repeats the search with exact buffers)
-    if (WRITE && row_splits[qi + 1] > capacity) return;
+// The candidate scan of one query by one wavefront.  MODE 0: count the hits; MODE 1: write them to the CSR row at
+// out_base; MODE 2: add window(d^2 / R^2) of every hit to `wsum` (per lane; the caller reduces over the wave).
+// Returns the number of hits.  Hits come out in a fixed order (cell rows, then position in the cell-sorted array).
+template <int MODE>
+__device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const FrsHeader* __restrict__ h,
+                                            const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                            float radius, int flags, int64_t out_base, int32_t* __restrict__ nbr_index,
+                                            float* __restrict__ nbr_dist, int window, float inv_r2, float& wsum) {
     const int lane = lane_id();
-    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     const float q[3] = {qx, qy, qz};
     const float r2 = __fmul_rn(radius, radius);
     int lo[3], hi[3];
@@ -241,9 +234,8 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
     int32_t cnt = 0;
     if (!empty) {
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
-        const int64_t out_base = WRITE ? row_splits[qi] : 0;
         const bool ignore = (flags & DMCF_FRS_IGNORE_QUERY_POINT) != 0;
-        // (y,z) rows are taken 64 at a time (9 at most when the cell edge is ~R; more only for coarsened grids)
+        // (y,z) rows are taken 64 at a time (25 at most when the cell edge is ~R/2; more only for coarsened grids)
         for (int row0 = 0; row0 < ny * nz; row0 += kWave) {
             const int r = row0 + lane;
             int32_t start = 0, len = 0;
@@ -285,18 +277,56 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                     pidx = __float_as_int(p.w);
                 }
                 const unsigned long long mask = __ballot(hit);
-                if (WRITE && hit) {
+                if (MODE == 1 && hit) {
                     const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                     const int64_t o = out_base + cnt + before;
                     nbr_index[o] = pidx;
                     if (nbr_dist) nbr_dist[o] = d2;
                 }
+                if (MODE == 2 && hit) wsum += window_value(window, d2, inv_r2, 1.0f);
                 cnt += __popcll(mask);
             }
         }
     }
-    if (!WRITE && lane == 0) counts[qi] = cnt;
+    return cnt;
+}
+
+// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queries, int64_t m,
+                                                 const FrsHeader* __restrict__ h,
+                                                 const uint32_t* __restrict__ cell_start,
+                                                 const float4* __restrict__ sorted, float radius, int flags,
+                                                 int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
+                                                 int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
+                                                 int64_t capacity) {
+    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= m) return;  // whole wave leaves
+    // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
+    // row_splits[m] > capacity and repeats the search with exact buffers)
+    if (WRITE && row_splits[qi + 1] > capacity) return;
+    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    float unused = 0.0f;
+    const int32_t cnt = frs_scan<WRITE ? 1 : 0>(qx, qy, qz, h, cell_start, sorted, radius, flags, WRITE ? row_splits[qi] : 0,
+                                                nbr_index, nbr_dist, 0, 0.0f, unused);
+    if (!WRITE && lane_id() == 0) counts[qi] = cnt;
+}
+
+// compute_density (utils/tools/losses.py:285-306) without the pair list: out[q] = sum over the points within R of
+// window(|x - q|^2 / R^2).  Same candidate scan as the search; nothing but the sums leaves the kernel.
+__global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ queries, int64_t m,
+                                                      const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
+                                                      const float4* __restrict__ sorted, float radius, int flags, int window,
+                                                      float* __restrict__ out) {
+    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= m) return;
+    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    float wsum = 0.0f;
+    frs_scan<2>(qx, qy, qz, h, cell_start, sorted, radius, flags, 0, nullptr, nullptr, window, 1.0f / (radius * radius), wsum);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
+    if (lane_id() == 0) out[qi] = wsum;
 }
 
 }  // namespace dmcf
@@ -389,6 +419,21 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
     const unsigned g = (unsigned)((m + 3) / 4);
     hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
                        flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity);
+    return check_launch();
+}
+
+int dmcf_frs_window_sum(const float* queries, int64_t m, int64_t n, float radius, int flags, int window,
+                        const void* workspace, size_t workspace_bytes, float* out, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || (m > 0 && (!queries || !out))) return DMCF_EINVAL;
+    if (window < DMCF_WINDOW_NONE || window > DMCF_WINDOW_CUBIC_GRAD) return DMCF_EINVAL;
+    if (m == 0) return DMCF_OK;
+    const FrsLayout L = frs_layout(n, m);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    const char* ws = (const char*)workspace;
+    const unsigned g = (unsigned)((m + 3) / 4);
+    hipLaunchKernelGGL(frs_window_sum, dim3(g), dim3(256), 0, stream, queries, m, (const FrsHeader*)(ws + L.off_header),
+                       (const uint32_t*)(ws + L.off_cell_start), (const float4*)(ws + L.off_sorted), radius, flags, window, out);
     return check_launch();
 }
 

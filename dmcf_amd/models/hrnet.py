@@ -66,6 +66,8 @@ class HRNet(PBFNet):
                 inp = []
                 for inp_scale in range(len(ans_convs[-1])):
                     feats = torch.relu(ans_convs[-1][inp_scale])  # :85
+                    if self.dens_norm and dens is not None and inp_scale < len(dens):  # :87-89
+                        feats = torch.cat([feats, feats / dens[inp_scale] ** 2], dim=-1)
                     ext = filter_extent[max(inp_scale, scale)]
                     conv_in = feats if importance == 1.0 else feats * importance
                     ans_conv = self.convs[layer][scale][0][inp_scale](conv_in, pos[inp_scale], pos[scale], ext, None)

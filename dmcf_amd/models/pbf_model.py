@@ -17,8 +17,8 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..utils.convolutions import ContinuousConv
-from ..utils.tools.losses import get_dilated_pos, get_window_func
+from ..utils.convolutions import ContinuousConv, PointSampling
+from ..utils.tools.losses import compute_density, compute_pressure, get_dilated_pos, get_window_func
 from .base_model import BaseModel, Dense
 
 
@@ -48,11 +48,9 @@ class PBFNet(BaseModel):
         super().__init__(name=name, **kwargs)
         if dens_radius is None:
             dens_radius = particle_radii
-        for flag, val in (("dens_feats", dens_feats), ("pres_feats", pres_feats), ("dens_norm", dens_norm),
-                          ("equivar", equivar)):
-            if val:
-                # False in every shipped config; needs compute_density / PointSampling
-                raise NotImplementedError(f"{flag}=True is outside the MI355X hot path (SURVEY.md section 8f rank 3)")
+        if equivar:
+            # False in every shipped config; needs compute_transformed_dx + quaternion features (losses.py:330-364)
+            raise NotImplementedError("equivar=True is not implemented (SURVEY.md section 2 row 14)")
         # NN setup (pbf_model.py:79-97)
         self.kernel_size = kernel_size
         self.channel = channels
@@ -70,6 +68,11 @@ class PBFNet(BaseModel):
         self.sample_hyst = sample_hyst
         # feats setup (pbf_model.py:99-115)
         self.dens_radius = dens_radius
+        self.dens_feats = dens_feats
+        self.pres_feats = pres_feats
+        self.dens_norm = dens_norm
+        self.rest_dens = rest_dens
+        self.stiffness = stiffness
         self.out_scale = [float(v) for v in out_scale]
         self.window_dens = window_dens
         self.use_vel = use_vel
@@ -91,6 +94,8 @@ class PBFNet(BaseModel):
         self.obs_convs = self.get_cconv(name="obs_conv", filters=channels, activation=None,
                                         window_func=self.window, circular=circular)
         self.obs_dense = Dense(units=channels, name="obs_dense")
+        if dens_norm:  # pbf_model.py:177-181
+            self.sampling = PointSampling(name="sampling", window_function=get_window_func(window_dens), normalize=True)
         if self.use_pre_adv:  # pbf_model.py:154-175
             self.adv_convs = torch.nn.ModuleList([
                 self.get_cconv(name="adv_conv0", filters=channels, activation=None, window_func=self.window,
@@ -200,6 +205,18 @@ class PBFNet(BaseModel):
             box_feats.append(bfeats)
         all_pos = torch.cat([pos, box], dim=0)  # :349
         self.all_pos = all_pos
+        dens = None
+        if self.dens_feats or self.dens_norm or self.pres_feats:  # :351-365
+            win = get_window_func(self.window_dens)
+            dens = compute_density(all_pos, all_pos, self.dens_radius[0], win=win)
+            n_fluid = pos.shape[0]
+            if self.dens_feats:
+                fluid_feats.append(dens[:n_fluid].unsqueeze(-1))
+                box_feats.append(dens[n_fluid:].unsqueeze(-1))
+            if self.pres_feats:
+                pres = compute_pressure(all_pos, all_pos, dens, self.rest_dens, win=win, stiffness=self.stiffness)
+                fluid_feats.append(pres[:n_fluid].unsqueeze(-1))
+                box_feats.append(pres[n_fluid:].unsqueeze(-1))
         fluid_feats = torch.cat(fluid_feats, dim=-1)
         box_feats = torch.cat(box_feats, dim=-1)
         self.inp_feats = fluid_feats
@@ -224,8 +241,15 @@ class PBFNet(BaseModel):
         dilated_pos, _, idx = get_dilated_pos(all_pos if self.use_bnds else pos, self.strides,
                                               voxel_size=self.voxel_size, centralize=self.centralize,
                                               pad=self.sample_pad, hyst=self.sample_hyst)  # :413-419
+        if self.dens_norm:  # :421-431
+            dens = [(dens if self.use_bnds else dens[:pos.shape[0]]).unsqueeze(-1)]
+            for scale in range(1, len(self.dens_radius)):
+                d = self.sampling(dens[-1], dilated_pos[scale - 1], dilated_pos[scale], self.dens_radius[scale], None)
+                dens.append(torch.clamp(d, min=1e-2))
+        else:
+            dens = None
         self.dilated_pos = dilated_pos
-        return [dilated_pos, fluid_feats, idx, None]
+        return [dilated_pos, fluid_feats, idx, dens]
 
     def postprocess(self, prev, data, training=True, vel_corr=None, **kwargs):
         pos, vel, acc = data[:3]

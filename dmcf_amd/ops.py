@@ -473,3 +473,24 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
         _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
                                          _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
     return out
+
+
+def window_sum(points, queries, radius, window=None, ignore_query_point=False, hash_table=None):
+    """dmcf_frs_window_sum: out[q] = sum_{|p - q| <= R} window(|p - q|^2 / R^2) (``window``: a WINDOWS key; None counts
+    the neighbours, 'explicit' sums the squared distances).  The fused form of ``compute_density``
+    (utils/tools/losses.py:285-306): the candidate scan of the search with the sum inside, no pair list."""
+    L = _lib.lib()
+    points = _dev_f32(points, "points", 3)
+    queries = _dev_f32(queries, "queries", 3)
+    radius = float(radius)
+    if window not in WINDOWS:
+        raise NotImplementedError(f"window {window!r}")
+    n, m = points.shape[0], queries.shape[0]
+    if hash_table is None or hash_table.n_queries_capacity < m or hash_table.points.data_ptr() != points.data_ptr() \
+            or hash_table.radius != radius:
+        hash_table = build_spatial_hash_table(points, radius, n_queries=m)
+    nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
+    out = torch.empty(m, dtype=torch.float32, device=points.device)
+    _lib.check(L.dmcf_frs_window_sum(_ptr(queries), m, n, radius, 1 if ignore_query_point else 0, WINDOWS[window],
+                                     _ptr(hash_table.workspace), nbytes, _ptr(out), _stream()), "dmcf_frs_window_sum")
+    return out

@@ -374,3 +374,66 @@ class ContinuousConv(torch.nn.Module):
 
     def compute_output_shape(self, inp_features_shape):
         return (None, self.filters)
+
+
+class PointSampling(torch.nn.Module):
+    """Mirror of the reference's ``PointSampling`` (utils/convolutions.py:888-1061): resamples features from one
+    point set to another -- a ContinuousConv with a fixed 1x1x1 identity filter, optional window and
+    normalisation by the summed window values.  Used by ``dens_norm`` to carry the density to the coarse
+    point sets (models/pbf_model.py:177-181, 421-431)."""
+
+    def __init__(self, window_function=None, normalize=True, name=None, **kwargs):
+        super().__init__()
+        self.normalize = normalize
+        self.window_function = window_function
+        self.fixed_radius_search = ops.FixedRadiusSearch(metric="L2", ignore_query_point=False,
+                                                         return_distances=window_function is not None)
+        self.kernel = None
+        self.nns = None
+        self.layer_name = name
+
+    def build(self, in_channels, device=None):  # :925-929
+        self.in_channels = in_channels
+        self.kernel = torch.eye(in_channels, dtype=torch.float32, device=device).reshape(1, 1, 1, in_channels, in_channels)
+
+    def forward(self, inp_features, inp_positions, out_positions, extents, inp_importance=None,
+                fixed_radius_search_hash_table=None, user_neighbors_index=None, user_neighbors_row_splits=None,
+                user_neighbors_importance=None):
+        if self.kernel is None or self.kernel.shape[-1] != inp_features.shape[-1] or self.kernel.device != inp_features.device:
+            self.build(inp_features.shape[-1], inp_features.device)
+        if isinstance(extents, torch.Tensor) and extents.dim() > 0 and extents.numel() != 1:
+            raise NotImplementedError("per-point extents (RadiusSearch, convolutions.py:1006-1010) are not implemented")
+        extent = float(np.float32(float(extents)))
+        window, window_fac, neighbors_value, n_pairs_ref = None, 1.0, None, None
+        if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :984-993
+            neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
+            if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
+                window, neighbors_value = "explicit", user_neighbors_importance
+        else:
+            radius = float(np.float32(0.5) * np.float32(extent))  # :997
+            if fixed_radius_search_hash_table is not None:
+                self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
+                                                    hash_table=fixed_radius_search_hash_table)
+            else:
+                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
+            neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
+            n_pairs_ref = self.nns.total_ref
+            if self.window_function is not None:  # :1015-1019
+                if isinstance(self.window_function, WindowFunction):
+                    window, window_fac, neighbors_value = self.window_function.name, self.window_function.fac, raw_dist
+                else:
+                    q = self.nns.neighbors_distance / (np.float32(radius) * np.float32(radius))
+                    neighbors_index = self.nns.neighbors_index
+                    window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
+        self._n_out_last = out_positions.shape[0]
+        self._pairs_last = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
+        # ml3d.ops.continuous_conv with its defaults (:1038-1052): align_corners=False, ball_to_cube_radial, linear --
+        # irrelevant for a one-cell filter, every neighbour puts all its weight on that cell
+        out = ops.cconv_forward(self.kernel, out_positions, extent, inp_positions, inp_features, neighbors_index,
+                                neighbors_row_splits, neighbors_value=neighbors_value, window=window, window_fac=window_fac,
+                                inp_importance=inp_importance, align_corners=False, coordinate_mapping="ball_to_cube_radial",
+                                interpolation="linear", normalize=self.normalize, n_pairs_ref=n_pairs_ref)
+        self._conv_output = out
+        return out
+
+    call = forward

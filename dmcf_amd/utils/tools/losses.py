@@ -5,8 +5,12 @@
   grid_pos          losses.py:136-181  dilated voxel-corner lattice, de-duplicated (tf.unique order)
   get_dilated_pos   losses.py:249-284  one point set per stride (voxel_size path)
 
-Losses / density helpers (losses.py:47-110, 287-414) are training / validation only and out of
-scope for the inference hot path.
+  compute_density   losses.py:285-306  windowed neighbour sum (fused into the search scan: ops.window_sum)
+  compute_pressure  losses.py:367-377  Tait-style pressure from the density
+  density_loss      losses.py:380-398  validation metric of pipelines/simulator.py:227-243
+
+The training losses (losses.py:47-110, 400-414: Chamfer / EMD / get_loss) need the reference's custom CUDA ops
+and stay out of scope.
 """
 import numpy as np
 import torch
@@ -131,3 +135,40 @@ def get_dilated_pos(pos, strides, voxel_size=None, centralize=False, pad=0, hyst
             dilated_pos.append(grid_pos(pos, v_scale, centralize=centralize, pad=pad, hyst=hyst))
             pcnt.append(dilated_pos[-1].shape[0])
     return dilated_pos, pcnt, idx
+
+
+def compute_density(out_pos, in_pos=None, radius=0.005, win=None):
+    """losses.py:285-306: ``dens[i] = sum_j win(|in_pos[j] - out_pos[i]|^2 / radius^2)`` over the points within
+    ``radius`` (the query point itself included).  ``win``: an object from :func:`get_window_func` (evaluated inside
+    the search kernel, no pair list), None (the reference warns and uses the identity: sum of q), or any callable
+    on a tensor of q values (evaluated with torch on the pair list)."""
+    from ... import ops
+    if in_pos is None:
+        in_pos = out_pos
+    radius = float(radius)
+    if win is None:
+        return ops.window_sum(in_pos, out_pos, radius, "explicit") / (radius * radius)
+    if isinstance(win, WindowFunction):
+        d = ops.window_sum(in_pos, out_pos, radius, win.name)
+        return d if win.fac == 1.0 else d * win.fac
+    nns = ops.fixed_radius_search(in_pos, out_pos, radius, return_distances=True)
+    return ops.reduce_subarrays_sum(win(nns.neighbors_distance / (radius * radius)), nns.neighbors_row_splits)
+
+
+def compute_pressure(out_pts, inp_pts=None, dens=None, rest_dens=3.5, stiffness=20.0, win=None):
+    """losses.py:367-377 (note: the reference ignores a radius here too: compute_density's default applies)."""
+    if inp_pts is None:
+        inp_pts = out_pts
+    if dens is None:
+        dens = compute_density(out_pts, inp_pts, win=win)
+    return torch.relu(stiffness * ((dens / rest_dens) ** 7 - 1))
+
+
+def density_loss(gt, pred, gt_in=None, pred_in=None, radius=0.005, eps=0.01, win=None, use_max=False, **kwargs):
+    """losses.py:380-398."""
+    pred_dens = compute_density(pred, pred_in, radius, win=win)
+    gt_dens = compute_density(gt, gt_in, radius, win=win)
+    rest_dens = gt_dens.max()
+    if use_max:
+        return torch.abs(pred_dens.max() - rest_dens) / rest_dens
+    return torch.relu(pred_dens - rest_dens - eps).mean()

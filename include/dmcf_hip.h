@@ -88,6 +88,14 @@ int dmcf_frs_write(const float* queries, int64_t n_queries, int64_t n_points, fl
                    int32_t* neighbors_index, float* neighbors_distance, int64_t pair_capacity,
                    dmcf_stream_t stream);
 
+/* compute_density (utils/tools/losses.py:285-306; models/pbf_model.py:351-355, pipelines/simulator.py:227-243):
+ *   out[q] = sum over the points p within `radius` of query q of window(|p - q|^2 / radius^2)
+ * evaluated inside the candidate scan of the search -- the pair list is never materialised.  `window` is a
+ * DMCF_WINDOW_* id (DMCF_WINDOW_NONE counts the neighbours, DMCF_WINDOW_EXPLICIT sums the squared distances);
+ * flags as for dmcf_frs_count.  Uses the workspace of dmcf_frs_build(points). */
+int dmcf_frs_window_sum(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags, int window,
+                        const void* workspace, size_t workspace_bytes, float* out, dmcf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Continuous convolution (CConv) and its antisymmetric variant (ASCC).
  * Replaces ml3d.ops.continuous_conv(filters, out_positions, extents[1,1], offset=0, inp_positions,

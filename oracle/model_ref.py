@@ -59,6 +59,13 @@ class ModelRef:
         self.use_acc = c.get("use_acc", True)
         self.use_box_feats = c.get("use_box_feats", True)
         self.use_bnds = c.get("use_bnds", True)
+        self.dens_feats = c.get("dens_feats", False)
+        self.pres_feats = c.get("pres_feats", False)
+        self.dens_norm = c.get("dens_norm", False)
+        self.window_dens = c.get("window_dens")
+        self.dens_radius = c.get("dens_radius") or c.get("particle_radii", [0.05])
+        self.rest_dens = c.get("rest_dens", 3.5)
+        self.stiffness = c.get("stiffness", 20.0)
         self.voxel_size = c.get("voxel_size")
         self.centralize = c.get("centralize", False)
         self.out_scale = np.asarray(c.get("out_scale", [0.01, 0.01, 0.01]), dtype=f32)
@@ -161,6 +168,17 @@ class ModelRef:
             box_feats.append(bfeats)
         all_pos = np.ascontiguousarray(np.concatenate([pos, box], axis=0))
         self.all_pos = all_pos
+        dens = None
+        if self.dens_feats or self.dens_norm or self.pres_feats:  # pbf_model.py:351-365
+            dens = O.compute_density(all_pos, all_pos, self.dens_radius[0], self.window_dens)
+            n = pos.shape[0]
+            if self.dens_feats:
+                fluid_feats.append(dens[:n, None])
+                box_feats.append(dens[n:, None])
+            if self.pres_feats:
+                pres = O.compute_pressure(dens, self.rest_dens, self.stiffness)
+                fluid_feats.append(pres[:n, None])
+                box_feats.append(pres[n:, None])
         fluid_feats = np.concatenate(fluid_feats, axis=-1).astype(f32)
         box_feats = np.concatenate(box_feats, axis=-1).astype(f32)
         # get_cconv (pbf_model.py:208-209): ignore_query_points=None -> the model-level flag, also for the input convs
@@ -182,6 +200,13 @@ class ModelRef:
             dilated = [base for _ in self.strides]
         dilated = [np.ascontiguousarray(d) for d in dilated]
         dilated[0] = base  # keep identity for the neighbour cache
+        self.dens = None
+        if self.dens_norm:  # pbf_model.py:421-431
+            self.dens = [(dens if self.use_bnds else dens[:pos.shape[0]])[:, None].astype(f32)]
+            for scale in range(1, len(self.dens_radius)):
+                d = O.point_sampling(self.dens[-1], dilated[scale - 1], dilated[scale], self.dens_radius[scale],
+                                     self.window_dens, normalize=True, f64=self.f64)
+                self.dens.append(np.maximum(d, f32(1e-2)).astype(f32))
         self._conv_count = 2
         return dilated, feats_out
 
@@ -199,6 +224,8 @@ class ModelRef:
                 inp = []
                 for inp_scale in range(len(ans_convs[-1])):
                     f = _relu(ans_convs[-1][inp_scale])
+                    if self.dens_norm and self.dens is not None and inp_scale < len(self.dens):  # hrnet.py:87-89
+                        f = np.concatenate([f, f / self.dens[inp_scale] ** 2], axis=-1).astype(f32)
                     ext = filter_extent[max(inp_scale, scale)]
                     index = self._conv_count
                     self._conv_count += 1

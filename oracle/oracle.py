@@ -303,3 +303,44 @@ def get_dilated_pos(pos, strides, voxel_size, centralize=False, pad=0, hyst=0.1)
         else:
             out.append(grid_pos(pos, _f32(voxel_size) * np.float32(stride), centralize, pad, hyst))
     return out
+
+
+def compute_density(out_pos, in_pos=None, radius=0.005, win=None):
+    """Restates losses.py:285-306: sum over the points within ``radius`` of win(|in - out|^2 / radius^2)
+    (win = a window name, or None = identity as in the reference's warning branch)."""
+    out_pos = _f32(out_pos)
+    in_pos = out_pos if in_pos is None else _f32(in_pos)
+    idx, rs, _ = fixed_radius_search(in_pos, out_pos, radius)
+    seg = np.repeat(np.arange(out_pos.shape[0]), np.diff(rs))
+    diff = in_pos[idx] - out_pos[seg]
+    q = ((diff ** 2).sum(axis=-1) / np.float32(radius) ** 2).astype(np.float32)
+    w = q if win is None else window(win, q)
+    return np.bincount(seg, weights=w.astype(np.float64), minlength=out_pos.shape[0]).astype(np.float32)
+
+
+def compute_pressure(dens, rest_dens=3.5, stiffness=20.0):
+    """losses.py:367-377 for a given density."""
+    d = np.asarray(dens, dtype=np.float64)
+    return np.maximum(stiffness * ((d / rest_dens) ** 7 - 1), 0).astype(np.float32)
+
+
+def density_loss(gt, pred, gt_in=None, pred_in=None, radius=0.005, eps=0.01, win=None, use_max=False):
+    """losses.py:380-398."""
+    pred_dens = compute_density(pred, pred_in, radius, win)
+    gt_dens = compute_density(gt, gt_in, radius, win)
+    rest = gt_dens.max()
+    if use_max:
+        return np.float32(abs(pred_dens.max() - rest) / rest)
+    return np.float32(np.maximum(pred_dens - rest - eps, 0).mean())
+
+
+def point_sampling(feats, inp_pos, out_pos, extent, win=None, normalize=True, f64=False):
+    """Restates PointSampling.call (convolutions.py:888-1061): continuous_conv with a 1x1x1 identity filter."""
+    feats = _f32(feats)
+    c = feats.shape[-1]
+    radius = np.float32(0.5) * np.float32(extent)
+    idx, rs, d = fixed_radius_search(_f32(inp_pos), _f32(out_pos), radius)
+    imp = None if win is None else window(win, d / (radius * radius))
+    k = np.eye(c, dtype=np.float32).reshape(1, 1, 1, c, c)
+    return continuous_conv(k, _f32(out_pos), extent, _f32(inp_pos), feats, idx, rs, imp, align_corners=False,
+                           coordinate_mapping="ball_to_cube_radial", interpolation="linear", normalize=normalize, f64=f64)

@@ -49,6 +49,14 @@ def install(monkeypatch):
             return out
         return y
 
+    def window_sum(points, queries, radius, window=None, ignore_query_point=False, hash_table=None):
+        idx, rs, d = O.fixed_radius_search(points.numpy(), queries.numpy(), radius, ignore_query_point)
+        q = d / (np.float32(radius) * np.float32(radius))
+        w = np.ones_like(q) if window is None else (d if window == "explicit" else O.window(window, q))
+        seg = np.repeat(np.arange(queries.shape[0]), np.diff(rs))
+        return torch.from_numpy(np.bincount(seg, weights=w.astype(np.float64), minlength=queries.shape[0]).astype(np.float32))
+
+    monkeypatch.setattr(ops, "window_sum", window_sum)
     monkeypatch.setattr(ops, "fixed_radius_search", fixed_radius_search)
     monkeypatch.setattr(ops, "build_spatial_hash_table", build_spatial_hash_table)
     monkeypatch.setattr(ops, "cconv_forward", cconv_forward)

@@ -165,3 +165,14 @@ def test_estimated_neighbour_buffers_recover_from_overflow(dev):
     neighbor_hints().clear()
     b = fresh.step([big])[0]
     assert torch.equal(a[0], b[0])
+
+
+def test_density_feature_flags_2d(dev):
+    """dens_feats + pres_feats + dens_norm (pbf_model.py:351-365,421-431; hrnet.py:87-89) on the WaterRamps
+    architecture: fused density kernel, PointSampling to the coarse scales, doubled layer inputs."""
+    from tools import configs, scenes
+    cfg = dict(configs.WATERRAMPS, dens_feats=True, pres_feats=True, dens_norm=True, window_dens="poly6", rest_dens=12.0)
+    w = scenes.random_weights(cfg, seed=4)
+    scene = scenes.box_scene(36, h=0.005, dim=2, origin=(-0.09, -0.09, 0.0))
+    model, ref = _compare_step(cfg, w, scene, dev, steps=2)
+    assert ref.dens is not None

@@ -492,3 +492,46 @@ def test_estimated_search_equals_exact(dev, n, m, radius, ignore):
         assert torch.equal(a.neighbors_index, c.neighbors_index) and torch.equal(a.neighbors_distance, c.neighbors_distance)
     e = ops.fixed_radius_search(pts, qs[:0], radius, return_distances=True, capacity_hint=10)
     assert e.neighbors_row_splits.tolist() == [0] and e.neighbors_index.shape[0] == 0
+
+
+@pytest.mark.parametrize("win", ["poly6", "cubic", "peak", "linear", None, "callable"])
+def test_compute_density_matches_oracle(oracle, dev, win):
+    """compute_density (losses.py:285-306): the fused search + window sum (dmcf_frs_window_sum) for the named windows and
+    the identity branch, the pair-list path for arbitrary callables."""
+    from dmcf_amd.utils.tools.losses import compute_density, compute_pressure, density_loss, get_window_func
+    rng = np.random.default_rng(2)
+    inp = _cloud(6000, 12)
+    out = _cloud(1500, 13)
+    radius = 0.25
+    if win == "callable":
+        d = compute_density(_t(out, dev), _t(inp, dev), radius, win=lambda q: torch.clamp((1 - q) ** 3, 0, 1)).cpu().numpy()
+        ref = oracle.compute_density(out, inp, radius, "poly6")
+    else:
+        d = compute_density(_t(out, dev), _t(inp, dev), radius, win=get_window_func(win)).cpu().numpy()
+        ref = oracle.compute_density(out, inp, radius, win)
+    np.testing.assert_allclose(d, ref, rtol=2e-5, atol=2e-5 * np.abs(ref).max())
+    if win == "poly6":
+        # self density (in_pos=None), pressure and the validation metric (simulator.py:227-243)
+        w = get_window_func("poly6")
+        ds = compute_density(_t(inp, dev), None, radius, win=w)
+        np.testing.assert_allclose(ds.cpu().numpy(), oracle.compute_density(inp, None, radius, "poly6"), rtol=2e-5)
+        p = compute_pressure(_t(inp, dev), dens=ds, rest_dens=float(ds.mean()), stiffness=20.0).cpu().numpy()
+        np.testing.assert_allclose(p, oracle.compute_pressure(ds.cpu().numpy(), float(ds.mean()), 20.0), rtol=1e-4, atol=1e-4)
+        moved = inp + rng.normal(0, 0.02, size=inp.shape).astype(np.float32)
+        for use_max in (False, True):
+            a = density_loss(_t(inp, dev), _t(moved, dev), radius=radius, win=w, use_max=use_max).item()
+            b = oracle.density_loss(inp, moved, radius=radius, win="poly6", use_max=use_max)
+            assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3)
+
+
+@pytest.mark.parametrize("win,normalize", [("poly6", True), (None, True), ("poly6", False)])
+def test_point_sampling_matches_oracle(oracle, dev, win, normalize):
+    from dmcf_amd.utils.convolutions import PointSampling
+    from dmcf_amd.utils.tools.losses import get_window_func
+    rng = np.random.default_rng(3)
+    inp, out = _cloud(4000, 21), _cloud(900, 22)
+    feats = rng.uniform(0.5, 2.0, size=(4000, 3)).astype(np.float32)
+    layer = PointSampling(window_function=get_window_func(win), normalize=normalize)
+    y = layer(_t(feats, dev), _t(inp, dev), _t(out, dev), 0.5, None).cpu().numpy()
+    ref = oracle.point_sampling(feats, inp, out, 0.5, win, normalize=normalize, f64=True)
+    _close(y, ref, 2e-5)

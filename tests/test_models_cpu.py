@@ -100,3 +100,29 @@ def test_grid_pos_matches_oracle(oracle):
         np.testing.assert_allclose(g, ref, atol=2e-6)
     d, cnt, idx = get_dilated_pos(torch.from_numpy(pos), [1, 2, 4], voxel_size=[0.05, 0.05, 0.05], centralize=True)
     assert cnt[0] == 3000 and cnt[1] > cnt[2] and idx == [None]
+
+
+def test_density_feature_flags_host_logic(oracle, monkeypatch):
+    """dens_feats / pres_feats / dens_norm (models/pbf_model.py:351-365,421-431; models/hrnet.py:87-89) wired the way
+    the reference wires them: the model on CPU tensors with the operators routed through the oracle (tests/shims.py)
+    equals the numpy restatement of the model."""
+    import torch
+    import shims
+    from oracle.model_ref import ModelRef
+    from dmcf_amd import models
+    from dmcf_amd.utils import tf_checkpoint as tc
+    from tools import configs, scenes
+    shims.install(monkeypatch)
+    cfg = dict(configs.WATERRAMPS, dens_feats=True, pres_feats=True, dens_norm=True, window_dens="poly6", rest_dens=12.0)
+    w = scenes.random_weights(cfg, seed=4)
+    scene = scenes.box_scene(14, h=0.005, dim=2, origin=(-0.03, -0.03, 0.0))
+    model = getattr(models, cfg["name"])(**cfg)
+    tc.load_into_model(model, w, device="cpu")
+    ref = ModelRef(cfg, w)
+    data_np = scenes.model_inputs(scene)
+    data_t = scenes.model_inputs(scene, device="cpu")
+    pos_ref, vel_ref = ref.step(data_np)
+    pos, vel = model(data_t, training=False)[:2]
+    assert np.abs(pos.numpy() - pos_ref).max() <= 1e-6 * np.abs(pos_ref).max()
+    assert np.abs(model.pos_correction.numpy() - ref.pos_correction).max() <= 1e-4 * np.abs(ref.pos_correction).max()
+    assert ref.dens is not None and len(ref.dens) == len(cfg["particle_radii"])

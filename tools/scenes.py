@@ -74,8 +74,11 @@ def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
         w[key + "/kernel"] = rng.uniform(-0.3, 0.3, size=(cin, cout)).astype(np.float32)
         w[key + "/bias"] = rng.uniform(lo, hi, size=(cout,)).astype(np.float32)
 
-    n_fluid = fluid_channels or (1 + (3 if c.get("use_vel", True) else 0) + (3 if c.get("use_acc", True) else 0))
-    n_box = 1 + (3 if c.get("use_box_feats", True) else 0)
+    extra = (1 if c.get("dens_feats") else 0) + (1 if c.get("pres_feats") else 0)  # pbf_model.py:356-365
+    n_fluid = (fluid_channels or (1 + (3 if c.get("use_vel", True) else 0) + (3 if c.get("use_acc", True) else 0))) + extra
+    n_box = 1 + (3 if c.get("use_box_feats", True) else 0) + extra
+    # dens_norm doubles the input of every layer that reads a scale with a density (hrnet.py:87-89)
+    n_dens = len(c.get("dens_radius") or c.get("particle_radii", [0.05])) if c.get("dens_norm") else 0
     if name == "CConv":
         ch0 = lc[0]
         conv("model/fluid_convs", n_fluid, ch0)
@@ -101,10 +104,11 @@ def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
         for j in range(len(trunk[i])):
             ch = trunk[i][j][0]
             for l in range(len(prev)):
-                conv(f"model/_all_convs/{idx}/1", prev[l], ch)
+                cin_l = prev[l] * (2 if l < n_dens else 1)
+                conv(f"model/_all_convs/{idx}/1", cin_l, ch)
                 idx += 1
                 if l == j:
-                    dense(f"model/denses/{i - 1}/{j}/0/{l}", prev[l], ch)
+                    dense(f"model/denses/{i - 1}/{j}/0/{l}", cin_l, ch)
             cur.append(ch)
         prev = cur
     if name == "SymNet":
