@@ -176,3 +176,35 @@ def test_density_feature_flags_2d(dev):
     scene = scenes.box_scene(36, h=0.005, dim=2, origin=(-0.09, -0.09, 0.0))
     model, ref = _compare_step(cfg, w, scene, dev, steps=2)
     assert ref.dens is not None
+
+
+def test_canyon_sample_with_inflow(dev):
+    """The reference's demo (run_sample.py: canyon scene, Liquid3d checkpoint, inflow every other step) on frames of the
+    reference's own scene file (tests/golden/canyon_crop.msgpack.zst): every step of dmcf_amd.run_sample.run_rollout
+    against the oracle model fed with the same state."""
+    from oracle.model_ref import ModelRef
+    from dmcf_amd.datasets import read_scene
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.run_sample import INFLOW_VELOCITY, run_rollout
+    from tools import configs
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    frame0 = read_scene(os.path.join(GOLDEN, "canyon_crop.msgpack.zst"))[0]
+    model = _build(configs.LIQUID3D, w, dev)
+    sim = Simulator(model, device="cuda")
+    results, timing = run_rollout(sim, frame0, timesteps=6, inflow=4)
+    assert [r.shape[0] for r in results] == [1280, 1280, 1280, 2560, 2560, 3840] and len(timing) == 5
+    ref = ModelRef(configs.LIQUID3D, w)
+    in_pos = frame0["pos"]
+    in_vel = (frame0["vel"] + np.float32([INFLOW_VELOCITY])).astype(np.float32)
+    in_acc = np.zeros_like(in_pos) + np.float32([[0, configs.LIQUID3D.get("grav", -9.81), 0]])
+    data = [in_pos, in_vel, in_acc, None, frame0["box"], frame0["box_normals"]]
+    for t in range(5):
+        # oracle step from the HIP path's own previous state: per-step parity, no error accumulation
+        pos_ref, vel_ref = ref.step(data)
+        got = results[t + 1].cpu().numpy()
+        assert got.shape == pos_ref.shape
+        assert _rel(got, pos_ref) <= 1e-5, f"step {t}: {_rel(got, pos_ref):.2e}"
+        data = [got, vel_ref] + data[2:]
+        if 4 > t and t % 2 == 1:
+            data = [np.concatenate([data[0], in_pos]), np.concatenate([data[1], in_vel]), np.concatenate([data[2], in_acc]),
+                    None, data[4], data[5]]

@@ -126,3 +126,39 @@ def test_density_feature_flags_host_logic(oracle, monkeypatch):
     assert np.abs(pos.numpy() - pos_ref).max() <= 1e-6 * np.abs(pos_ref).max()
     assert np.abs(model.pos_correction.numpy() - ref.pos_correction).max() <= 1e-4 * np.abs(ref.pos_correction).max()
     assert ref.dens is not None and len(ref.dens) == len(cfg["particle_radii"])
+
+
+def test_scene_file_io_roundtrip_and_reference_fixture(tmp_path):
+    """datasets: the reference's scene format (zstd frame > msgpack list of frame dicts > msgpack-numpy arrays).
+    tests/golden/canyon_crop.msgpack.zst holds frames of the reference's own canyon scene (make_fixtures.py)."""
+    from dmcf_amd.datasets import Dataset, get_rollout, read_scene, write_results, write_results_npz, write_scene
+    frames = read_scene(os.path.join(ROOT, "tests", "golden", "canyon_crop.msgpack.zst"))
+    assert len(frames) == 3 and frames[0]["pos"].shape == (1280, 3) and frames[0]["pos"].dtype == np.float32
+    assert frames[0]["box"].shape == (10006, 3) and frames[0]["box_normals"].shape == (10006, 3)
+    assert "box" not in frames[1] and int(frames[2]["frame_id"]) == 2 and frames[0]["scene_id"] == "sim_canyon"
+    np.testing.assert_allclose(np.linalg.norm(frames[0]["box_normals"], axis=1), 1.0, atol=1e-4)
+    # write -> read round trip, bit exact, scalars and strings included
+    p = str(tmp_path / "a.msgpack.zst")
+    write_scene(p, frames, level=3)
+    again = read_scene(p)
+    for a, b in zip(frames, again):
+        assert a.keys() == b.keys()
+        for k in a:
+            assert np.array_equal(a[k], b[k]) and type(a[k]) is type(b[k])
+    # directory data set + get_rollout (dataset_reader_physics.py:410-456) with the input transform
+    ds = Dataset(dataset_path=str(tmp_path))
+    assert len(ds) == 1
+    r = get_rollout(ds, translate=[0.5, 0.0, 0.0], scale=[1.0, 1.0, 1.0])[0]
+    assert r["pos"].shape == (3, 1280, 3) and r["box"].shape == (3, 10006, 3) and list(r["frame_id"]) == [0, 1, 2]
+    np.testing.assert_array_equal(r["pos"][1], frames[1]["pos"] + np.float32([0.5, 0, 0]))
+    assert get_rollout(ds, time_start=1, time_end=2)[0]["pos"].shape[0] == 1
+    # result writers: npz always, HDF5 only with h5py (absent here: a clear error, no silent substitute)
+    out = [(r["pos"], {"name": "pred", "type": "PARTICLE"}), (frames[0]["box"], {"name": "bnd", "type": "PARTICLE"})]
+    write_results_npz(str(tmp_path / "r.npz"), "SymNet", out)
+    z = np.load(str(tmp_path / "r.npz"))
+    assert z["SymNet/pred"].shape == (3, 1280, 3) and str(z["SymNet/bnd.type"]) == "PARTICLE"
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError):
+            write_results(str(tmp_path / "r.hdf5"), "SymNet", out)
