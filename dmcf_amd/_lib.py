@@ -49,6 +49,7 @@ SYMBOLS = [
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_window_sum",
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
     "dmcf_reduce_subarrays_sum",
+    "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
     "dmcf_grid_pos_workspace_bytes", "dmcf_grid_pos_bounds", "dmcf_grid_pos_count", "dmcf_grid_pos_write",
 ]
 
@@ -100,6 +101,12 @@ def lib():
     L.dmcf_cconv_geometry.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_reduce_subarrays_sum.restype = c.c_int
     L.dmcf_reduce_subarrays_sum.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    L.dmcf_fps_workspace_bytes.restype = c.c_size_t
+    L.dmcf_fps_workspace_bytes.argtypes = [c.c_int64]
+    L.dmcf_farthest_point_sample.restype = c.c_int
+    L.dmcf_farthest_point_sample.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_size_t, c.c_void_p, c.c_void_p]
+    L.dmcf_gather_point.restype = c.c_int
+    L.dmcf_gather_point.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int, c.c_void_p, c.c_void_p]
     L.dmcf_grid_pos_workspace_bytes.restype = c.c_size_t
     L.dmcf_grid_pos_workspace_bytes.argtypes = [c.c_int64]
     f3 = c.POINTER(c.c_float)

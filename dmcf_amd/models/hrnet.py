@@ -76,9 +76,16 @@ class HRNet(PBFNet):
                             ans_conv = ans_conv + self.denses[layer][scale][0][inp_scale](feats)
                             if ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:
                                 ans_conv = ans_conv + ans_convs[-1][scale]
-                        elif self.voxel_size is None:
-                            raise NotImplementedError("cross-scale Dense branch (hrnet.py:100-113) needs the FPS "
-                                                      "index lists of voxel_size=None configs; out of scope")
+                        elif self.voxel_size is None:  # :100-113: Dense across scales through the FPS index lists
+                            if scale > inp_scale:
+                                for i in range(inp_scale, scale):
+                                    feats = feats[idx[i + 1][0].long()]
+                                ans_conv = ans_conv + self.denses[layer][scale][0][inp_scale](feats)
+                            else:
+                                ind = idx[scale + 1][0].long()
+                                for i in range(scale + 1, inp_scale):
+                                    ind = ind[idx[i + 1][0].long()]
+                                ans_conv = ans_conv.index_add(0, ind, self.denses[layer][scale][0][inp_scale](feats))
                     inp.append(ans_conv)
                 if self.add_merge:  # :115-118
                     merged = inp[0]

@@ -494,3 +494,35 @@ def window_sum(points, queries, radius, window=None, ignore_query_point=False, h
     _lib.check(L.dmcf_frs_window_sum(_ptr(queries), m, n, radius, 1 if ignore_query_point else 0, WINDOWS[window],
                                      _ptr(hash_table.workspace), nbytes, _ptr(out), _stream()), "dmcf_frs_window_sum")
     return out
+
+
+def farthest_point_sample(npoint, inp):
+    """Mirror of ``utils/tools/sampling.py: farthest_point_sample(npoint, inp)``: ``inp`` [1, n, 3] -> int32 [1, npoint]
+    (dmcf_farthest_point_sample; the batch dimension of this path is always 1, utils/tools/losses.py:278-279)."""
+    L = _lib.lib()
+    if inp.dim() != 3 or inp.shape[0] != 1 or inp.shape[2] != 3:
+        raise ValueError("farthest_point_sample expects a [1, n, 3] tensor")
+    pts = _dev_f32(inp[0], "inp", 3)
+    n, m = pts.shape[0], int(npoint)
+    if m > 0 and n == 0:
+        raise ValueError("cannot sample from an empty point set")
+    nbytes = L.dmcf_fps_workspace_bytes(n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pts.device)
+    idx = torch.empty(m, dtype=torch.int32, device=pts.device)
+    _lib.check(L.dmcf_farthest_point_sample(_ptr(pts), n, m, _ptr(ws), nbytes, _ptr(idx), _stream()),
+               "dmcf_farthest_point_sample")
+    return idx.unsqueeze(0)
+
+
+def gather_point(inp, idx):
+    """Mirror of ``gather_point(inp [1, n, c], idx [1, m]) -> [1, m, c]`` (utils/tools/sampling.py)."""
+    L = _lib.lib()
+    if inp.dim() != 3 or inp.shape[0] != 1 or idx.dim() != 2 or idx.shape[0] != 1:
+        raise ValueError("gather_point expects inp [1, n, c] and idx [1, m]")
+    x = _dev_f32(inp[0], "inp")
+    if idx.dtype != torch.int32 or not idx.is_cuda:
+        raise TypeError("idx must be an int32 GPU tensor")
+    ii = idx[0].contiguous()
+    out = torch.empty((ii.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
+    _lib.check(L.dmcf_gather_point(_ptr(x), _ptr(ii), ii.shape[0], x.shape[1], _ptr(out), _stream()), "dmcf_gather_point")
+    return out.unsqueeze(0)

@@ -3,7 +3,7 @@
 
   get_window_func   losses.py:8-44     poly6 / cubic / linear / peak / cubic_grad on q = d^2/R^2
   grid_pos          losses.py:136-181  dilated voxel-corner lattice, de-duplicated (tf.unique order)
-  get_dilated_pos   losses.py:249-284  one point set per stride (voxel_size path)
+  get_dilated_pos   losses.py:249-284  one point set per stride (lattice with voxel_size, farthest point sampling without)
 
   compute_density   losses.py:285-306  windowed neighbour sum (fused into the search scan: ops.window_sum)
   compute_pressure  losses.py:367-377  Tait-style pressure from the density
@@ -117,23 +117,27 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
 
 
 def get_dilated_pos(pos, strides, voxel_size=None, centralize=False, pad=0, hyst=0.1):
-    """losses.py:249-284 -> (dilated_pos, pcnt, idx).  Every coarse level is computed from the
-    full-resolution set (:268).  The farthest-point-sampling branch (voxel_size is None, :274-282) needs
-    the reference's FPS custom op and is not on the path of any shipped multi-scale config."""
+    """losses.py:249-284 -> (dilated_pos, pcnt, idx).  With ``voxel_size`` every coarse level is a lattice computed from
+    the full-resolution set (:266-272; no entry is appended to ``idx`` on that branch, as in the reference); without it
+    level k is ``n // stride`` farthest-point samples of level k-1 (:274-282) and ``idx[k]`` the [1, m] sample indices
+    HRNet's cross-scale Dense branch uses."""
+    from ... import ops
     pcnt, dilated_pos, idx = [], [], []
     for stride in strides:
         if stride == 1:
             pcnt.append(pos.shape[0])
             dilated_pos.append(pos)
             idx.append(None)
-        else:
-            if voxel_size is None:
-                raise NotImplementedError("strides > 1 without voxel_size need farthest point sampling "
-                                          "(utils/tools/sampling.cu), which is out of scope (SURVEY.md section 8f rank 4)")
+        elif voxel_size is not None:
             vs = voxel_size.detach().cpu().numpy() if isinstance(voxel_size, torch.Tensor) else voxel_size
             v_scale = np.asarray(vs, dtype=np.float32) * np.float32(stride)  # :266
             dilated_pos.append(grid_pos(pos, v_scale, centralize=centralize, pad=pad, hyst=hyst))
             pcnt.append(dilated_pos[-1].shape[0])
+        else:
+            sample_cnt = max(pos.shape[0] // stride, 1)  # :275
+            pcnt.append(sample_cnt)
+            idx.append(ops.farthest_point_sample(sample_cnt, dilated_pos[-1].unsqueeze(0)))
+            dilated_pos.append(ops.gather_point(dilated_pos[-1].unsqueeze(0), idx[-1])[0])
     return dilated_pos, pcnt, idx
 
 

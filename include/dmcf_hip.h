@@ -14,6 +14,7 @@
  *   ml3d.ops.continuous_conv (utils/convolutions.py:414-431)     dmcf_cconv_forward
  *   ASCC: mirror :410-412 + second continuous_conv :433-458      dmcf_cconv_forward(DMCF_FLAG_SYMMETRIC)
  *   o3dml.ops.reduce_subarrays_sum (models/pbf_model.py:450-453) dmcf_reduce_subarrays_sum
+ *   farthest_point_sample / gather_point (utils/tools/sampling.cu) dmcf_farthest_point_sample / dmcf_gather_point
  *   grid_pos: candidate cells + tf.unique + decode               dmcf_grid_pos_bounds / _count / _write
  *     (utils/tools/losses.py:136-181, called from :266-272)
  *
@@ -210,6 +211,20 @@ int dmcf_grid_pos_count(const float* positions, int64_t n_points, const float* v
 int dmcf_grid_pos_write(const float* positions, int64_t n_points, const float* voxel_size, int centralize, int pad,
                         float hyst, void* workspace, size_t workspace_bytes, const void* cell_table, int64_t table_cells,
                         float* out, int64_t out_capacity, dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * farthest_point_sample(npoint, inp[1,n,3]) and gather_point(inp, idx) (utils/tools/sampling.py / sampling.cu:125-201):
+ * the sub-sampling of get_dilated_pos for multi-scale configs without voxel_size (utils/tools/losses.py:274-282) and
+ * the index lists of HRNet's cross-scale Dense branch (models/hrnet.py:100-113).  One point set per call (the
+ * reference's batch dimension is always 1 on this path).  sample_index[0] = 0; sample j maximises the float32
+ * squared distance to samples 0..j-1; equal maxima resolve as in the reference's 512-thread kernel (smallest
+ * index mod 512, then smallest index).  Sequential in the samples by definition: O(n_points * n_samples).
+ * ---------------------------------------------------------------------------------------------- */
+size_t dmcf_fps_workspace_bytes(int64_t n_points);
+int dmcf_farthest_point_sample(const float* points, int64_t n_points, int64_t n_samples, void* workspace,
+                               size_t workspace_bytes, int32_t* sample_index, dmcf_stream_t stream);
+int dmcf_gather_point(const float* inp, const int32_t* index, int64_t n_index, int channels, float* out,
+                      dmcf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -196,8 +196,7 @@ class ModelRef:
             dilated = O.get_dilated_pos(base, self.strides, self.voxel_size, self.centralize, self.sample_pad,
                                         self.sample_hyst)
         else:
-            assert all(s == 1 for s in self.strides)
-            dilated = [base for _ in self.strides]
+            dilated, self.fps_idx = O.get_dilated_pos_fps(base, self.strides)  # losses.py:274-282
         dilated = [np.ascontiguousarray(d) for d in dilated]
         dilated[0] = base  # keep identity for the neighbour cache
         self.dens = None
@@ -236,6 +235,19 @@ class ModelRef:
                         ans_conv = ans_conv + self._dense(f"model/denses/{layer}/{scale}/0/{inp_scale}", f)
                         if ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:
                             ans_conv = ans_conv + ans_convs[-1][scale]
+                    elif self.voxel_size is None:  # hrnet.py:100-113
+                        idx = self.fps_idx
+                        if scale > inp_scale:
+                            g = f
+                            for s_ in range(inp_scale, scale):
+                                g = g[idx[s_ + 1]]
+                            ans_conv = ans_conv + self._dense(f"model/denses/{layer}/{scale}/0/{inp_scale}", g)
+                        else:
+                            ind = idx[scale + 1]
+                            for s_ in range(scale + 1, inp_scale):
+                                ind = ind[idx[s_ + 1]]
+                            ans_conv = ans_conv.copy()
+                            np.add.at(ans_conv, ind, self._dense(f"model/denses/{layer}/{scale}/0/{inp_scale}", f))
                     inp.append(ans_conv.astype(f32))
                 if self.add_merge:
                     m = inp[0]

@@ -344,3 +344,42 @@ def point_sampling(feats, inp_pos, out_pos, extent, win=None, normalize=True, f6
     k = np.eye(c, dtype=np.float32).reshape(1, 1, 1, c, c)
     return continuous_conv(k, _f32(out_pos), extent, _f32(inp_pos), feats, idx, rs, imp, align_corners=False,
                            coordinate_mapping="ball_to_cube_radial", interpolation="linear", normalize=normalize, f64=f64)
+
+
+def farthest_point_sample(npoint, pts):
+    """Restates farthestpointsamplingKernel (utils/tools/sampling.cu:125-182) for one point set: sample 0 = point 0,
+    float32 squared distances (dx*dx + dy*dy) + dz*dz, running minimum, arg-max with the kernel's tie order
+    (512 threads striding the points, first strict maximum per thread, tree reduction that keeps the lower slot):
+    smallest (index mod 512), then smallest index."""
+    pts = _f32(pts).reshape(-1, 3)
+    n = pts.shape[0]
+    idx = np.zeros(int(npoint), dtype=np.int32)
+    temp = np.full(n, np.float32(1e38), dtype=np.float32)
+    k = np.arange(n)
+    order = np.lexsort((k, k & 511))  # candidates in tie-preference order
+    old = 0
+    for j in range(1, int(npoint)):
+        d = pts - pts[old]
+        d2 = ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) + d[:, 2] * d[:, 2]).astype(np.float32)
+        temp = np.minimum(temp, d2)
+        best = temp.max()
+        cand = order[temp[order] == best]
+        old = int(cand[0])
+        idx[j] = old
+    return idx
+
+
+def get_dilated_pos_fps(pos, strides):
+    """losses.py:274-282 (voxel_size is None): level k = n // stride farthest-point samples of level k-1.
+    Returns (dilated_pos, idx) with idx[0] = None."""
+    pos = _f32(pos)
+    out, idx = [], []
+    for stride in strides:
+        if stride == 1:
+            out.append(pos)
+            idx.append(None)
+        else:
+            cnt = max(pos.shape[0] // stride, 1)
+            idx.append(farthest_point_sample(cnt, out[-1]))
+            out.append(np.ascontiguousarray(out[-1][idx[-1]]))
+    return out, idx

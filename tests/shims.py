@@ -56,6 +56,14 @@ def install(monkeypatch):
         seg = np.repeat(np.arange(queries.shape[0]), np.diff(rs))
         return torch.from_numpy(np.bincount(seg, weights=w.astype(np.float64), minlength=queries.shape[0]).astype(np.float32))
 
+    def farthest_point_sample(npoint, inp):
+        return torch.from_numpy(O.farthest_point_sample(npoint, inp[0].numpy())).unsqueeze(0)
+
+    def gather_point(inp, idx):
+        return inp[:, idx[0].long()]
+
+    monkeypatch.setattr(ops, "farthest_point_sample", farthest_point_sample)
+    monkeypatch.setattr(ops, "gather_point", gather_point)
     monkeypatch.setattr(ops, "window_sum", window_sum)
     monkeypatch.setattr(ops, "fixed_radius_search", fixed_radius_search)
     monkeypatch.setattr(ops, "build_spatial_hash_table", build_spatial_hash_table)

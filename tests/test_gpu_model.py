@@ -208,3 +208,14 @@ def test_canyon_sample_with_inflow(dev):
         if 4 > t and t % 2 == 1:
             data = [np.concatenate([data[0], in_pos]), np.concatenate([data[1], in_vel]), np.concatenate([data[2], in_acc]),
                     None, data[4], data[5]]
+
+
+def test_fps_multiscale_2d(dev):
+    """voxel_size: None: farthest-point-sampled scales (losses.py:274-282) and HRNet's cross-scale Dense branch
+    (hrnet.py:100-113) on the WaterRamps architecture."""
+    from tools import configs, scenes
+    cfg = dict(configs.WATERRAMPS, voxel_size=None, centralize=False)
+    w = scenes.random_weights(cfg, seed=6)
+    scene = scenes.box_scene(30, h=0.005, dim=2, origin=(-0.07, -0.07, 0.0))
+    model, ref = _compare_step(cfg, w, scene, dev, steps=2)
+    assert [len(i) for i in ref.fps_idx[1:]] == [len(model.all_pos) // 2, len(model.all_pos) // 4]

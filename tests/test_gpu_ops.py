@@ -535,3 +535,32 @@ def test_point_sampling_matches_oracle(oracle, dev, win, normalize):
     y = layer(_t(feats, dev), _t(inp, dev), _t(out, dev), 0.5, None).cpu().numpy()
     ref = oracle.point_sampling(feats, inp, out, 0.5, win, normalize=normalize, f64=True)
     _close(y, ref, 2e-5)
+
+
+@pytest.mark.parametrize("kind,n,m", [("cloud", 3000, 1500), ("cloud", 20000, 700), ("lattice", 1331, 665), ("plane", 900, 899),
+                                      ("one", 1, 1), ("dup", 64, 40)])
+def test_farthest_point_sample_matches_oracle(oracle, dev, kind, n, m):
+    """dmcf_farthest_point_sample against the restatement of sampling.cu:125-182, index for index -- including exact
+    ties (lattice / duplicated points), which resolve as in the reference's 512-thread kernel, and point sets larger
+    than the 8192 points the kernel keeps in registers."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(7)
+    if kind == "cloud":
+        p = _cloud(n, 51)
+    elif kind == "lattice":
+        g = np.arange(11, dtype=np.float32) * np.float32(0.125)
+        p = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3)
+    elif kind == "plane":
+        g = np.arange(30, dtype=np.float32) * np.float32(0.25)
+        p = np.stack(np.meshgrid(g, g, np.zeros(1, np.float32), indexing="ij"), -1).reshape(-1, 3)
+    elif kind == "one":
+        p = np.float32([[1, 2, 3]])
+    else:
+        p = np.repeat(rng.uniform(-1, 1, size=(8, 3)).astype(np.float32), 8, axis=0)
+    idx = ops.farthest_point_sample(m, _t(p, dev).unsqueeze(0))
+    assert idx.shape == (1, m) and idx.dtype == torch.int32
+    ref = oracle.farthest_point_sample(m, p)
+    assert np.array_equal(idx[0].cpu().numpy(), ref)
+    feats = rng.normal(size=(p.shape[0], 5)).astype(np.float32)
+    got = ops.gather_point(_t(feats, dev).unsqueeze(0), idx)[0].cpu().numpy()
+    assert np.array_equal(got, feats[ref])

@@ -162,3 +162,25 @@ def test_scene_file_io_roundtrip_and_reference_fixture(tmp_path):
     except ImportError:
         with pytest.raises(ImportError):
             write_results(str(tmp_path / "r.hdf5"), "SymNet", out)
+
+
+def test_fps_multiscale_host_logic(oracle, monkeypatch):
+    """voxel_size: None multi-scale (losses.py:274-282) + the cross-scale Dense branch of HRNet (hrnet.py:100-113):
+    the model on CPU tensors with oracle-backed operators equals the numpy restatement."""
+    import shims
+    from oracle.model_ref import ModelRef
+    from dmcf_amd import models
+    from dmcf_amd.utils import tf_checkpoint as tc
+    from tools import configs, scenes
+    shims.install(monkeypatch)
+    cfg = dict(configs.WATERRAMPS, voxel_size=None, centralize=False)
+    w = scenes.random_weights(cfg, seed=6)
+    scene = scenes.box_scene(12, h=0.005, dim=2, origin=(-0.03, -0.03, 0.0))
+    model = getattr(models, cfg["name"])(**cfg)
+    tc.load_into_model(model, w, device="cpu")
+    ref = ModelRef(cfg, w)
+    pos_ref, vel_ref = ref.step(scenes.model_inputs(scene))
+    pos, vel = model(scenes.model_inputs(scene, device="cpu"), training=False)[:2]
+    assert np.abs(pos.numpy() - pos_ref).max() <= 1e-6 * np.abs(pos_ref).max()
+    assert np.abs(model.pos_correction.numpy() - ref.pos_correction).max() <= 1e-4 * np.abs(ref.pos_correction).max()
+    assert [len(i) for i in ref.fps_idx[1:]] == [len(model.all_pos) // 2, len(model.all_pos) // 4]

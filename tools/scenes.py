@@ -107,7 +107,7 @@ def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
                 cin_l = prev[l] * (2 if l < n_dens else 1)
                 conv(f"model/_all_convs/{idx}/1", cin_l, ch)
                 idx += 1
-                if l == j:
+                if l == j or c.get("voxel_size") is None:  # cross-scale Dense layers only exist on the FPS path (hrnet.py:100-113)
                     dense(f"model/denses/{i - 1}/{j}/0/{l}", cin_l, ch)
             cur.append(ch)
         prev = cur
