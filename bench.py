@@ -69,7 +69,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # DMCF_BENCH_SHARDED=1 under torch.distributed.run with ONE process: the sharded driver + RCCL collectives at world
+    # size 1 (the only way to exercise that path on a 1-GPU box; its ghost sets are empty)
+    sharded = world > 1 or (os.environ.get("DMCF_BENCH_SHARDED") == "1" and "RANK" in os.environ)
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -86,7 +89,7 @@ def main():
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, weights, device=dev)
-    if world == 1:
+    if not sharded:
         sim = Simulator(model, device=f"cuda:{local_rank}")
         scene = scenes.box_scene(args.side)
         n_fluid = scene["pos"].shape[0]
@@ -107,7 +110,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if sharded:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -126,7 +129,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, ops.timer = (ops.timer if ops.timer is not None else ops.LaunchTimer()), None
     assert torch.isfinite(state["pos"] if isinstance(state, dict) else state[0]).all()
-    if world > 1:
+    if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -152,7 +155,7 @@ def main():
             "config": {"workload": f"synthetic 3-D box, {n_fluid} fluid + {scene['box'].shape[0]} boundary particles per GPU, "
                                    f"Liquid3d SymNet (18 CConv/ASCC layers, reference checkpoint weights), one rollout step",
                        "parallelism": (f"{world} slabs along x of one {world * args.side}x{args.side}x{args.side} box, 1 process per GPU, "
-                                       "per-layer ghost all-to-all-v over RCCL") if world > 1 else "single GPU",
+                                       "per-layer ghost all-to-all-v over RCCL") if sharded else "single GPU",
                        "particles_per_gpu": n_fluid},
             "roofline": {"bound": "hbm", "kernel": "dmcf::cconv_* (all CConv/ASCC launches of the timed steps: cconv_kernel, cconv_mfma_kernel, cconv_blk_kernel, cconv_direct_kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -165,7 +168,7 @@ def main():
         if args.layers_json:
             json.dump([dict(kind=k, ms=ms, **m) for k, m, ms in recs], open(args.layers_json, "w"))
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if sharded:
         dist.destroy_process_group()
 
 

@@ -51,7 +51,7 @@ class Comm:
         """In place all-reduce of a small tensor; op in {'sum', 'min', 'max'}."""
         return t
 
-    def all_to_all(self, send):
+    def all_to_all(self, send, recv_counts=None):
         """send[r]: tensor for rank r (same dtype / trailing dims everywhere, variable first dim).
         Returns recv with recv[r] = what rank r sent to this rank."""
         return [send[0]]
@@ -72,16 +72,21 @@ class TorchDistComm(Comm):
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t
 
-    def all_to_all(self, send):
+    def all_to_all(self, send, recv_counts=None):
+        """``recv_counts``: rows each rank will send here, when the caller already knows them (a ghost plan exchanges
+        the same rows for every layer): skips the count exchange and its host round trip."""
         dist = self.dist
         dev = send[0].device
         trailing = tuple(send[0].shape[1:])
         width = int(np.prod(trailing)) if trailing else 1
-        send_counts = torch.tensor([s.shape[0] for s in send], dtype=torch.int64, device=dev)
-        recv_counts = torch.empty_like(send_counts)
-        dist.all_to_all_single(recv_counts, send_counts, group=self.group)
-        sc = send_counts.tolist()
-        rc = recv_counts.tolist()
+        sc = [int(s.shape[0]) for s in send]
+        if recv_counts is None:
+            send_counts = torch.tensor(sc, dtype=torch.int64, device=dev)
+            rc_t = torch.empty_like(send_counts)
+            dist.all_to_all_single(rc_t, send_counts, group=self.group)
+            rc = rc_t.tolist()
+        else:
+            rc = [int(c) for c in recv_counts]
         inp = torch.cat([s.reshape(s.shape[0], width) for s in send], dim=0).contiguous()
         out = torch.empty((sum(rc), width), dtype=inp.dtype, device=dev)
         dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
@@ -114,7 +119,7 @@ class LocalComm(Comm):
         t.copy_(res)
         return t
 
-    def all_to_all(self, send):
+    def all_to_all(self, send, recv_counts=None):
         hub = self.hub
         hub.slots[self.rank] = send
         hub.barrier.wait()
@@ -193,6 +198,7 @@ class GhostPlan:
         self.send_idx = [empty if r == comm.rank else torch.nonzero(decomp.within(pos_owned, r, width)).reshape(-1)
                          for r in range(comm.world)]
         recv = comm.all_to_all([pos_owned[i] for i in self.send_idx])
+        self.recv_counts = [int(r.shape[0]) for r in recv]  # the same rows travel for every layer of the step
         self.n_owned = pos_owned.shape[0]
         self.ghost_pos = torch.cat(recv, dim=0) if comm.world > 1 else pos_owned[:0]
         self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous()
@@ -201,7 +207,7 @@ class GhostPlan:
         """[n_owned, C] -> [n_owned + n_ghost, C] (owned rows first, ghosts in the order of ``pos_ext``)."""
         if self.comm.world == 1:
             return feats_owned
-        recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx])
+        recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx], recv_counts=self.recv_counts)
         return torch.cat([feats_owned] + recv, dim=0).contiguous()
 
 
