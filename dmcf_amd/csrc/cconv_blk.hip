@@ -30,12 +30,11 @@
 namespace dmcf {
 
 #ifndef BLK_WAVES
-#define BLK_WAVES 4
+#define BLK_WAVES 8
 #endif
 constexpr int kBWaves = BLK_WAVES;
 #ifndef BLK_OCC
-#define BLK_OCC 4  // waves per SIMD the register budget is set for.  Measured (L8, 3.07e8 pairs): 4 waves x 4 WGs with
-                   // ~40 spilled VGPRs outside the inner loop 8.2 ms; 3 per SIMD without spills 8.7 ms; 8-wave WGs 8.5 ms
+#define BLK_OCC 4  // waves per SIMD the register budget is set for (3 waves per SIMD: 8.5 ms against 7.3 ms)
 #endif
 constexpr int kBThreads = 64 * kBWaves;
 constexpr int BTM = 2 * kBWaves;   // output points per workgroup = rows of the B tile
@@ -240,39 +239,19 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                         }
                     }
                 };
-                // inner loops: `cnt` consecutive slots into the plane pair (lo, hi).  No VALU besides the two
-                // pointer bumps per 4 pairs, no VMEM.
                 // inner loops: `cnt` consecutive slots into the plane pair (lo, hi).  Hand-issued LDS reads (ds_read_b64
-                // for {A plane lo, A plane hi}: the compiler would merge two of them into ds_read2_b64, which runs at
-                // half the rate) with the next group of 4 pairs in flight while the current one feeds the MFMAs.
+                // for {A plane lo, A plane hi}: the compiler would merge two of them into ds_read2_b64, which runs at half
+                // the rate), four pairs per group.  Keeping a second group in flight (double-buffered operands) was
+                // measured and dropped: its 12 extra live registers pushed ~40 VGPRs of loop-invariant state into
+                // scratch around every call (3-6 GB of spill traffic per launch) -- 8.2 ms against 7.3 ms without.
                 auto run = [&](int cnt, uint32_t& pa, uint32_t& pf, f32x4& lo, f32x4& hi) {
                     const int ng = cnt >> 2;
-                    if (ng > 0) {
-                        // one group is always requested ahead (the last request reads slots that are not consumed:
-                        // inside LDS, or beyond its end where reads return 0); both register sets are drained before
-                        // the compiler may reuse them.
-                        f32x2 xa0, xa1, xa2, xa3, ya0, ya1, ya2, ya3;
-                        float xf0, xf1, xf2, xf3, yf0, yf1, yf2, yf3;
+                    for (int g = 0; g < ng; ++g) {
+                        f32x2 xa0, xa1, xa2, xa3;
+                        float xf0, xf1, xf2, xf3;
                         BLK_LOAD4(xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3, pa, pf);
-                        int g = 0;
-                        while (true) {
-                            BLK_LOAD4(ya0, ya1, ya2, ya3, yf0, yf1, yf2, yf3, pa, pf);
-                            BLK_WAIT(8, xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3);
-                            BLK_MFMA4(xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3);
-                            if (++g >= ng) {
-                                BLK_WAIT(0, ya0, ya1, ya2, ya3, yf0, yf1, yf2, yf3);
-                                break;
-                            }
-                            BLK_LOAD4(xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3, pa, pf);
-                            BLK_WAIT(8, ya0, ya1, ya2, ya3, yf0, yf1, yf2, yf3);
-                            BLK_MFMA4(ya0, ya1, ya2, ya3, yf0, yf1, yf2, yf3);
-                            if (++g >= ng) {
-                                BLK_WAIT(0, xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3);
-                                break;
-                            }
-                        }
-                        pa -= 64;
-                        pf -= 256;
+                        BLK_WAIT(0, xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3);
+                        BLK_MFMA4(xa0, xa1, xa2, xa3, xf0, xf1, xf2, xf3);
                     }
                     for (int t = 4 * ng; t < cnt; ++t) {
                         f32x2 av;
