@@ -29,6 +29,8 @@
 //   * consecutive tiles go to the same XCD (blockIdx swizzle) so neighbouring outputs share one L2.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "cconv_common.h"
 
 namespace dmcf {
@@ -39,6 +41,7 @@ constexpr int TM = 16;           // output points per workgroup (MFMA M)
 constexpr int kMaxNT = 4;        // N tiles of 16 output channels (Cout <= 64)
 constexpr int kWStride = 8;      // staged corner weights per pair
 constexpr int kFStride = 8;      // staged features per pair
+constexpr int kStage = 64 * (kWStride + kFStride + 1);  // floats per wave: weights, features, base offset per pair
 
 // Layout of one row of B (floats): [z plane][y row][x cell][channel].  z planes are padded to "PS" floats so
 // that the +z corners of a pair fall on other LDS banks than the -z corners (make_cfg picks the padding with a
@@ -54,10 +57,11 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     const int KCp = p.KCp, cin = p.cin, cout = p.cout, PS = p.PS;
     float* Bt = smem;                                   // [TM][KCp]
     float* norm = Bt + p.bfloats;                       // [TM]
-    float* stage = norm + TM + (size_t)wave * 64 * (kWStride + kFStride);
+    float* stage = norm + TM + (size_t)wave * kStage;
     float* wst = stage;                                 // [64][kWStride]
     float* fst = stage + 64 * kWStride;                 // [64][kFStride]
-    float* deadbase = norm + TM + (size_t)kWaves * 64 * (kWStride + kFStride);  // [kThreads][2], only if a filter axis is 1
+    int* bst = (int*)(fst + 64 * kFStride);             // [64] base cell offset of the pair (floats into its B row)
+    float* deadbase = norm + TM + (size_t)kWaves * kStage;  // [kThreads][2], only if a filter axis is 1
     // XCD-aware tile order: blocks b, b+8, b+16.. (same XCD) take consecutive tiles
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
@@ -207,6 +211,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                     }
                 }
                 base = bz * PS + (by * p.sx + bx) * CC;
+                bst[lane] = base;
                 // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
                 const float w00 = wx0 * wy0, w10 = wx1 * wy0, w01 = wx0 * wy1, w11 = wx1 * wy1;
                 // the two float4 halves of a pair's weights swap places every 4 lanes: conflict-free b128 stores
@@ -234,28 +239,60 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
             // on two rows.  Branch-free body: slots beyond a half's pair count hold zero features
             // (phase 1 wrote f*a = 0 and a valid base cell for them), so they add 0.
             const int nq = max(__builtin_amdgcn_readlane(np_h, 0), __builtin_amdgcn_readlane(np_h, 32));
-            const float* wsrc = wst + (32 * h) * kWStride;
-            const float* fsrc = fst + (32 * h) * kFStride;
-            float* dead = deadbase + 2 * tid;
-#pragma unroll 4
-            for (int q = 0; q < nq; ++q) {
-                const int b0 = __builtin_amdgcn_readlane(base, q);
-                const int b1 = __builtin_amdgcn_readlane(base, 32 + q);
-                const int off = (h ? b1 : b0) + lane_off;
-                const float w = wsrc[q * kWStride + (t ^ (((q >> 2) & 1) << 2))];
-                if constexpr (CPL == 2) {
-                    const f32x2 fv = *(const f32x2*)(fsrc + q * kFStride + ((c4 * 2) ^ (((q >> 2) & 1) << 2)));
-                    f32x2* dst = (f32x2*)(lane_live ? Brow + off : dead);
-                    f32x2 o = *dst;
-                    o.x += w * fv.x;
-                    o.y += w * fv.y;
-                    *dst = o;
-                } else {
-                    const float fv = fsrc[q * kFStride + c4];
-                    float* dst = lane_live ? Brow + off : dead;
-                    *dst = *dst + w * fv;
+            // Groups of 8 slots, fully unrolled: the half-swap of the staging layout has period 8, so every staging
+            // address is a loop-carried lane pointer + an immediate; the base cell comes from the staging area with
+            // one broadcast read (it used to take 2 v_readlane + 2 v_mov + v_cndmask per pair of pairs) and the only
+            // VALU work left per iteration is one address add, the multiply and the add of the read-modify-write.
+            // Slots beyond a half's pair count hold zero features and a valid base cell: a group may run past nq.
+            const float* wq0 = wst + (32 * h) * kWStride + t;        // slots with (q >> 2) even
+            const float* wq1 = wst + (32 * h) * kWStride + (t ^ 4);  // ... odd
+            const float* fq0 = fst + (32 * h) * kFStride + (CPL == 2 ? c4 * 2 : c4);
+            const float* fq1 = fst + (32 * h) * kFStride + (CPL == 2 ? ((c4 * 2) ^ 4) : c4);
+            const int* bq = bst + 32 * h;
+            float* const brow = Brow + lane_off;
+            float* const dead = deadbase + 2 * tid;
+            auto splat8 = [&](auto all_live_tag) {
+                constexpr bool ALL_LIVE = decltype(all_live_tag)::value;
+                for (int q0 = 0; q0 < nq; q0 += 8) {
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) {  // g = (q >> 2) & 1 selects the swapped staging halves
+                        const float* wq = g ? wq1 : wq0;
+                        const float* fq = g ? fq1 : fq0;
+                        // staging reads of four pairs first (they never alias B), then the four dependent read-modify-writes
+                        float w[4];
+                        int boff[4];
+                        f32x2 fv2[4];
+                        float fv1[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const int q = q0 + 4 * g + u;
+                            w[u] = wq[q * kWStride];
+                            boff[u] = bq[q];
+                            if constexpr (CPL == 2)
+                                fv2[u] = *(const f32x2*)(fq + q * kFStride);
+                            else
+                                fv1[u] = fq0[q * kFStride];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            float* d = (ALL_LIVE || lane_live) ? brow + boff[u] : dead;
+                            if constexpr (CPL == 2) {
+                                f32x2* dst = (f32x2*)d;
+                                f32x2 o = *dst;
+                                o.x += w[u] * fv2[u].x;
+                                o.y += w[u] * fv2[u].y;
+                                *dst = o;
+                            } else {
+                                *d = *d + w[u] * fv1[u];
+                            }
+                        }
+                    }
                 }
-            }
+            };
+            if (p.sx >= 2 && p.sy >= 2 && p.sz >= 2)  // 3-D filters: every corner lane is live
+                splat8(std::true_type{});
+            else
+                splat8(std::false_type{});
             // rotate the pipeline registers
             jA = jB; gA = gB; gbA = gbB; vA = vB;
             jB = jC; gB = gC; gbB = gbC; vB = vC;
@@ -427,7 +464,7 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
         size_t bf = (size_t)TM * kcp;
         const size_t rf = (size_t)kWaves * TM * 16 * ((cout + 15) / 16);
         if (bf < rf) bf = rf;
-        return (bf + TM + (size_t)kWaves * 64 * (kWStride + kFStride) + (has_dead ? 2 * kThreads : 0)) * sizeof(float);
+        return (bf + TM + (size_t)kWaves * kStage + (has_dead ? 2 * kThreads : 0)) * sizeof(float);
     };
     const int PS0 = (PR + 7) / 8 * 8;
     const size_t step = lds_bytes(PS0) <= 80 * 1024 ? 80 * 1024 : 160 * 1024;  // keep the occupancy step of the unpadded tile
