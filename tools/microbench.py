@@ -16,35 +16,40 @@ def timed(fn, n=5):
         ts.append(a.elapsed_time(b))
     return float(np.median(ts))
 
-dev = torch.device("cuda:0")
-side = int(os.environ.get("SIDE", "100"))
-sc = scenes.box_scene(side)
-s0 = torch.from_numpy(np.concatenate([sc["pos"], sc["box"]])).to(dev)
-s1 = grid_pos(s0, np.float32([0.05] * 3), centralize=True)
-g = torch.Generator(device=dev).manual_seed(0)
-cases = [("L3  24->8  s0->s1 R0.2", s0, s1, 0.2, 24, 8, (4, 4, 4), "poly6", False),
-         ("L14 32->32 s0->s0 R0.1", s0, s0, 0.1, 32, 32, (4, 4, 4), "poly6", False),
-         ("L8  16->16 s0->s1 R0.2", s0, s1, 0.2, 16, 16, (4, 4, 4), "poly6", False),
-         ("L6   8->32 s1->s0 R0.2", s1, s0, 0.2, 8, 32, (4, 4, 4), "poly6", False),
-         ("L7   4->32 s1->s0 R0.2", s1, s0, 0.2, 4, 32, (4, 4, 4), "poly6", False),
-         ("L4  24->4  s0->s2 R0.4", s0, grid_pos(s0, np.float32([0.1] * 3), centralize=True), 0.4, 24, 4, (4, 4, 4), "poly6", False),
-         ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
-for name, inp, out, R, cin, cout, ks, win, sym in cases:
-    if os.environ.get('ONLY') and not name.startswith(os.environ['ONLY']): continue
-    nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=True)
-    feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
-    W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
-    geo = None
-    if os.environ.get("GEO", "0") == "1":
-        g = lambda: ops.cconv_geometry(ks, out, 2 * R, inp, nns.neighbors_index, nns.neighbors_row_splits,
-                                       neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
-        geo = g()
-        print(f"   geometry build {timed(g):.2f} ms", flush=True)
-    f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
-                                  neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1, geometry=geo)
-    f()
-    ms = timed(f)
-    P = nns.neighbors_index.shape[0]
-    K = ks[0] * ks[1] * ks[2] * (2 if sym else 1)
-    by = P * (20 + 4 * cin) + out.shape[0] * (20 + 4 * cout) + 4 * K * cin * cout
-    print(f"{name}: pairs {P/1e6:7.1f}M  {ms:7.2f} ms  {1e6*ms/P/((cin+7)//8):.4f} ns/pair/chunk  alg {by/ms/1e6:7.0f} GB/s ({100*by/ms/1e6/8000:.1f}% of 8 TB/s)", flush=True)
+def main():
+    dev = torch.device("cuda:0")
+    side = int(os.environ.get("SIDE", "100"))
+    sc = scenes.box_scene(side)
+    s0 = torch.from_numpy(np.concatenate([sc["pos"], sc["box"]])).to(dev)
+    s1 = grid_pos(s0, np.float32([0.05] * 3), centralize=True)
+    g = torch.Generator(device=dev).manual_seed(0)
+    cases = [("L3  24->8  s0->s1 R0.2", s0, s1, 0.2, 24, 8, (4, 4, 4), "poly6", False),
+             ("L14 32->32 s0->s0 R0.1", s0, s0, 0.1, 32, 32, (4, 4, 4), "poly6", False),
+             ("L8  16->16 s0->s1 R0.2", s0, s1, 0.2, 16, 16, (4, 4, 4), "poly6", False),
+             ("L6   8->32 s1->s0 R0.2", s1, s0, 0.2, 8, 32, (4, 4, 4), "poly6", False),
+             ("L7   4->32 s1->s0 R0.2", s1, s0, 0.2, 4, 32, (4, 4, 4), "poly6", False),
+             ("L4  24->4  s0->s2 R0.4", s0, grid_pos(s0, np.float32([0.1] * 3), centralize=True), 0.4, 24, 4, (4, 4, 4), "poly6", False),
+             ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
+    for name, inp, out, R, cin, cout, ks, win, sym in cases:
+        if os.environ.get('ONLY') and not name.startswith(os.environ['ONLY']): continue
+        nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=True)
+        feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
+        W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
+        geo = None
+        if os.environ.get("GEO", "0") == "1":
+            g = lambda: ops.cconv_geometry(ks, out, 2 * R, inp, nns.neighbors_index, nns.neighbors_row_splits,
+                                           neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
+            geo = g()
+            print(f"   geometry build {timed(g):.2f} ms", flush=True)
+        f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
+                                      neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1, geometry=geo)
+        f()
+        ms = timed(f)
+        P = nns.neighbors_index.shape[0]
+        K = ks[0] * ks[1] * ks[2] * (2 if sym else 1)
+        by = P * (20 + 4 * cin) + out.shape[0] * (20 + 4 * cout) + 4 * K * cin * cout
+        print(f"{name}: pairs {P/1e6:7.1f}M  {ms:7.2f} ms  {1e6*ms/P/((cin+7)//8):.4f} ns/pair/chunk  alg {by/ms/1e6:7.0f} GB/s ({100*by/ms/1e6/8000:.1f}% of 8 TB/s)", flush=True)
+
+
+if __name__ == "__main__":
+    main()
