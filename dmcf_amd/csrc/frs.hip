@@ -242,7 +242,8 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                                             uint32_t* marks) {
     const int lane = lane_id();
     int mark_tag = 0;
-    marks[lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
+    marks[lane] = 0;
+    marks[kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
     const float q[3] = {qx, qy, qz};
     const float r2 = __fmul_rn(radius, radius);
     int lo[3], hi[3];
@@ -275,34 +276,34 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
             const int32_t excl = incl - len;
             const int32_t rel = start - excl;  // candidate c of this run sits at sorted[rel + flat]
             int carry = 0;                     // the run that contains the first flat index of the window
-            for (int32_t f0 = 0; f0 < total; f0 += kWave) {
-                const int32_t f = f0 + lane;
-                // Which run does flat index f fall into?  Every non-empty run that STARTS inside the window
-                // [f0, f0 + 64) drops its number at its start slot of a per-wave LDS array (tagged with the window
-                // counter so the array never needs clearing); an inclusive max-scan over the lanes (DPP, no LDS)
-                // then carries the latest start to every slot, and `carry` covers the slots before the first start.
-                // One LDS round trip instead of the six dependent ds_bpermute steps of a binary search (measured:
-                // 3.8 -> 3.1 ms for a 307M-pair list).  Requesting the next window's candidates before testing the
-                // current ones was tried on top of this and was slower (3.4 ms).
+            // Which run does flat index f fall into?  Every non-empty run that STARTS inside the window
+            // [f0, f0 + 64) drops its number at its start slot of a per-wave LDS array (tagged with the window
+            // counter so the array never needs clearing); an inclusive max-scan over the lanes (DPP, no LDS)
+            // then carries the latest start to every slot, and `carry` covers the slots before the first start.
+            // One LDS round trip instead of the six dependent ds_bpermute steps of a binary search (measured:
+            // 3.8 -> 3.1 ms for a 307M-pair list).
+            auto locate = [&](int32_t f0, uint32_t* mk) -> int32_t {
                 const uint32_t tag = (uint32_t)(++mark_tag) << 8;
                 const int32_t sl = excl - f0;
-                if (len > 0 && sl >= 0 && sl < kWave) marks[sl] = tag | (uint32_t)lane;
+                if (len > 0 && sl >= 0 && sl < kWave) mk[sl] = tag | (uint32_t)lane;
                 // lanes talk to each other through LDS here: without a (wavefront-scope) fence the compiler may keep
-                // using this lane's own last value of marks[lane] (seen: it sank the load into the store's branch)
+                // using this lane's own last value of mk[lane] (seen: it sank the load into the store's branch)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t mv = marks[lane];
+                const uint32_t mv = mk[lane];
                 int run = ((mv & ~255u) == tag) ? (int)(mv & 255u) : 0;
                 run = wave_inclusive_max(run);
                 run = max(run, carry);
                 carry = __builtin_amdgcn_readlane(run, kWave - 1);
-                const int32_t src = __shfl(rel, run, kWave) + f;
+                return __shfl(rel, run, kWave) + f0 + lane;
+            };
+            auto test = [&](int32_t f0, const float4& p) {
+                const int32_t f = f0 + lane;
                 bool hit = false;
                 float d2 = 0.0f;
                 int32_t pidx = 0;
                 if (f < total) {
-                    const float4 p = sorted[src];
                     d2 = dist2_unfused(p.x, p.y, p.z, qx, qy, qz);
                     hit = d2 <= r2;
                     if (ignore && p.x == qx && p.y == qy && p.z == qz) hit = false;
@@ -318,6 +319,17 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 }
                 if (MODE == 2 && hit) wsum += window_value(window, d2, inv_r2, 1.0f);
                 cnt += __popcll(mask);
+            };
+            // two windows per iteration: both lookups and both candidate loads are in flight together
+            for (int32_t f0 = 0; f0 < total; f0 += 2 * kWave) {
+                const bool two = f0 + kWave < total;
+                const int32_t sa = locate(f0, marks);
+                const int32_t sb = two ? locate(f0 + kWave, marks + kWave) : 0;
+                float4 pa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pb = pa;
+                if (f0 + lane < total) pa = sorted[sa];
+                if (f0 + kWave + lane < total) pb = sorted[sb];
+                test(f0, pa);
+                if (two) test(f0 + kWave, pb);
             }
         }
     }
@@ -333,7 +345,7 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                                                  int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
                                                  int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
                                                  int64_t capacity) {
-    __shared__ uint32_t marks[4][kWave];
+    __shared__ uint32_t marks[4][2 * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;  // whole wave leaves
     // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ 
                                                       const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
                                                       const float4* __restrict__ sorted, float radius, int flags, int window,
                                                       float* __restrict__ out) {
-    __shared__ uint32_t marks[4][kWave];
+    __shared__ uint32_t marks[4][2 * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
