@@ -60,7 +60,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void* q) {
         "offset:48\n\tds_read_b32 %4, %9\n\tds_read_b32 %5, %9 offset:64\n\tds_read_b32 %6, %9 offset:128\n\t"      \
         "ds_read_b32 %7, %9 offset:192"                                                                            \
         : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(f0), "=&v"(f1), "=&v"(f2), "=&v"(f3)                   \
-        : "v"(pa), "v"(pf));                                                                                       \
+        : "v"(pa), "v"(pf));                                                                                     \
     pa += 64;                                                                                                      \
     pf += 256
 #define BLK_WAIT(n, a0, a1, a2, a3, f0, f1, f2, f3)                                                                \
@@ -169,9 +169,9 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     return c;
                 };
                 // The pairs of a batch are ordered by plane pair (bz = 0, 1, 2) so that each inner loop has fixed
-                // accumulators; a half = 31 consecutive slots of that order.  `inv` (lane s) = the lane that owns slot s.
+                // accumulators; a half = 31 consecutive slots of that order.
                 struct Order {
-                    int inv, c0, c1;  // pairs with bz == 0, bz == 1
+                    int pos, c0, c1;  // slot of this lane's pair in the ordered batch (63: none); pairs with bz == 0, bz == 1
                 };
                 auto order = [&](int bz) -> Order {  // bz == 3: lane without a pair
                     Order o;
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     const uint64_t mine = bz == 0 ? m0 : (bz == 1 ? m1 : m2);
                     const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0));
                     const int pos = rank + (bz == 0 ? 0 : (bz == 1 ? o.c0 : o.c0 + o.c1));
-                    o.inv = __builtin_amdgcn_ds_permute((bz < 3 ? pos : 63) << 2, lane);
+                    o.pos = bz < 3 ? pos : 63;
                     return o;
                 };
                 // slots of group g inside half h of a batch of np pairs
@@ -192,14 +192,32 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     n[1] = max(0, min(e1, hi) - max(e0, lo));
                     n[2] = max(0, hi - max(e1, lo));
                 };
-                // 16-byte feature loads of half h of a batch: two groups of 16 slots, lane = (slot, 4 channels).
-                // Branch free; slots beyond the half read some valid row and are never consumed.
-                auto f_issue = [&](int bj, int inv, int h, f32x4 (&f)[2]) {
+                // Exchange area = the feature staging (dead between two splats): the lanes that own the pairs of a half
+                // PUSH {x, y, w0, w1} (for the A products) or the neighbour index (for the feature loads) to the slot
+                // their pair has in the ordered batch; the publishing / loading lanes read their slot.  One LDS round
+                // trip, where pulling through ds_bpermute chains (slot -> owner lane -> value) took three.
+                float* xcomp = Fst;               // [31][4]
+                int* xidx = (int*)(Fst + 128);    // [31]
+                auto push_compact = [&](const Compact& c, int pos, int h) {
+                    const int s = pos - kHalf * h;
+                    if (s >= 0 && s < kHalf) *(f32x4*)(xcomp + 4 * s) = (f32x4){c.x, c.y, c.w0, c.w1};
+                };
+                auto push_index = [&](int j, int pos, int h) {
+                    const int s = pos - kHalf * h;
+                    if (s >= 0 && s < kHalf) xidx[s] = j;
+                };
+                auto xfence = [&]() {  // cross-lane communication through LDS: keep the compiler from reordering around it
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                };
+                // 16-byte feature loads of a half with n pairs: two groups of 16 slots, lane = (slot, 4 channels).
+                // Slots beyond n read row 0 and are never consumed.
+                auto f_issue = [&](int n, f32x4 (&f)[2]) {
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
-                        const int s = 16 * k + fr;  // slot 31 of group 1 does not exist: harmless duplicate load
-                        const int src = __shfl(inv, kHalf * h + (s < kHalf ? s : 0), 64);
-                        const int jj = __shfl(bj, src, 64);
+                        const int s = 16 * k + fr;
+                        const int jj = s < n ? xidx[s] : 0;
                         f[k] = *(const f32x4*)(p.inp_feat + (int64_t)jj * cin + fch);
                     }
                 };
@@ -216,13 +234,12 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     }
                 };
                 // A staging of half h: lane (slot ps, rows 2 yh, 2 yh + 1) writes its 16 products (both planes)
-                auto a_publish = [&](const Compact& c, int inv, int h) {
+                auto a_publish = [&]() {
 #ifdef BLK_NO_APUB
                     return;
 #endif
-                    const int src = __shfl(inv, kHalf * h + (ps < kHalf ? ps : 0), 64);
-                    const float x = __shfl(c.x, src, 64), y = __shfl(c.y, src, 64);
-                    const float w0 = __shfl(c.w0, src, 64), w1 = __shfl(c.w1, src, 64);
+                    const f32x4 cv = *(const f32x4*)(xcomp + 4 * (ps < kHalf ? ps : 0));
+                    const float x = cv.x, y = cv.y, w0 = cv.z, w1 = cv.w;
                     float hx[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hx[k] = hat01(x - (float)k);
@@ -266,6 +283,9 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     }
                 };
                 auto splat = [&](const int (&n)[3]) {
+                    // the staging stores above are plain C++, the loads below hand-written asm: one compiler barrier
+                    // between them (LDS itself executes a wave's operations in order)
+                    asm volatile("" ::: "memory");
                     uint32_t pa = a_rd_lds, pf = f_rd_lds;
                     run(n[0], pa, pf, b0, b1);
                     run(n[1], pa, pf, b1, b2);
@@ -283,7 +303,9 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     int curj = j0;
                     Order oc = order(bzc);
                     f32x4 fA[2], fB[2];
-                    f_issue(curj, oc.inv, 0, fA);
+                    push_index(curj, oc.pos, 0);
+                    xfence();
+                    f_issue((int)min((int64_t)kHalf, ntot), fA);
                     ld_pos(j1, v1, px, py, pz);
                     for (int b = 0; b < nb; ++b) {
                         const int np = (int)min((int64_t)kBatch, ntot - (int64_t)kBatch * b);
@@ -292,10 +314,14 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                         bool v2;
                         int nseg[3];
                         ld_idx(b + 2, j2, nv2, v2);
-                        // ---- half 0
-                        a_publish(cur, oc.inv, 0);
+                        // ---- half 0: A products of (this batch, half 0), feature loads of (this batch, half 1)
+                        push_compact(cur, oc.pos, 0);
+                        push_index(curj, oc.pos, 1);
+                        xfence();
+                        a_publish();
+                        f_issue(max(np - kHalf, 0), fB);
+                        xfence();
                         f_publish(fA);
-                        f_issue(curj, oc.inv, 1, fB);
                         seg(oc, np, 0, nseg);
                         splat(nseg);
                         // geometry of the next batch (its position gathers were issued one batch ago)
@@ -304,11 +330,15 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                         const int nxtj = j1;
                         const Order on = order(bzn);
                         ld_pos(j2, v2, px, py, pz);
-                        // ---- half 1
+                        // ---- half 1: A products of (this batch, half 1), feature loads of (next batch, half 0)
                         if (np > kHalf) {
-                            a_publish(cur, oc.inv, 1);
+                            push_compact(cur, oc.pos, 1);
+                            push_index(nxtj, on.pos, 0);
+                            xfence();
+                            a_publish();
+                            f_issue((int)min((int64_t)kHalf, max((int64_t)0, ntot - (int64_t)kBatch * (b + 1))), fA);
+                            xfence();
                             f_publish(fB);
-                            f_issue(nxtj, on.inv, 0, fA);
                             seg(oc, np, 1, nseg);
                             splat(nseg);
                         }
@@ -387,10 +417,9 @@ size_t cconv_blk_packed_floats(int cin, int cout) {
     return (size_t)nchunks * (kRow / 16) * 4 * NT * 16 * 4;
 }
 
-// 4x4x4 filter, the flag set every DMCF model uses, 16-byte addressable feature rows.  Measured on MI355X (3.07e8
-// pairs, 265 per output, 16 channels): 8.6 ms against 9.3 ms for the 16x16x4 splat; at 29 pairs per output the
-// 62-pair batches are half empty and it loses (6.1 ms against 4.3 ms), so it is only picked for wide layers with
-// large neighbourhoods.
+// 4x4x4 filter, the flag set every DMCF model uses, 16-byte addressable feature rows.  Measured on MI355X (16
+// channels): 7.3 ms against 9.3 ms for the 16x16x4 splat at 3.07e8 pairs / 265 per output, 4.0 against 4.35 ms
+// at 3.3e7 pairs / 29 per output (32 -> 32): picked for every layer with at least 12 input channels.
 bool cconv_blk_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma" / "blk": force one implementation (A/B tests)
     if (e && e[0] != 'b') return false;
@@ -403,7 +432,7 @@ bool cconv_blk_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     if ((cin & 3) || cout > 16 * kBMaxNT) return false;
     if ((uintptr_t)a->inp_features & 15) return false;
     if (e) return true;
-    return cin >= 12 && a->n_pairs >= 96 * a->n_out;
+    return cin >= 12;
 }
 
 int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {
