@@ -221,6 +221,11 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
     return v;
 }
 
+#ifndef FRS_WIN
+#define FRS_WIN 4
+#endif
+constexpr int kWin = FRS_WIN;  // candidate windows (64 each) in flight per iteration
+
 __device__ __forceinline__ int wave_inclusive_add(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
@@ -242,8 +247,7 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                                             uint32_t* marks) {
     const int lane = lane_id();
     int mark_tag = 0;
-    marks[lane] = 0;
-    marks[kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
+    for (int w = 0; w < kWin; ++w) marks[w * kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
     const float q[3] = {qx, qy, qz};
     const float r2 = __fmul_rn(radius, radius);
     int lo[3], hi[3];
@@ -320,16 +324,20 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 if (MODE == 2 && hit) wsum += window_value(window, d2, inv_r2, 1.0f);
                 cnt += __popcll(mask);
             };
-            // two windows per iteration: both lookups and both candidate loads are in flight together
-            for (int32_t f0 = 0; f0 < total; f0 += 2 * kWave) {
-                const bool two = f0 + kWave < total;
-                const int32_t sa = locate(f0, marks);
-                const int32_t sb = two ? locate(f0 + kWave, marks + kWave) : 0;
-                float4 pa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pb = pa;
-                if (f0 + lane < total) pa = sorted[sa];
-                if (f0 + kWave + lane < total) pb = sorted[sb];
-                test(f0, pa);
-                if (two) test(f0 + kWave, pb);
+            // kWin windows per iteration: their lookups and candidate loads are in flight together
+            for (int32_t f0 = 0; f0 < total; f0 += kWin * kWave) {
+                int32_t src[kWin];
+                float4 pv[kWin];
+#pragma unroll
+                for (int w = 0; w < kWin; ++w) src[w] = (w == 0 || f0 + w * kWave < total) ? locate(f0 + w * kWave, marks + w * kWave) : 0;
+#pragma unroll
+                for (int w = 0; w < kWin; ++w) {
+                    pv[w] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (f0 + w * kWave + lane < total) pv[w] = sorted[src[w]];
+                }
+#pragma unroll
+                for (int w = 0; w < kWin; ++w)
+                    if (w == 0 || f0 + w * kWave < total) test(f0 + w * kWave, pv[w]);
             }
         }
     }
@@ -345,7 +353,7 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                                                  int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
                                                  int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
                                                  int64_t capacity) {
-    __shared__ uint32_t marks[4][2 * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;  // whole wave leaves
     // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
@@ -364,7 +372,7 @@ __global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ 
                                                       const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
                                                       const float4* __restrict__ sorted, float radius, int flags, int window,
                                                       float* __restrict__ out) {
-    __shared__ uint32_t marks[4][2 * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
