@@ -219,3 +219,24 @@ def test_fps_multiscale_2d(dev):
     scene = scenes.box_scene(30, h=0.005, dim=2, origin=(-0.07, -0.07, 0.0))
     model, ref = _compare_step(cfg, w, scene, dev, steps=2)
     assert [len(i) for i in ref.fps_idx[1:]] == [len(model.all_pos) // 2, len(model.all_pos) // 4]
+
+
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line with the fields the driver reads (small workload so the test stays quick)."""
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--side", "24", "--steps", "2", "--warmup", "1",
+                          "--cpu-side", "8"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["vs_baseline"] is None and d["value"] > 0
+    assert abs(d["value"] - 24 ** 3 * 2 / (d["ms_per_step"] * 2e-3)) < 1e-6 * d["value"]
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
+    assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
+    assert "workload" in d["config"] and "model" not in d["config"]
