@@ -10,11 +10,12 @@
 // one instruction adds ONE pair's contribution to one 16-cell z plane of B_i[cell, 16 channels]; the pair
 // touches two planes (bz, bz+1), so two instructions per pair = 16 clocks per SIMD -- the 16x16x4 form of
 // cconv_mfma.hip needs 32 and feeds them with ~6 VALU operations per instruction.  Here K = 1: everything about
-// "which pair" is wave uniform.  The plane pair is selected with SCALAR branches on ballot masks, the operands
-// come from a per-wave LDS staging area (ds_read_b64: both planes' A value, ds_read_b32: the feature) and the
-// inner loop has no VALU and no VMEM instruction at all.  The staging area is filled once per 62 pairs by the
-// lanes that own the pairs (phase 1: gather, window, ball->cube map as in the other kernels, then the 32 products
-// hat*hat*wz per pair) and by 16-byte feature loads issued half a batch ahead.
+// "which pair" is wave uniform.  The pairs of a 62-pair batch are ordered by plane pair (bz = 0, 1, 2) so that each
+// of three inner loops has fixed accumulators; the operands come from a per-wave LDS staging area (ds_read_b64: both
+// planes' A value, ds_read_b32: the feature) and the inner loop has no VMEM instruction and two VALU adds per 4
+// pairs.  The staging area is filled once per 31 pairs: the lanes that own the pairs (phase 1: gather, window,
+// ball->cube map as in the other kernels) push {x, y, w0, w1} to their ordered slot, two lanes per slot form the 32
+// products hat*hat*wz, and the feature rows arrive by 16-byte loads issued half a batch ahead.
 //
 // LDS (80 KB per workgroup, two workgroups per CU): B tile [16 points][64 cells x 16 channels] without padding
 // (XOR swizzle instead) + 2 KB of feature staging per wave.  While a wave splats it uses the B row of its SECOND
@@ -22,7 +23,8 @@
 // of consecutive lanes and the 8-byte loads of the (y, x) lanes are both conflict free) -- the first point's
 // accumulators go to its own row when it is done, the second point's replace the staging.
 //
-// Accumulation order = neighbour order, one fmaf per pair and cell (the MFMA is an exact fp32 fma): deterministic.
+// Accumulation order = the (fixed) ordered-batch order, one fmaf per pair and cell (the MFMA is an exact fp32 fma):
+// deterministic.
 #include <stdlib.h>
 
 #include "cconv_common.h"
@@ -222,9 +224,6 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                     }
                 };
                 auto f_publish = [&](const f32x4 (&f)[2]) {
-#ifdef BLK_NO_FPUB
-                    return;
-#endif
 #pragma unroll
                     for (int k = 0; k < 2; ++k) {
                         const int s = 16 * k + fr;
@@ -235,9 +234,6 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                 };
                 // A staging of half h: lane (slot ps, rows 2 yh, 2 yh + 1) writes its 16 products (both planes)
                 auto a_publish = [&]() {
-#ifdef BLK_NO_APUB
-                    return;
-#endif
                     const f32x4 cv = *(const f32x4*)(xcomp + 4 * (ps < kHalf ? ps : 0));
                     const float x = cv.x, y = cv.y, w0 = cv.z, w1 = cv.w;
                     float hx[4];
