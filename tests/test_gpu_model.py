@@ -240,3 +240,29 @@ def test_bench_line_contract():
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"} and d["roofline"]["bound"] == "hbm"
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_full_size_step_properties(dev):
+    """BASELINE.json's bench configuration at full size (100^3 fluid + 124,864 boundary particles, Liquid3d weights),
+    checked through size-independent properties: the step is bit-reproducible (every kernel has a fixed summation
+    order), the ASCC head conserves momentum, the estimated-buffer path equals the exact one, nothing is NaN."""
+    from tools import configs, scenes
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.utils.convolutions import neighbor_cache
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    model = _build(configs.LIQUID3D, w, dev)
+    sim = Simulator(model, device="cuda")
+    state = scenes.model_inputs(scenes.box_scene(100), device=dev)
+    a = sim.step([state])[0]          # exact sizes (first step), fills the estimates
+    b = sim.step([state])[0]          # estimated sizes, same input
+    c = sim.step([state])[0]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(b[0], c[0])
+    assert torch.isfinite(a[0]).all() and torch.isfinite(a[1]).all()
+    with neighbor_cache():
+        d = model.transform(state)
+        x = model.preprocess(d)
+        out = model.run_forward(x, d)
+    tot = out.double().sum(0).abs()
+    assert torch.all(tot <= 2e-5 * out.double().abs().sum(0)), tot
+    corr = model.pos_correction
+    assert corr.shape == (100 ** 3, 3) and float(corr.abs().max()) < 0.05  # a sub-particle-spacing correction
