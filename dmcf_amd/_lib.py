@@ -40,13 +40,14 @@ class CconvArgs(ctypes.Structure):
         ("out", ctypes.c_void_p),
         ("geometry", ctypes.c_void_p),
         ("n_pairs", ctypes.c_int64),
+        ("neighbors_row_count", ctypes.c_void_p),
     ]
 
 
 # names every entry point include/dmcf_hip.h declares (tests/test_abi.py cross-checks against the header)
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
-    "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_window_sum",
+    "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
     "dmcf_reduce_subarrays_sum",
     "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
@@ -88,6 +89,9 @@ def lib():
     L.dmcf_frs_write.restype = c.c_int
     L.dmcf_frs_write.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_void_p, c.c_size_t,
                                  c.c_void_p, c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p]
+    L.dmcf_frs_search_padded.restype = c.c_int
+    L.dmcf_frs_search_padded.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_void_p, c.c_size_t, c.c_int64,
+                                         c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     L.dmcf_frs_window_sum.restype = c.c_int
     L.dmcf_frs_window_sum.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_float, c.c_int, c.c_int, c.c_void_p, c.c_size_t,
                                       c.c_void_p, c.c_void_p]

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     float ox = 0.0f, oy = 0.0f, oz = 0.0f;
     if (pt_valid) {
         rb = p.rs[i];
-        re = p.rs[i + 1];
+        re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
         if (re > p.pair_cap) re = rb;
         ox = p.out_pos[3 * i]; oy = p.out_pos[3 * i + 1]; oz = p.out_pos[3 * i + 2];
     }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void cconv_geometry_kernel(const CconvParams p
     if (i >= p.n_out) return;
     const int lane = lane_id();
     const int64_t rb = p.rs[i];
-    int64_t re = p.rs[i + 1];
+    int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
     if (re > p.pair_cap) re = rb;
     const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
     for (int64_t pp = rb + lane; pp < re; pp += 64) {
@@ -581,6 +581,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.inp_imp = a->inp_importance;
     p.idx = a->neighbors_index;
     p.rs = a->neighbors_row_splits;
+    p.cnt = a->neighbors_row_count;
     p.nval = a->neighbors_value;
     p.geo4 = nullptr;
     p.geob = nullptr;
@@ -658,6 +659,7 @@ int dmcf_cconv_geometry(const dmcf_cconv_args* a, void* geometry, size_t geometr
     p.inp_pos = a->inp_positions;
     p.idx = a->neighbors_index;
     p.rs = a->neighbors_row_splits;
+    p.cnt = a->neighbors_row_count;
     p.nval = a->neighbors_value;
     p.n_out = a->n_out;
     p.pair_cap = a->n_pairs;

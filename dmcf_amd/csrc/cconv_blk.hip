@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
             f32x4 b0 = {0.0f, 0.0f, 0.0f, 0.0f}, b1 = b0, b2 = b0, b3 = b0;
             if (i < p.n_out) {
                 const int64_t rb = p.rs[i];
-                int64_t re = p.rs[i + 1];
+                int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
                 if (re > p.pair_cap) re = rb;
                 const int64_t ntot = re - rb;
                 const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];

@@ -16,6 +16,7 @@ struct CconvParams {
     const float* inp_imp;
     const int32_t* idx;
     const int64_t* rs;
+    const int32_t* cnt;    // optional pairs per row (padded lists: row i = [rs[i], rs[i] + cnt[i])); NULL = CSR
     const float* nval;
     const f32x4_t* geo4;   // optional per-pair geometry cache: {w1x, w1y, w1z, a}
     const int32_t* geob;   //   and packed base cell bx | by << 8 | bz << 16

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(1024, 1) void cconv_direct_kernel(const DirectParam
         float ox = 0.0f, oy = 0.0f, oz = 0.0f, fi = 0.0f;
         if (pt_valid) {
             rb = p.rs[i];
-            re = p.rs[i + 1];
+            re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
             if (re > p.pair_cap) re = rb;
             ox = p.out_pos[3 * i]; oy = p.out_pos[3 * i + 1]; oz = p.out_pos[3 * i + 2];
             if (symmetric && c_ok) fi = p.inp_feat[i * cin + c];

@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
             float nsum = 0.0f;
             if (i < p.n_out) {
                 const int64_t rb = p.rs[i];
-                int64_t re = p.rs[i + 1];
+                int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
                 if (re > p.pair_cap) re = rb;
                 const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
                 const float fi = (symmetric && ch_ok) ? p.inp_feat[i * cin + c0 + mi] : 0.0f;

@@ -244,7 +244,7 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                                             const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                             float radius, int flags, int64_t out_base, int32_t* __restrict__ nbr_index,
                                             float* __restrict__ nbr_dist, int window, float inv_r2, float& wsum,
-                                            uint32_t* marks) {
+                                            uint32_t* marks, int32_t row_cap = 0x7fffffff) {
     const int lane = lane_id();
     int mark_tag = 0;
     for (int w = 0; w < kWin; ++w) marks[w * kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
@@ -317,9 +317,12 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 if (MODE == 1 && hit) {
                     const int before = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
                                                                  __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    const int64_t o = out_base + cnt + before;
-                    nbr_index[o] = pidx;
-                    if (nbr_dist) nbr_dist[o] = d2;
+                    const int32_t slot = cnt + before;
+                    if (slot < row_cap) {  // padded rows: hits beyond the row's capacity are counted, not written
+                        const int64_t o = out_base + slot;
+                        nbr_index[o] = pidx;
+                        if (nbr_dist) nbr_dist[o] = d2;
+                    }
                 }
                 if (MODE == 2 && hit) wsum += window_value(window, d2, inv_r2, 1.0f);
                 cnt += __popcll(mask);
@@ -364,6 +367,30 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
     const int32_t cnt = frs_scan<WRITE ? 1 : 0>(qx, qy, qz, h, cell_start, sorted, radius, flags, WRITE ? row_splits[qi] : 0,
                                                 nbr_index, nbr_dist, 0, 0.0f, unused, marks[threadIdx.x >> 6]);
     if (!WRITE && lane_id() == 0) counts[qi] = cnt;
+}
+
+// Single pass into padded rows (see dmcf_frs_search_padded): row qi starts at qi * stride.
+__global__ __launch_bounds__(256) void frs_query_padded(const float* __restrict__ queries, int64_t m,
+                                                        const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
+                                                        const float4* __restrict__ sorted, float radius, int flags,
+                                                        int64_t stride, int64_t* __restrict__ row_begin,
+                                                        int32_t* __restrict__ row_count, int32_t* __restrict__ nbr_index,
+                                                        float* __restrict__ nbr_dist, int32_t* __restrict__ max_count) {
+    __shared__ uint32_t marks[4][kWin * kWave];
+    const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (qi >= m) return;
+    const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+    float unused = 0.0f;
+    const int32_t cnt = frs_scan<1>(qx, qy, qz, h, cell_start, sorted, radius, flags, qi * stride, nbr_index, nbr_dist, 0, 0.0f,
+                                    unused, marks[threadIdx.x >> 6], (int32_t)min(stride, (int64_t)0x7fffffff));
+    if (lane_id() == 0) {
+        row_begin[qi] = qi * stride;
+        if (qi == m - 1) row_begin[m] = m * stride;
+        row_count[qi] = (int32_t)min((int64_t)cnt, stride);
+        // same-address atomics serialise (1.1M of them cost ~3 ms per search): only rows that beat the value currently
+        // visible try; a stale read merely costs a redundant atomic
+        if (cnt > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, cnt);
+    }
 }
 
 // compute_density (utils/tools/losses.py:285-306) without the pair list: out[q] = sum over the points within R of
@@ -474,6 +501,24 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
     const unsigned g = (unsigned)((m + 3) / 4);
     hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
                        flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity);
+    return check_launch();
+}
+
+int dmcf_frs_search_padded(const float* queries, int64_t m, int64_t n, float radius, int flags, const void* workspace,
+                           size_t workspace_bytes, int64_t row_stride, int64_t* row_begin, int32_t* row_count,
+                           int32_t* neighbors_index, float* neighbors_distance, int32_t* max_count, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_begin || !max_count || (m > 0 && (!queries || !row_count)))
+        return DMCF_EINVAL;
+    if (row_stride < 0 || (m > 0 && row_stride > 0 && !neighbors_index)) return DMCF_EINVAL;
+    const FrsLayout L = frs_layout(n, m);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    if (m == 0) return hipMemsetAsync(row_begin, 0, 8, stream) == hipSuccess ? DMCF_OK : DMCF_ELAUNCH;
+    const char* ws = (const char*)workspace;
+    const unsigned g = (unsigned)((m + 3) / 4);
+    hipLaunchKernelGGL(frs_query_padded, dim3(g), dim3(256), 0, stream, queries, m, (const FrsHeader*)(ws + L.off_header),
+                       (const uint32_t*)(ws + L.off_cell_start), (const float4*)(ws + L.off_sorted), radius, flags, row_stride,
+                       row_begin, row_count, neighbors_index, neighbors_distance, max_count);
     return check_launch();
 }
 

@@ -255,7 +255,7 @@ class PBFNet(BaseModel):
         pos, vel, acc = data[:3]
         pcnt = pos.shape[0]
         # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
-        counts = ops.neighbor_counts(self.fluid_convs.nns.neighbors_row_splits)
+        counts = ops.neighbor_counts(self.fluid_convs.nns)
         self.num_fluid_neighbors = counts[:pcnt]
 
         out = prev

@@ -80,6 +80,59 @@ class NeighborSearchResult:
     def __len__(self):
         return 3
 
+class PaddedNeighborList(NeighborSearchResult):
+    """Result of the single-pass search (dmcf_frs_search_padded): row i lives at ``index[i * stride ...]`` with
+    ``counts[i]`` entries; no count pass, no prefix scan, no host round trip.  ``raw()`` / ``row_count`` feed the
+    kernels directly; the Open3D-style attributes compact the rows on first use (one synchronisation)."""
+
+    def __init__(self, index_buf, row_begin, dist_buf, counts, max_count, stride, redo_exact):
+        super().__init__(index_buf, row_begin, dist_buf, total=None, redo=None)
+        self.row_count = counts          # int32 [m]
+        self.max_count = max_count       # int32 [1] on the device: largest unclamped row
+        self.stride = int(stride)
+        self._redo_exact = redo_exact
+        self._compact = None
+
+    @property
+    def total_ref(self):
+        return self.row_count.sum()
+
+    def overflowed(self, max_count):
+        return max_count > self.stride
+
+    def resolve(self):
+        if self._compact is None:
+            if int(self.max_count.item()) > self.stride:  # truncated rows: the exact two-pass search instead
+                self._compact = self._redo_exact()
+            else:
+                m = self.row_count.shape[0]
+                cnt = self.row_count.long()
+                rs = torch.zeros(m + 1, dtype=torch.int64, device=cnt.device)
+                torch.cumsum(cnt, 0, out=rs[1:])
+                total = int(rs[-1].item())
+                row = torch.repeat_interleave(torch.arange(m, device=cnt.device), cnt, output_size=total)
+                src = row * self.stride + (torch.arange(total, device=cnt.device) - rs[:-1][row])
+                dist = self._dist_buf[src] if self._dist_buf.shape[0] else self._dist_buf
+                self._compact = NeighborSearchResult(self._index_buf[src], rs, dist, total=total)
+        return self._compact
+
+    @property
+    def neighbors_index(self):
+        return self.resolve().neighbors_index
+
+    @property
+    def neighbors_distance(self):
+        return self.resolve().neighbors_distance
+
+    @property
+    def csr_row_splits(self):
+        return self.resolve().neighbors_row_splits
+
+    def __iter__(self):
+        c = self.resolve()
+        return iter((c.neighbors_index, c.neighbors_row_splits, c.neighbors_distance))
+
+
 MAPPINGS = {"ball_to_cube_radial": 0, "ball_to_cube_volume_preserving": 1, "identity": 2}
 INTERPOLATIONS = {"linear": 0, "linear_border": 1, "nearest_neighbor": 2}
 WINDOWS = {None: 0, "explicit": 1, "poly6": 2, "cubic": 3, "linear": 4, "peak": 5, "cubic_grad": 6}
@@ -181,12 +234,14 @@ def pair_capacity(total):
 
 
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
-                        hash_table=None, capacity_hint=None):
+                        hash_table=None, capacity_hint=None, row_stride=None):
     """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
     neighbors_distance float32 [P] (squared L2; empty if not return_distances)).
 
     ``capacity_hint``: an estimate of P.  With it count, scan and write are enqueued back to back with buffers of
-    that size and NO host synchronisation; the result is validated later (see NeighborSearchResult)."""
+    that size and NO host synchronisation; the result is validated later (see NeighborSearchResult).
+    ``row_stride``: an upper bound of the row lengths.  With it ONE pass writes padded rows (PaddedNeighborList): no
+    count pass at all; validated later through ``max_count``."""
     L = _lib.lib()
     points = _dev_f32(points, "points", 3)
     queries = _dev_f32(queries, "queries", 3)
@@ -203,6 +258,27 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     dev = points.device
     row_splits = torch.empty(m + 1, dtype=torch.int64, device=dev)
     t0 = timer.begin() if timer is not None else None
+    if row_stride is not None:
+        stride = max(int(row_stride), 1)
+        # allocation sizes in coarse buckets (see pair_capacity): the lattice point sets change size every step
+        need = m * stride
+        g = max(1 << 16, 1 << max(need.bit_length() - 4, 0))
+        cap = (need + g - 1) // g * g
+        index = torch.empty(cap, dtype=torch.int32, device=dev)
+        dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
+        counts = torch.empty(m, dtype=torch.int32, device=dev)
+        max_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.dmcf_frs_search_padded(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, stride, _ptr(row_splits),
+                                            _ptr(counts), _ptr(index), _ptr(dist) if return_distances else None,
+                                            _ptr(max_count), _stream()), "dmcf_frs_search_padded")
+        keep = (points, queries, ws)  # noqa: F841
+        res = PaddedNeighborList(index, row_splits, dist, counts, max_count, stride,
+                                 lambda: fixed_radius_search(points, queries, radius, ignore_query_point, return_distances,
+                                                             hash_table))
+        if timer is not None:
+            timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
+            timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
+        return res
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
     if timer is not None:
@@ -249,14 +325,14 @@ class FixedRadiusSearch:
         self.max_hash_table_size = max_hash_table_size
 
     def __call__(self, points, queries, radius, points_row_splits=None, queries_row_splits=None,
-                 hash_table_size_factor=1 / 64, hash_table=None, capacity_hint=None):
+                 hash_table_size_factor=1 / 64, hash_table=None, capacity_hint=None, row_stride=None):
         if points_row_splits is not None or queries_row_splits is not None:
             raise NotImplementedError("batched row_splits are not used by DMCF (batch items are looped, "
                                       "pipelines/simulator.py:68-70)")
         if isinstance(radius, torch.Tensor):
             radius = float(radius)
         return fixed_radius_search(points, queries, radius, self.ignore_query_point, self.return_distances,
-                                   hash_table=hash_table, capacity_hint=capacity_hint)
+                                   hash_table=hash_table, capacity_hint=capacity_hint, row_stride=row_stride)
 
     call = __call__
 
@@ -267,7 +343,7 @@ def _empty(t):
 
 def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                 neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
-                normalize, symmetric, sym_axis, bias, out, accumulate, geometry):
+                normalize, symmetric, sym_axis, bias, out, accumulate, geometry, neighbors_row_count=None):
     """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
@@ -324,7 +400,13 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     a.out = None if out is None else out.data_ptr()
     a.geometry = None if geometry is None else geometry.data_ptr()
     a.n_pairs = neighbors_index.shape[0]
-    keep = (filters, out_positions, inp_positions, inp_features, inp_importance, neighbors_index, neighbors_row_splits,
+    a.neighbors_row_count = None
+    if neighbors_row_count is not None:
+        if neighbors_row_count.dtype != torch.int32 or neighbors_row_count.shape[0] != n_out:
+            raise TypeError("neighbors_row_count must be int32 [n_out]")
+        neighbors_row_count = neighbors_row_count.contiguous()
+        a.neighbors_row_count = neighbors_row_count.data_ptr()
+    keep = (neighbors_row_count, filters, out_positions, inp_positions, inp_features, inp_importance, neighbors_index, neighbors_row_splits,
             neighbors_value, bias, out, geometry)
     return a, keep
 
@@ -358,8 +440,8 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
                   normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None,
-                  n_pairs_ref=None):
-    """One call of dmcf_cconv_forward.  ``window``: None | 'explicit' (neighbors_value = importance) |
+                  n_pairs_ref=None, neighbors_row_count=None):
+    """One call of dmcf_cconv_forward.  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
     ``geometry``: optional result of :func:`cconv_geometry` for the same operands."""
     L = _lib.lib()
@@ -373,7 +455,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
-                          geometry)
+                          geometry, neighbors_row_count)
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None
@@ -424,7 +506,11 @@ def reduce_subarrays_sum(values, row_splits):
 
 def neighbor_counts(row_splits):
     """``reduce_subarrays_sum(ones_like(neighbors_index), row_splits)`` without materialising the ones
-    (models/pbf_model.py:450-453): float32 neighbour count per row."""
+    (models/pbf_model.py:450-453): float32 neighbour count per row.  Also accepts a search result."""
+    if isinstance(row_splits, PaddedNeighborList):
+        return row_splits.row_count.to(torch.float32)
+    if isinstance(row_splits, NeighborSearchResult):
+        row_splits = row_splits.neighbors_row_splits
     L = _lib.lib()
     if row_splits.dtype != torch.int64 or not row_splits.is_cuda:
         raise _lib.DmcfError("row_splits must be an int64 GPU tensor")

@@ -61,16 +61,23 @@ class _NeighborCache:
             self.geometries.clear()
             self.keepalive.clear()
             if exc_type is None and pending:
-                # one synchronisation per step: validate the estimated buffer sizes, refresh the estimates
-                totals = torch.stack([r.total_ref for _, r in pending]).tolist()
+                # one synchronisation per step: validate the estimated row capacities, refresh the estimates
+                # (hint = the longest row of the list)
+                def longest(r):
+                    if isinstance(r, ops.PaddedNeighborList):
+                        return r.max_count[0].long()
+                    rs = r.neighbors_row_splits
+                    return torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(())
+                maxima = torch.stack([longest(r) for _, r in pending]).tolist()
                 bad = False
-                for (slot, r), total in zip(pending, totals):
-                    bad |= r.overflowed(total)
+                for (slot, r), mx in zip(pending, maxima):
+                    if isinstance(r, ops.PaddedNeighborList):
+                        bad |= r.overflowed(mx)
                     while len(self.hints) <= slot:
                         self.hints.append(None)
-                    self.hints[slot] = total
+                    self.hints[slot] = int(mx)
                 if bad:
-                    raise ops.NeighborCapacityExceeded("a neighbour list outgrew its estimated buffer; repeat the step")
+                    raise ops.NeighborCapacityExceeded("a neighbour row outgrew its estimated capacity; repeat the step")
         return False
 
     @staticmethod
@@ -94,10 +101,10 @@ class _NeighborCache:
         slot, self.order = self.order, self.order + 1
         hint = self.hints[slot] if (self.use_hints and slot < len(self.hints)) else None
         if hint is not None:
-            # 1/8 + 64 Ki pairs of slack over the previous step's count (HBM is plentiful: 288 GB); an overflow is
-            # detected at the end of the step (one sync) and the step is repeated with exact sizes.  Measured on the
-            # 1M-particle box: neighbour counts can grow by 2-3 % per step while the initial lattice relaxes.
-            res = frs(points, queries, radius, hash_table=table, capacity_hint=hint)
+            # Padded rows of (longest row of the previous step) * 1.25 + 8 entries: ONE candidate scan per query, no
+            # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
+            # stride is detected at the end of the step (one sync) and the step is repeated with the exact search.
+            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint))
         else:
             res = frs(points, queries, radius, hash_table=table)
         self.pending.append((slot, res))
@@ -160,6 +167,14 @@ def neighbor_cache(estimate=False):
 def neighbor_hints():
     """The per-slot pair-count estimates of the process-wide cache (tests / diagnostics)."""
     return _CACHE.hints
+
+
+def row_stride(longest):
+    """Row capacity for the padded single-pass search from the longest row of the previous step: 1/4 slack, rounded up
+    to 1/8 of the enclosing power of two (a handful of distinct buffer sizes for the caching allocator)."""
+    x = int(longest) + int(longest) // 4 + 8
+    g = max(8, 1 << max(x.bit_length() - 4, 0))  # 1/8 of the enclosing power of two
+    return (x + g - 1) // g * g
 
 
 def _init_tensor(name, shape, device):
@@ -286,7 +301,7 @@ class ContinuousConv(torch.nn.Module):
             extent = float(extents)
         else:
             extent = float(np.float32(extents))
-        window, window_fac, neighbors_value, n_pairs_ref = None, 1.0, None, None
+        window, window_fac, neighbors_value, n_pairs_ref, row_count = None, 1.0, None, None, None
         if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :341-349
             neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
             if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
@@ -300,6 +315,7 @@ class ContinuousConv(torch.nn.Module):
                 self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
             # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
+            row_count = getattr(self.nns, "row_count", None)  # padded rows of the single-pass search
             n_pairs_ref = self.nns.total_ref
             if self.window_function is not None:  # :359-379
                 if isinstance(self.window_function, WindowFunction):
@@ -307,7 +323,9 @@ class ContinuousConv(torch.nn.Module):
                     neighbors_value = raw_dist  # d^2; q = d^2/R^2 is formed in the kernel
                 else:
                     q = self.nns.neighbors_distance / (np.float32(radius) * np.float32(radius))
-                    neighbors_index = self.nns.neighbors_index
+                    neighbors_index = self.nns.neighbors_index  # compact CSR form (synchronises)
+                    if row_count is not None:
+                        neighbors_row_splits, row_count = self.nns.csr_row_splits, None
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
         # stats (convolutions.py:385-388) are formed lazily (property _avg_neighbors): no host sync here
         self._n_out_last = out_positions.shape[0]
@@ -333,7 +351,7 @@ class ContinuousConv(torch.nn.Module):
             raise NotImplementedError("symmetric=True with normalize=True (DMCF always uses normalize=False, "
                                       "models/pbf_model.py:203)")
         geometry = None
-        if (USE_GEOMETRY_CACHE and self.nns is not None and user_neighbors_index is None
+        if (USE_GEOMETRY_CACHE and self.nns is not None and user_neighbors_index is None and row_count is None
                 and window not in (None, "explicit")
                 and inp_importance is None and not self.circular
                 and ops.geometry_supported(self.align_corners, self.coordinate_mapping, self.interpolation)):
@@ -352,7 +370,8 @@ class ContinuousConv(torch.nn.Module):
             neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
-            bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref)
+            bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref,
+            neighbors_row_count=row_count)
         self._conv_output = out_features
         if self.use_dense_layer_for_center:  # :462-464
             self._dense_output = inp_features @ self.dense
@@ -404,7 +423,7 @@ class PointSampling(torch.nn.Module):
         if isinstance(extents, torch.Tensor) and extents.dim() > 0 and extents.numel() != 1:
             raise NotImplementedError("per-point extents (RadiusSearch, convolutions.py:1006-1010) are not implemented")
         extent = float(np.float32(float(extents)))
-        window, window_fac, neighbors_value, n_pairs_ref = None, 1.0, None, None
+        window, window_fac, neighbors_value, n_pairs_ref, row_count = None, 1.0, None, None, None
         if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :984-993
             neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
             if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
@@ -417,6 +436,7 @@ class PointSampling(torch.nn.Module):
             else:
                 self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
+            row_count = getattr(self.nns, "row_count", None)
             n_pairs_ref = self.nns.total_ref
             if self.window_function is not None:  # :1015-1019
                 if isinstance(self.window_function, WindowFunction):
@@ -424,6 +444,8 @@ class PointSampling(torch.nn.Module):
                 else:
                     q = self.nns.neighbors_distance / (np.float32(radius) * np.float32(radius))
                     neighbors_index = self.nns.neighbors_index
+                    if row_count is not None:
+                        neighbors_row_splits, row_count = self.nns.csr_row_splits, None
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
         self._n_out_last = out_positions.shape[0]
         self._pairs_last = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
@@ -432,7 +454,8 @@ class PointSampling(torch.nn.Module):
         out = ops.cconv_forward(self.kernel, out_positions, extent, inp_positions, inp_features, neighbors_index,
                                 neighbors_row_splits, neighbors_value=neighbors_value, window=window, window_fac=window_fac,
                                 inp_importance=inp_importance, align_corners=False, coordinate_mapping="ball_to_cube_radial",
-                                interpolation="linear", normalize=self.normalize, n_pairs_ref=n_pairs_ref)
+                                interpolation="linear", normalize=self.normalize, n_pairs_ref=n_pairs_ref,
+                                neighbors_row_count=row_count)
         self._conv_output = out
         return out
 

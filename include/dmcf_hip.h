@@ -89,6 +89,18 @@ int dmcf_frs_write(const float* queries, int64_t n_queries, int64_t n_points, fl
                    int32_t* neighbors_index, float* neighbors_distance, int64_t pair_capacity,
                    dmcf_stream_t stream);
 
+/* Single-pass search into PADDED rows, for callers that know an upper bound of the row lengths (a rollout takes the
+ * largest row of the previous time step + slack): row i is written at neighbors_index[i * row_stride ...], its length
+ * (clamped to row_stride) goes to row_count[i], row_begin[i] = i * row_stride for i = 0..n_queries, and the largest
+ * unclamped length is max-ed into *max_count (a device int32 the caller zeroed) -- max_count > row_stride means rows
+ * were truncated and the caller must repeat with a larger stride or with dmcf_frs_count / dmcf_frs_write.  No count
+ * pass, no prefix scan: one candidate scan per query.  Same neighbours in the same order per row as dmcf_frs_write;
+ * dmcf_cconv_forward consumes the result through args->neighbors_row_count. */
+int dmcf_frs_search_padded(const float* queries, int64_t n_queries, int64_t n_points, float radius, int flags,
+                           const void* workspace, size_t workspace_bytes, int64_t row_stride, int64_t* row_begin,
+                           int32_t* row_count, int32_t* neighbors_index, float* neighbors_distance, int32_t* max_count,
+                           dmcf_stream_t stream);
+
 /* compute_density (utils/tools/losses.py:285-306; models/pbf_model.py:351-355, pipelines/simulator.py:227-243):
  *   out[q] = sum over the points p within `radius` of query q of window(|p - q|^2 / radius^2)
  * evaluated inside the candidate scan of the search -- the pair list is never materialised.  `window` is a
@@ -161,6 +173,9 @@ typedef struct dmcf_cconv_args {
     const void* geometry;
     int64_t n_pairs;            /* entries in neighbors_index / neighbors_value (>= P = neighbors_row_splits[n_out]);
                                  * rows reaching past it are treated as empty (see dmcf_frs_write pair_capacity) */
+    const int32_t* neighbors_row_count; /* optional [n_out]: PADDED lists as written by dmcf_frs_search_padded -- row i is
+                                   neighbors_index[row_splits[i] .. row_splits[i] + row_count[i]); NULL = CSR rows
+                                   [row_splits[i], row_splits[i+1]) */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);

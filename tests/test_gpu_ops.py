@@ -564,3 +564,36 @@ def test_farthest_point_sample_matches_oracle(oracle, dev, kind, n, m):
     feats = rng.normal(size=(p.shape[0], 5)).astype(np.float32)
     got = ops.gather_point(_t(feats, dev).unsqueeze(0), idx)[0].cpu().numpy()
     assert np.array_equal(got, feats[ref])
+
+
+@pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
+                                                ("direct", 32, 3, (6, 6, 6)), ("lds", 4, 8, (3, 5, 2))])
+def test_padded_single_pass_search_and_conv(dev, monkeypatch, kernel, cin, cout, ks):
+    """dmcf_frs_search_padded (one pass, rows at a fixed stride, no count pass) holds the same neighbours in the same order
+    as the two-pass search, and every CConv kernel gives bit-identical results on the padded list (args->neighbors_row_count)
+    and on the CSR list.  A stride that is too small is detected and the public attributes fall back to the exact search."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
+    rng = np.random.default_rng(9)
+    dim = 2 if ks[0] == 1 else 3
+    inp, out = _cloud(5000, 61, dim), _cloud(1201, 62, dim)
+    radius = 0.3 if dim == 3 else 0.12
+    P, Q = _t(inp, dev), _t(out, dev)
+    exact = ops.fixed_radius_search(P, Q, radius, return_distances=True)
+    longest = int(torch.diff(exact.neighbors_row_splits).max())
+    pad = ops.fixed_radius_search(P, Q, radius, return_distances=True, row_stride=longest + 5)
+    assert isinstance(pad, ops.PaddedNeighborList) and int(pad.max_count) == longest and not pad.overflowed(longest)
+    assert torch.equal(pad.row_count.long(), torch.diff(exact.neighbors_row_splits))
+    assert torch.equal(pad.neighbors_index, exact.neighbors_index) and torch.equal(pad.neighbors_distance, exact.neighbors_distance)
+    assert torch.equal(pad.csr_row_splits, exact.neighbors_row_splits)
+    feat = _t(rng.normal(size=(5000, cin)).astype(np.float32), dev)
+    W = _t(rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32), dev)
+    idx, rb, dist = pad.raw()
+    a = ops.cconv_forward(W, Q, 2 * radius, P, feat, exact.neighbors_index, exact.neighbors_row_splits,
+                          neighbors_value=exact.neighbors_distance, window="poly6")
+    b = ops.cconv_forward(W, Q, 2 * radius, P, feat, idx, rb, neighbors_value=dist, window="poly6", neighbors_row_count=pad.row_count)
+    assert torch.equal(a, b)
+    assert torch.equal(ops.neighbor_counts(pad), ops.neighbor_counts(exact.neighbors_row_splits))
+    small = ops.fixed_radius_search(P, Q, radius, return_distances=True, row_stride=max(longest // 2, 1))
+    assert small.overflowed(int(small.max_count)) and int(small.max_count) == longest
+    assert torch.equal(small.neighbors_index, exact.neighbors_index)
