@@ -57,7 +57,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=3)  # the caching allocator reaches its steady state after ~3 steps
     ap.add_argument("--side", type=int, default=100, help="fluid cube edge in particles (100 -> 1M particles)")
     ap.add_argument("--cpu-side", type=int, default=40, help="edge of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--layers-json", default=None, help="write the per-launch table here")
