@@ -37,6 +37,7 @@ import numpy as np
 import torch
 
 from .utils.convolutions import neighbor_cache
+from . import ops
 from .utils.tools.losses import grid_pos
 
 
@@ -250,11 +251,22 @@ class ShardedSimulator:
     # -- one step ----------------------------------------------------------------------------------
     @torch.no_grad()
     def step(self, state):
-        # Estimated neighbour-buffer sizes are NOT used here: an overflow would have to be agreed on by all ranks
-        # before anyone repeats the step (an extra all-reduce per step); the host round trips they save are hidden
-        # by the all-to-all synchronisation points this path has anyway.
-        with neighbor_cache(estimate=False):
-            return self._step(state)
+        """One time step.  Like Simulator.run_inference the searches run with row capacities estimated from the previous
+        step (single pass, no host round trips); whether any rank outgrew an estimate is agreed with ONE tiny all-reduce
+        after the step -- the validation happens when the cache scope closes, i.e. after every collective of the step --
+        and then all ranks repeat the step with the exact search."""
+        try:
+            with neighbor_cache(estimate=True):
+                out = self._step(state)
+            ok = 1
+        except ops.NeighborCapacityExceeded:
+            out, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=state["pos"].device)
+        self.comm.all_reduce(flag, "min")
+        if int(flag.item()) == 0:
+            with neighbor_cache(estimate=False):
+                out = self._step(state)
+        return out
 
     def _step(self, state):
         m, comm = self.model, self.comm

@@ -12,6 +12,7 @@ section 2 row 16).
 """
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -126,7 +127,33 @@ class _NeighborCache:
         return geo
 
 
-_CACHE = _NeighborCache()
+class _PerThreadCache:
+    """One _NeighborCache per thread: the virtual ranks of dmcf_amd.parallel.run_local_ranks are threads of one process and
+    each must see its own step scope, search order and estimates (a real rank is a process and has one anyway)."""
+
+    def __init__(self):
+        object.__setattr__(self, "_tls", threading.local())
+
+    def _get(self):
+        c = getattr(self._tls, "cache", None)
+        if c is None:
+            c = self._tls.cache = _NeighborCache()
+        return c
+
+    def __getattr__(self, name):
+        return getattr(self._get(), name)
+
+    def __setattr__(self, name, value):
+        setattr(self._get(), name, value)
+
+    def __enter__(self):
+        return self._get().__enter__()
+
+    def __exit__(self, *exc):
+        return self._get().__exit__(*exc)
+
+
+_CACHE = _PerThreadCache()
 
 # The per-pair geometry cache (dmcf_cconv_geometry) feeds the LDS-splat kernel; the matrix-core kernel that
 # handles every filter of up to 64 cells recomputes the geometry per 16-channel pass at ~15 % of its MFMA time,
