@@ -3,7 +3,7 @@
 set -u
 OUT=${1:-gpurun_out/pmc_blk}
 mkdir -p $OUT
-export ONLY=L8
+export ONLY=${ONLY:-L8}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 run() { name=$1; shift; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --kernel-include-regex "cconv" --output-format csv -d $OUT/$name -o p -- python tools/microbench.py > $OUT/$name.log 2>&1; }
 run sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS
