@@ -86,9 +86,14 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
     const int nbatch = (cnt_max + 31) / 32;
     float* Brow = Bt + (size_t)pt * KCp;
 
-    // phase-2 lane role inside a half-wave: corner t (bit0 x, bit1 y, bit2 z) x 4 channel groups
+    // phase-2 lane role inside a half-wave: corner x 4 channel groups.  The corner bits of the lane can be (x, Z, y)
+    // instead of (x, y, z): a 64-bit LDS store is served in groups of 16 lanes = 4 corners against 32 banks, and with a 4-wide
+    // filter the +y corner is 32 floats away (same banks, a 2-way conflict on every store) while the +z corner is one
+    // padded plane away (make_cfg puts it 16 banks off): grouping (x, z) makes the stores conflict free.
     constexpr int CPL = CC / 4;  // channels per lane (2 -> 64-bit read-modify-write, 1 -> 32-bit)
-    const int t = pl >> 2, c4 = pl & 3;
+    const int lt = pl >> 2, c4 = pl & 3;
+    // staged-weight index (bit0 x, bit1 y, bit2 z) of this lane's corner; make_cfg picks the grouping per filter shape
+    const int t = p.zgroup ? ((lt & 1) | ((lt & 4) >> 1) | ((lt & 2) << 1)) : lt;
     const int tx = (t & 1) && p.sx >= 2, ty = ((t >> 1) & 1) && p.sy >= 2, tz = ((t >> 2) & 1) && p.sz >= 2;
     const int lane_off = tz * PS + (ty * p.sx + tx) * CC + c4 * CPL;  // this corner's offset from the base cell
     // a "+1" corner along an axis of size 1 has weight 0 and would alias the base cell: such lanes stay idle
@@ -426,7 +431,7 @@ __global__ void pack_filter(const float* __restrict__ src, float* __restrict__ d
 }
 
 struct LaunchCfg {
-    int CC, PS, KCp, nblocks, NT, nchunks;
+    int CC, PS, KCp, nblocks, NT, nchunks, zgroup;
     size_t lds, packed_floats, bfloats;
 };
 
@@ -438,7 +443,7 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
     // in the LDS bank models of the splat's accesses (CC = 8: 64-bit reads see 64 banks over the 8 corners of
     // a half-wave, 64-bit writes 32 banks over 4 corners at a time; CC = 4: 32-bit accesses, 32 banks over all
     // 8 corners), while one workgroup's B tile still fits.
-    auto conflicts = [&](int PS) {
+    auto conflicts = [&](int PS, int zgroup) {
         int bad = 0;
         for (int by = 0; by < 2; ++by)
             for (int bx = 0; bx < 2; ++bx) {
@@ -452,7 +457,9 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
                         if (off[a] == off[b]) continue;  // collapsed corners are masked off in the kernel
                         const int rd = c.CC == 8 ? 64 : 32;
                         if ((off[a] % rd) / c.CC == (off[b] % rd) / c.CC) ++bad;                        // read model
-                        if ((a < 4) == (b < 4) && (off[a] % 32) / c.CC == (off[b] % 32) / c.CC) ++bad;  // write model
+                        // write model: a 16-lane store group holds the 4 corners with equal z bit, or (zgroup) equal y bit
+                        const int ga = zgroup ? (a >> 1) & 1 : a >> 2, gb = zgroup ? (b >> 1) & 1 : b >> 2;
+                        if (ga == gb && (off[a] % 32) / c.CC == (off[b] % 32) / c.CC) ++bad;
                     }
             }
         return bad;
@@ -468,15 +475,17 @@ static LaunchCfg make_cfg(int sx, int sy, int sz, int cin, int cout) {
     };
     const int PS0 = (PR + 7) / 8 * 8;
     const size_t step = lds_bytes(PS0) <= 80 * 1024 ? 80 * 1024 : 160 * 1024;  // keep the occupancy step of the unpadded tile
-    int best = PS0, best_bad = 1 << 30;
-    for (int k = 0; k < 12; ++k) {
-        const int PS = PS0 + 8 * k;
-        if (k > 0 && (sz < 2 || lds_bytes(PS) > step)) break;
-        const int bad = conflicts(PS);
-        if (bad < best_bad) { best_bad = bad; best = PS; }
-        if (bad == 0) break;
-    }
+    int best = PS0, best_bad = 1 << 30, best_group = 0;
+    for (int zgroup = 0; zgroup < 2 && best_bad > 0; ++zgroup)
+        for (int k = 0; k < 12; ++k) {
+            const int PS = PS0 + 8 * k;
+            if (k > 0 && (sz < 2 || lds_bytes(PS) > step)) break;
+            const int bad = conflicts(PS, zgroup);
+            if (bad < best_bad) { best_bad = bad; best = PS; best_group = zgroup; }
+            if (bad == 0) break;
+        }
     c.PS = best;
+    c.zgroup = best_group;
     const int KC = (sz * c.PS + 15) / 16 * 16;  // multiple of 16 (k blocks of the contraction)
     c.nblocks = KC / 16;
     // row stride == 4 (mod 64) floats: the 16 rows read by one ds_read_b128 of the contraction spread over all banks
@@ -602,6 +611,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
     p.KCp = cfg.KCp;
     p.PS = cfg.PS;
+    p.zgroup = cfg.zgroup;
     p.nblocks = cfg.nblocks;
     p.NT = cfg.NT;
     p.nchunks = cfg.nchunks;

@@ -28,6 +28,7 @@ struct CconvParams {
     const float* bias;
     float* out;
     int PS;        // plane stride of B in floats (see cell_offset)
+    int zgroup;    // LDS splat: corner bits of the phase-2 lanes are (x, z, y) instead of (x, y, z)
     int KCp;       // row stride of B in floats: sz*PS padded to 4 (mod 64)
     int nblocks;   // sz*PS/16 : 16-wide k blocks per chunk
     int NT;        // ceil(cout/16)
