@@ -553,6 +553,8 @@ size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
     if (floats < mf) floats = mf;
     const size_t bf = cconv_blk_packed_floats(a->filter_dims[3], a->filter_dims[4]);
     if (floats < bf) floats = bf;
+    const size_t cf = cconv_cls_packed_floats(a->filter_dims[3], a->filter_dims[4]);
+    if (floats < cf) floats = cf;
     const size_t df = cconv_direct_packed_floats(dz, dy, dx, a->filter_dims[3]);
     if (floats < df) floats = df;
     return 256 + align_up(floats * sizeof(float), 256);
@@ -607,6 +609,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.bias = a->bias;
     p.out = a->out;
     if (cconv_direct_eligible(a, dz, dy, dx)) return cconv_direct_launch(p, a, dz, dy, dx, workspace, stream);
+    if (cconv_cls_eligible(a, dz, dy, dx)) return cconv_cls_launch(p, a, workspace, stream);
     if (cconv_blk_eligible(a, dz, dy, dx)) return cconv_blk_launch(p, a, workspace, stream);
     if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
     p.KCp = cfg.KCp;

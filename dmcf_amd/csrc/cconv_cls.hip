@@ -1,0 +1,492 @@
+// CConv / ASCC for 4x4x4 filters: CLASS-SORTED splat on v_mfma_f32_16x16x4_f32, four neighbour pairs per instruction.
+//
+// A pair's trilinear footprint is 2 x 2 x 2 cells of the 4 x 4 x 4 filter.  Pairs with the same base plane bz and
+// base row by -- one of 9 classes -- only touch the 16 cells (z' in 0..1, y' in 0..1, x in 0..3) of the tile
+// (bz + z', by + y', x), and for such pairs the splat is a dense rank-4 update per instruction
+//
+//     D[m = (z', y', x)][n = channel] += sum_k A[m][k] F[k][n],     A[m][k] = hat(X_k - x) * w_k[z'][y'],
+//
+// with k = 4 pairs of the class and w = window * (1 -+ fz) * (1 -+ fy).  That is 8 clocks of matrix core per pair and
+// 16 channels (half of the products are useful), against 16 for the pair-per-instruction form (cconv_blk.hip) and
+// 32 for the unsorted 64-cell form (cconv_mfma.hip); the operands need four VALU operations per instruction.
+//
+// Per batch of 64 pairs a wave: computes the geometry (lane = pair, as in the other kernels), orders the pairs by
+// class with 9 ballots (classes are padded to multiples of 4 with zero-weight slots), pushes {X, w[4]} and the
+// neighbour index to the pair's slot of the ordered batch in LDS, stages the feature rows of the ordered slots
+// (16-byte loads issued half a batch ahead) and runs 9 inner loops with fixed accumulator tiles: 36 VGPRs hold the
+// whole 64-cell x 16-channel B_i of the output point.  When a point is done its 9 tiles are merged into the point's
+// row of the B tile [16 points][64 cells x 16 channels] in LDS (4-float read-modify-writes), which the contraction
+// with the packed filter reads as in cconv_blk.hip.
+//
+// LDS (80 KB per workgroup, two workgroups per CU): B tile 64 KB + 2 KB per wave for {X, w}; the feature staging
+// (48 slots x 16 channels) and the two index buffers live in the B row of the wave's SECOND point, which is free
+// until that point's tiles are merged.
+//
+// Accumulation order = the ordered-batch order (stable inside a class): deterministic.
+#include <stdlib.h>
+
+#include "cconv_common.h"
+
+namespace dmcf {
+
+constexpr int kCWaves = 8;
+constexpr int kCThreads = 64 * kCWaves;
+constexpr int CTM = 2 * kCWaves;  // output points per workgroup = rows of the B tile
+constexpr int kCRows = 16;        // M of the contraction MFMA
+constexpr int CCH = 16;           // channels per pass
+constexpr int kCRow = 1024;       // floats per B row: k' = (z * 4 + y) * 64 + channel * 4 + x
+constexpr int kSlots = 96;        // slots of an ordered batch: 64 pairs + at most 3 padding slots per class
+constexpr int kHalfSlots = 48;    // feature staging holds half of them
+constexpr int kGrp = 20;          // floats per group of 4 slots: w[4][4], X[4]
+constexpr int kXst = 512;         // floats per wave outside the B tile: 24 groups
+constexpr int kCMaxNT = 4;
+constexpr int kNoPair = 9;
+
+struct ClsRec {  // per pair, in the registers of the owner lane
+    float x;     // clamped filter coordinate in [0, 3]
+    f32x4 w;     // window * wz(z') * wy(y'), index 2 z' + y'
+};
+
+__device__ __forceinline__ uint32_t cls_lds_addr(const void* q) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)q;
+}
+
+// cross-lane communication through LDS inside a wave: keeps the compiler from reordering around it
+__device__ __forceinline__ void xfence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int NTT>
+__global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cin = p.cin, cout = p.cout;
+    float* Bt = smem;                                 // [CTM][kCRow], 4-float groups XOR-swizzled by the row
+    float* Gs = smem + CTM * kCRow + wave * kXst;     // [24][kGrp]
+    unsigned char* Cst = (unsigned char*)(Gs + 24 * kGrp);  // [24]: class of each group
+    float* Fst = Bt + (wave + kCWaves) * kCRow;       // [48][16] in the row of this wave's second point
+    int* Jst = (int*)(Fst + kHalfSlots * 16);         // [96]
+    const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
+    if (tile >= p.ntiles) return;
+    const int64_t pt0 = (int64_t)tile * CTM;
+    const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
+
+    // splat roles (A / B operands of 16x16x4): tile row m = lane & 15 = (z', y', x), pair k = lane >> 4, channel lane & 15
+    const int mk = lane >> 4, mn = lane & 15;
+    const float xm = (float)(lane & 3);
+    const int widx = (lane >> 2) & 3;
+    // feature load roles: lane -> (slot in a group of 16, 4 channels)
+    const int fr = lane >> 2, fc4 = lane & 3;
+    // contraction roles
+    const int mi = lane & 15, mg = lane >> 4;
+    const uint32_t gs_lds = cls_lds_addr(Gs), fst_lds = cls_lds_addr(Fst);
+    const float* zero4 = p.Wp + (size_t)p.nchunks * 64 * (4 * p.NT * 16 * 4);
+
+    f32x4 acc[NTT];
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int c0 = chunk * CCH;
+        const int nch = min(CCH, cin - c0);
+        const bool fch_ok = c0 + 4 * fc4 < cin;
+        const int fch = fch_ok ? c0 + 4 * fc4 : 0;
+        // The batches of the wave's two points form ONE stream (point A's batches, then point B's): index, position and
+        // feature loads run ahead across the point boundary, so a point's first batch does not start with four dependent
+        // round trips to memory.
+        int64_t rbs[2];
+        int nts[2], nbs[2];
+        float oxs[2], oys[2], ozs[2];
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp) {
+            const int64_t i = pt0 + wave + kCWaves * pp;
+            rbs[pp] = 0;
+            nts[pp] = 0;
+            oxs[pp] = oys[pp] = ozs[pp] = 0.0f;
+            if (i < p.n_out) {
+                const int64_t rb = p.rs[i];
+                int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
+                if (re > p.pair_cap) re = rb;
+                rbs[pp] = rb;
+                nts[pp] = (int)min(re - rb, (int64_t)0x7fffffc0);
+                oxs[pp] = p.out_pos[3 * i];
+                oys[pp] = p.out_pos[3 * i + 1];
+                ozs[pp] = p.out_pos[3 * i + 2];
+            }
+            nbs[pp] = (nts[pp] + 63) >> 6;
+        }
+        const int nbA = nbs[0], NB = nbs[0] + nbs[1];
+        f32x4 tl[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+
+        // batch t of the stream -> is this lane's pair valid, and where is it
+        auto where = [&](int t, int& pp, int64_t& at) -> bool {
+            pp = t >= nbA ? 1 : 0;
+            const int o = 64 * (t - (pp ? nbA : 0)) + lane;
+            at = (pp ? rbs[1] : rbs[0]) + o;
+            return t < NB && o < (pp ? nts[1] : nts[0]);
+        };
+        auto ld_idx = [&](int t, int& j, float& nv) {
+            int pp;
+            int64_t at;
+            j = 0;
+            nv = 0.0f;
+            if (where(t, pp, at)) {
+                j = p.idx[at];
+                if (p.nval && !(p.KT & 16)) nv = p.nval[at];
+            }
+        };
+        auto ld_pos = [&](int t, int j, float& x, float& y, float& z) {
+            int pp;
+            int64_t at;
+            x = y = z = 0.0f;
+            if (where(t, pp, at) && !(p.KT & 8)) {
+                x = p.inp_pos[3 * (int64_t)j];
+                y = p.inp_pos[3 * (int64_t)j + 1];
+                z = p.inp_pos[3 * (int64_t)j + 2];
+            }
+        };
+        auto geom = [&](int t, int j, float nv, float x, float y, float z, int& cls) -> ClsRec {
+            ClsRec c = {0.0f, {0.0f, 0.0f, 0.0f, 0.0f}};
+            cls = kNoPair;
+            int pp;
+            int64_t at;
+            if (where(t, pp, at)) {
+                x -= pp ? oxs[1] : oxs[0];
+                y -= pp ? oys[1] : oys[0];
+                z -= pp ? ozs[1] : ozs[0];
+                float a = window_value(p.window, nv, p.inv_r2, p.window_fac);
+                if (p.inp_imp) a *= p.inp_imp[j];
+                filter_coords<false>(x, y, z, p);
+                c.x = fminf(3.0f, fmaxf(0.0f, x));
+                y = fminf(3.0f, fmaxf(0.0f, y));
+                z = fminf(3.0f, fmaxf(0.0f, z));
+                const float yf = fminf(floorf(y), 2.0f), zf = fminf(floorf(z), 2.0f);
+                const float fy = y - yf, fz = z - zf;
+                cls = 3 * (int)zf + (int)yf;
+                const float a0 = a * (1.0f - fz), a1 = a * fz;
+                c.w = (f32x4){a0 * (1.0f - fy), a0 * fy, a1 * (1.0f - fy), a1 * fy};
+            }
+            return c;
+        };
+        // Ordered batch: class c occupies slots [cb[c], cb[c + 1]), a multiple of 4 long; the lanes of a class keep
+        // their order.  cb[] is wave uniform.
+        struct Order {
+            int pos;     // slot of this lane's pair (lanes without a pair: unused)
+            int cb[10];
+        };
+        auto order = [&](int cls) -> Order {
+            Order o;
+            o.pos = 0;
+            int base = 0;
+            if (p.KT & 128) {
+                o.pos = lane;
+                for (int c = 0; c < 10; ++c) o.cb[c] = c > 4 ? 64 : 0;
+                return o;
+            }
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const uint64_t m = __ballot(cls == c);
+                const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+                o.pos = cls == c ? rank : o.pos;
+                o.cb[c] = base;
+                base += (__builtin_popcountll(m) + 3) & ~3;
+            }
+            o.cb[9] = base;
+            return o;
+        };
+        auto push_index = [&](int j, int cls, int pos) {
+            Jst[lane] = -1;
+            if (lane < kSlots - 64) Jst[64 + lane] = -1;
+            xfence();
+            if (cls != kNoPair) Jst[pos] = j;
+        };
+        auto push_rec = [&](const ClsRec& c, int cls, int pos) {
+            if (p.KT & 32) return;
+            *(f32x4*)(Gs + 4 * lane) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0, X 0
+            if (lane < kGrp * 6 - 64) *(f32x4*)(Gs + 4 * (64 + lane)) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            xfence();
+            if (cls != kNoPair) {
+                float* g = Gs + (pos >> 2) * kGrp + (pos & 3);
+                g[16] = c.x;
+                *(f32x4*)(g + 3 * (pos & 3)) = c.w;
+                if ((pos & 3) == 0) Cst[pos >> 2] = (unsigned char)(16 * cls + 12);  // see splat
+            }
+        };
+        // 16-byte feature loads of half h of the ordered batch: three groups of 16 slots, lane = (slot, 4 channels).
+        // Padding slots (index -1), slots past the batch and channels past cin read a block of zeros behind the packed
+        // filter: unconditional loads, nothing for the compiler to wait on before it issues them.
+        auto f_issue = [&](int h, f32x4 (&f)[3]) {
+            if (p.KT & 256) return;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int jj = Jst[kHalfSlots * h + 16 * k + fr];  // -1: padding slot or past the batch
+                const float* src = p.inp_feat + (int64_t)jj * cin + fch;
+                f[k] = *(const f32x4*)((jj >= 0 && fch_ok) ? src : zero4);
+            }
+        };
+        // (the antisymmetric form adds the output point's own features: a padding slot then holds f_i, times weight 0)
+        auto f_publish = [&](int t, const f32x4 (&f)[3]) {
+            if (p.KT & 256) return;
+            f32x4 fi4 = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (symmetric && fch_ok) fi4 = *(const f32x4*)(p.inp_feat + (pt0 + wave + (t >= nbA ? kCWaves : 0)) * cin + fch);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (16 * k + fr) * 16 + 4 * fc4) = f[k] + fi4;
+        };
+        // Splat of half h: the (at most 12) groups at fixed staging addresses -- no address arithmetic -- each into the tile
+        // of its class.  The class of a group is wave uniform: the owner of a group's first slot left it in Cst (as the
+        // byte offset of the class's case), three broadcast reads bring the 12 bytes into scalar registers and a computed
+        // jump picks the in-place matrix instruction.  Hand scheduled (tools/gen_cls_splat.py): with a C++ switch the
+        // compiler copies the nine tiles around every case.
+        auto splat = [&](int h, int nslots) {
+            if (p.KT & 1) return;
+            const int lo = kHalfSlots * h;
+            const int ng = (min(lo + kHalfSlots, nslots) - lo) >> 2;  // wave uniform
+            const uint32_t pw = gs_lds + ((lo >> 2) * kGrp + 4 * mk + widx) * 4;
+            const uint32_t px = gs_lds + ((lo >> 2) * kGrp + 16 + mk) * 4;
+            const uint32_t pf = fst_lds + (16 * mk + mn) * 4;
+            const uint32_t* cw = (const uint32_t*)(Cst + (lo >> 2));
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane(cw[0]), c1 = __builtin_amdgcn_readfirstlane(cw[1]),
+                           c2 = __builtin_amdgcn_readfirstlane(cw[2]);
+            float xa, wa, fa, xb, wb, fb, av;
+            uint32_t sc;
+            asm volatile(
+#include "cconv_cls_splat.inc"
+                : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]),
+                  "+v"(tl[8]), [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
+                  [a] "=&v"(av), [sc] "=&s"(sc)
+                : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2)
+                : "vcc", "scc", "memory");
+        };
+        // Merge the 9 tiles into the point's B row and clear them.  D layout of 16x16x4: lane (group G = lane >> 4 =
+        // (z', y'), channel lane & 15), register r = x  ->  k' = ((bz + z') * 4 + by + y') * 64 + channel * 4 + x.
+        // The four classes with even (bz, by) tile the 16 (z, y) rows exactly: they are plain stores.  The others are added
+        // in three rounds of classes with disjoint rows.
+        auto merge = [&](int pt) {
+            if (p.KT & 64) return;
+            float* Brow = Bt + pt * kCRow;
+            // the tiles were written by hand-issued matrix instructions: cover their write -> VALU read distance here
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+            xfence();  // the staging lives in the row of the second point
+            const int gz = lane >> 5, gy = (lane >> 4) & 1;
+            const int col = (mn ^ (pt & 15)) << 2;
+            auto at = [&](int c) { return (f32x4*)(Brow + ((c / 3 + gz) * 4 + (c % 3) + gy) * 64 + col); };
+            auto put = [&](int c) {
+                *at(c) = tl[c];
+                tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            };
+            auto add = [&](int c) {
+                f32x4* q = at(c);
+                *q = *q + tl[c];
+                tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            };
+            put(0); put(2); put(6); put(8);
+            xfence();  // the next round adds to rows other lanes wrote
+            add(1); add(7);
+            xfence();
+            add(3); add(5);
+            xfence();
+            add(4);
+            xfence();
+        };
+
+        if (nbA == 0) merge(wave);
+        if (NB > 0) {
+            // stages: indices two batches ahead, positions (issued once the indices have had half an iteration to arrive)
+            // and geometry + order + feature loads one batch ahead
+            int jA, jB, cl;
+            float nvA, nvB, px, py, pz;
+            ld_idx(0, jA, nvA);
+            ld_idx(1, jB, nvB);
+            ld_pos(0, jA, px, py, pz);
+            const ClsRec first = geom(0, jA, nvA, px, py, pz, cl);
+            Order oc = order(cl);
+            f32x4 ff[3];
+            push_index(jA, cl, oc.pos);
+            push_rec(first, cl, oc.pos);
+            xfence();
+            f_issue(0, ff);
+            jA = jB;
+            nvA = nvB;
+            ld_pos(1, jA, px, py, pz);
+            for (int t = 0; t < NB; ++t) {
+                // here: (jA, nvA, px, py, pz) = batch t + 1.  Every wait on a load below finds that load the youngest one
+                // outstanding (or the younger ones long issued): the counter the hardware offers is in order.
+                const int nslots = oc.cb[9];
+                const bool two = nslots > kHalfSlots;
+                f_publish(t, ff);
+                ld_idx(t + 2, jB, nvB);
+                // ---- half 0 of this batch; the feature loads of half 1 fly meanwhile
+                if (two) f_issue(1, ff);
+                xfence();
+                splat(0, nslots);
+                // geometry + order of the next batch
+                const ClsRec nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
+                const Order on = order(cl);
+                push_index(jA, cl, on.pos);
+                xfence();
+                // ---- half 1; the positions of batch t + 2 and the feature loads of the next batch's half 0 fly meanwhile
+                if (two) f_publish(t, ff);
+                jA = jB;
+                nvA = nvB;
+                ld_pos(t + 2, jA, px, py, pz);
+                if (t + 1 < NB) f_issue(0, ff);
+                if (two) {
+                    xfence();
+                    splat(1, nslots);
+                }
+                push_rec(nxt, cl, on.pos);
+                oc = on;
+                if (t == nbA - 1) merge(wave);
+            }
+        }
+        merge(wave + kCWaves);
+        __syncthreads();
+        // ---------------- contraction of this channel chunk on the matrix cores ----------------
+        // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4; blocks of channels past the chunk's end are skipped.
+        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
+        const int nq = (nch + 3) >> 2;
+        for (int t = wave; t < 16 * nq; t += kCWaves) {
+            const int blk = (t / nq) * 4 + t % nq;
+            const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % CTM) * kCRow + ((blk * 16 + mg * 4) ^ ((mi % CTM) << 2)));
+            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+#pragma unroll
+            for (int n = 0; n < NTT; ++n) {
+                if (n < p.NT) {
+                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- cross-wave reduction + epilogue ----------------
+    float* red = Bt;  // [kCWaves][kCRows][16*NT]
+    const int ncol = 16 * p.NT;
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) {
+        if (n < p.NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * kCRows + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CTM * cout; e += kCThreads) {
+        const int ptt = e / cout, o = e % cout;
+        const int64_t ii = pt0 + ptt;
+        if (ii >= p.n_out) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kCWaves; ++w) v += red[((size_t)w * kCRows + ptt) * ncol + o];
+        if (p.bias) v += p.bias[o];
+        float* dst = p.out + ii * cout + o;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        *dst = v;
+    }
+}
+
+static constexpr size_t kClsLds = (size_t)(CTM * kCRow + kCWaves * kXst) * sizeof(float);
+
+size_t cconv_cls_packed_floats(int cin, int cout) {
+    const int nchunks = (cin + CCH - 1) / CCH, NT = (cout + 15) / 16;
+    return (size_t)nchunks * 64 * 4 * NT * 16 * 4 + 16;  // + a block of zeros (see f_issue)
+}
+
+// Packs [4][4][4][cin][cout] (optionally mirrored: ASCC, utils/convolutions.py:410-412) into the B-fragment order of
+// v_mfma_f32_16x16x4_f32 for the k' order of the B rows above:
+//   Wp[chunk][blk][g][n][j][q] = W[z][y][x = q][16 chunk + 4 (blk & 3) + g][16 n + j],   z * 4 + y = blk >> 2
+__global__ void pack_filter_cls(const float* __restrict__ src, float* __restrict__ dst, int cin, int cout, int nchunks, int NT,
+                                int symmetric, int sym_axis) {
+    const int64_t total = (int64_t)nchunks * 64 * 4 * NT * 16 * 4 + 16;
+    const int hd[3] = {(symmetric && sym_axis == 0) ? 2 : 4, (symmetric && sym_axis == 1) ? 2 : 4,
+                       (symmetric && sym_axis == 2) ? 2 : 4};
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        int64_t s = e;
+        const int q = (int)(s & 3); s >>= 2;
+        const int j = (int)(s & 15); s >>= 4;
+        const int n = (int)(s % NT); s /= NT;
+        const int g = (int)(s & 3); s >>= 2;
+        const int blk = (int)(s & 63); s >>= 6;
+        const int chunk = (int)s;
+        const int ci = chunk * CCH + 4 * (blk & 3) + g, o = 16 * n + j;
+        float v = 0.0f;
+        if (chunk < nchunks && ci < cin && o < cout) {
+            int c3[3] = {blk >> 4, (blk >> 2) & 3, q};
+            float sign = 1.0f;
+            if (symmetric) {
+                const int hh = hd[sym_axis];
+                if (c3[sym_axis] >= hh) {
+                    c3[sym_axis] -= hh;
+                } else {
+                    sign = -1.0f;
+                    for (int a = 0; a < 3; ++a) c3[a] = hd[a] - 1 - c3[a];
+                }
+            }
+            v = sign * src[((((int64_t)c3[0] * hd[1] + c3[1]) * hd[2] + c3[2]) * cin + ci) * cout + o];
+        }
+        dst[e] = v;
+    }
+}
+
+// Same filters and flags as cconv_blk.hip.  Measured on MI355X against it (16 -> 16 channels): 6.2 ms against 7.3 ms at
+// 3.07e8 pairs / 265 per output, 4.25 against 4.0 ms at 3.3e7 pairs / 29 per output (32 -> 32: one batch per point).
+// Picked for at least 12 input channels; the rule must not look at the list (capacity, padding): the same step gives
+// bit-identical results whichever neighbour-list representation it runs on.
+bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
+    const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma" / "blk" / "cls" / "direct": force one implementation
+    if (e && e[0] != 'c') return false;
+    if (dx != 4 || dy != 4 || dz != 4) return false;
+    if (a->geometry) return false;
+    if (a->coordinate_mapping != DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING || a->interpolation != DMCF_INTERP_LINEAR ||
+        !(a->flags & DMCF_FLAG_ALIGN_CORNERS) || (a->flags & DMCF_FLAG_NORMALIZE))
+        return false;
+    const int cin = a->filter_dims[3], cout = a->filter_dims[4];
+    if ((cin & 3) || cout > 16 * kCMaxNT) return false;
+    if ((uintptr_t)a->inp_features & 15) return false;
+    if (e) return true;
+    return cin >= 12;
+}
+
+int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {
+    const int nchunks = (p.cin + CCH - 1) / CCH, NT = (p.cout + 15) / 16;
+    float* packed = (float*)workspace;
+    {
+        const int64_t total = (int64_t)cconv_cls_packed_floats(p.cin, p.cout);
+        const unsigned g = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(pack_filter_cls, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, p.cin, p.cout,
+                           nchunks, NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
+    }
+    p.Wp = packed;
+    p.KT = getenv("DMCF_CLS_DEBUG") ? atoi(getenv("DMCF_CLS_DEBUG")) : 0;
+    p.NT = NT;
+    p.nchunks = nchunks;
+    const int64_t ntiles = (p.n_out + CTM - 1) / CTM;
+    if (ntiles > 0x7fffffff / 8) return DMCF_EUNSUPPORTED;
+    p.ntiles = (int)ntiles;
+    p.tiles_per_xcd = (int)((ntiles + 7) / 8);
+    const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    const void* fn = NT <= 1 ? (const void*)cconv_cls_kernel<1>
+                             : (NT <= 2 ? (const void*)cconv_cls_kernel<2> : (const void*)cconv_cls_kernel<4>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClsLds);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    void* kargs[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(kCThreads), kargs, kClsLds, stream);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    return check_launch();
+}
+
+}  // namespace dmcf

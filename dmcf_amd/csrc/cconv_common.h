@@ -224,6 +224,12 @@ size_t cconv_blk_packed_floats(int cin, int cout);
 int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
 
+// cconv_cls.hip
+bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+size_t cconv_cls_packed_floats(int cin, int cout);
+int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+
+
 // cconv_direct.hip
 bool cconv_direct_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_direct_packed_floats(int dz, int dy, int dx, int cin);

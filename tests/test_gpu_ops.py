@@ -299,11 +299,11 @@ def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, m
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
 def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, cout, ks, dim):
-    """The dispatcher picks one of the three splat kernels; force each and check it ("blk" only exists for 4x4x4
+    """The dispatcher picks one of the splat kernels; force each and check it ("blk" and "cls" only exist for 4x4x4
     filters, the other shapes then exercise the fallback order)."""
     from dmcf_amd import ops
     monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
@@ -319,11 +319,12 @@ def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, 
 
 @pytest.mark.parametrize("cin,cout,sym,radius", [(4, 8, False, 0.3), (8, 32, False, 0.45), (16, 16, False, 0.6), (24, 8, False, 0.3),
                                                  (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45)])
-def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, cin, cout, sym, radius):
-    """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA): rows from empty to several 62-pair batches, every
-    channel-chunk count, bias + accumulate, and the antisymmetric form."""
+@pytest.mark.parametrize("kernel", ["blk", "cls"])
+def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, kernel, cin, cout, sym, radius):
+    """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA) and cconv_cls.hip (class-sorted, four pairs per 16x16x4
+    MFMA): rows from empty to several batches, every channel-chunk count, bias + accumulate, and the antisymmetric form."""
     from dmcf_amd import ops
-    monkeypatch.setenv("DMCF_CCONV_KERNEL", "blk")
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
     rng = np.random.default_rng(5)
     if sym:
         n = 2500
@@ -566,7 +567,7 @@ def test_farthest_point_sample_matches_oracle(oracle, dev, kind, n, m):
     assert np.array_equal(got, feats[ref])
 
 
-@pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
+@pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("cls", 24, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
                                                 ("direct", 32, 3, (6, 6, 6)), ("lds", 4, 8, (3, 5, 2))])
 def test_padded_single_pass_search_and_conv(dev, monkeypatch, kernel, cin, cout, ks):
     """dmcf_frs_search_padded (one pass, rows at a fixed stride, no count pass) holds the same neighbours in the same order
