@@ -8,21 +8,26 @@
 //
 // with k = 4 pairs of the class and w = window * (1 -+ fz) * (1 -+ fy).  That is 8 clocks of matrix core per pair and
 // 16 channels (half of the products are useful), against 16 for the pair-per-instruction form (cconv_blk.hip) and
-// 32 for the unsorted 64-cell form (cconv_mfma.hip); the operands need four VALU operations per instruction.
+// 32 for the unsorted 64-cell form (cconv_mfma.hip); the A operand costs three VALU operations per instruction.
 //
-// Per batch of 64 pairs a wave: computes the geometry (lane = pair, as in the other kernels), orders the pairs by
-// class with 9 ballots (classes are padded to multiples of 4 with zero-weight slots), pushes {X, w[4]} and the
-// neighbour index to the pair's slot of the ordered batch in LDS, stages the feature rows of the ordered slots
-// (16-byte loads issued half a batch ahead) and runs 9 inner loops with fixed accumulator tiles: 36 VGPRs hold the
-// whole 64-cell x 16-channel B_i of the output point.  When a point is done its 9 tiles are merged into the point's
-// row of the B tile [16 points][64 cells x 16 channels] in LDS (4-float read-modify-writes), which the contraction
-// with the packed filter reads as in cconv_blk.hip.
+// A wave owns two output points of the workgroup's 16-point tile and walks their neighbour lists as ONE stream of
+// 64-pair batches (loads run ahead across the point boundary).  Per batch it
+//   1. computes the geometry (lane = pair, as in the other kernels) and the pair's class,
+//   2. orders the pairs by class with 9 ballots (classes padded to multiples of 4 with zero-weight slots),
+//   3. pushes {X, w[4]}, the class of each group of 4 slots and the neighbour index to the pair's slot of the ordered
+//      batch in LDS, and loads the feature rows of the ordered slots (16 bytes per lane, half a batch ahead),
+//   4. splats: a hand-scheduled block (tools/gen_cls_splat.py -> cconv_cls_splat.inc) reads each group's operands at
+//      fixed LDS offsets, one group ahead, and jumps to the in-place matrix instruction of the group's class tile:
+//      36 VGPRs hold the whole 64-cell x 16-channel B_i of the output point.
+// When a point's last batch is done its 9 tiles are merged into the point's row of the B tile [16 points][64 cells x 16
+// channels] in LDS (four stores, five 4-float read-modify-writes), which the contraction with the packed filter reads as
+// in cconv_blk.hip.
 //
-// LDS (80 KB per workgroup, two workgroups per CU): B tile 64 KB + 2 KB per wave for {X, w}; the feature staging
-// (48 slots x 16 channels) and the two index buffers live in the B row of the wave's SECOND point, which is free
-// until that point's tiles are merged.
+// LDS (80 KB per workgroup, two workgroups per CU): B tile 64 KB + 2 KB per wave for {X, w} and the group classes; the
+// feature staging (48 slots x 16 channels = half a batch) and the index buffer live in the B row of the wave's SECOND
+// point, which is free until that point's tiles are merged.
 //
-// Accumulation order = the ordered-batch order (stable inside a class): deterministic.
+// Accumulation order = the ordered-batch order (stable inside a class), then the fixed merge order: deterministic.
 #include <stdlib.h>
 
 #include "cconv_common.h"
@@ -137,14 +142,14 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             nv = 0.0f;
             if (where(t, pp, at)) {
                 j = p.idx[at];
-                if (p.nval && !(p.KT & 16)) nv = p.nval[at];
+                if (p.nval) nv = p.nval[at];
             }
         };
         auto ld_pos = [&](int t, int j, float& x, float& y, float& z) {
             int pp;
             int64_t at;
             x = y = z = 0.0f;
-            if (where(t, pp, at) && !(p.KT & 8)) {
+            if (where(t, pp, at)) {
                 x = p.inp_pos[3 * (int64_t)j];
                 y = p.inp_pos[3 * (int64_t)j + 1];
                 z = p.inp_pos[3 * (int64_t)j + 2];
@@ -183,11 +188,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             Order o;
             o.pos = 0;
             int base = 0;
-            if (p.KT & 128) {
-                o.pos = lane;
-                for (int c = 0; c < 10; ++c) o.cb[c] = c > 4 ? 64 : 0;
-                return o;
-            }
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
                 const uint64_t m = __ballot(cls == c);
@@ -206,7 +206,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             if (cls != kNoPair) Jst[pos] = j;
         };
         auto push_rec = [&](const ClsRec& c, int cls, int pos) {
-            if (p.KT & 32) return;
             *(f32x4*)(Gs + 4 * lane) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0, X 0
             if (lane < kGrp * 6 - 64) *(f32x4*)(Gs + 4 * (64 + lane)) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             xfence();
@@ -221,7 +220,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         // Padding slots (index -1), slots past the batch and channels past cin read a block of zeros behind the packed
         // filter: unconditional loads, nothing for the compiler to wait on before it issues them.
         auto f_issue = [&](int h, f32x4 (&f)[3]) {
-            if (p.KT & 256) return;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int jj = Jst[kHalfSlots * h + 16 * k + fr];  // -1: padding slot or past the batch
@@ -231,7 +229,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         };
         // (the antisymmetric form adds the output point's own features: a padding slot then holds f_i, times weight 0)
         auto f_publish = [&](int t, const f32x4 (&f)[3]) {
-            if (p.KT & 256) return;
             f32x4 fi4 = {0.0f, 0.0f, 0.0f, 0.0f};
             if (symmetric && fch_ok) fi4 = *(const f32x4*)(p.inp_feat + (pt0 + wave + (t >= nbA ? kCWaves : 0)) * cin + fch);
 #pragma unroll
@@ -243,7 +240,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         // jump picks the in-place matrix instruction.  Hand scheduled (tools/gen_cls_splat.py): with a C++ switch the
         // compiler copies the nine tiles around every case.
         auto splat = [&](int h, int nslots) {
-            if (p.KT & 1) return;
             const int lo = kHalfSlots * h;
             const int ng = (min(lo + kHalfSlots, nslots) - lo) >> 2;  // wave uniform
             const uint32_t pw = gs_lds + ((lo >> 2) * kGrp + 4 * mk + widx) * 4;
@@ -267,7 +263,6 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         // The four classes with even (bz, by) tile the 16 (z, y) rows exactly: they are plain stores.  The others are added
         // in three rounds of classes with disjoint rows.
         auto merge = [&](int pt) {
-            if (p.KT & 64) return;
             float* Brow = Bt + pt * kCRow;
             // the tiles were written by hand-issued matrix instructions: cover their write -> VALU read distance here
             asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
@@ -465,7 +460,6 @@ int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
                            nchunks, NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
     }
     p.Wp = packed;
-    p.KT = getenv("DMCF_CLS_DEBUG") ? atoi(getenv("DMCF_CLS_DEBUG")) : 0;
     p.NT = NT;
     p.nchunks = nchunks;
     const int64_t ntiles = (p.n_out + CTM - 1) / CTM;
