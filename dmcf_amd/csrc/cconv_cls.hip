@@ -431,10 +431,11 @@ __global__ void pack_filter_cls(const float* __restrict__ src, float* __restrict
     }
 }
 
-// Same filters and flags as cconv_blk.hip.  Measured on MI355X against it (16 -> 16 channels): 6.2 ms against 7.3 ms at
-// 3.07e8 pairs / 265 per output, 4.25 against 4.0 ms at 3.3e7 pairs / 29 per output (32 -> 32: one batch per point).
-// Picked for at least 12 input channels; the rule must not look at the list (capacity, padding): the same step gives
-// bit-identical results whichever neighbour-list representation it runs on.
+// Same filters and flags as cconv_blk.hip.  Measured on MI355X against it at 3.07e8 pairs / 265 per output: 6.0 against
+// 7.4 ms (16 -> 16), 11.6 against 14.6 ms (24 -> 8); 8 -> 32: 5.8 ms against 6.0 for the LDS splat; 4 -> 32: 5.6 against
+// 4.7 (LDS splat); at 29 pairs per output (32 -> 32, one batch per point) 4.2 against 4.1 ms.  Picked for at least 8 input
+// channels; the rule must not look at the list (capacity, padding): the same step gives bit-identical results whichever
+// neighbour-list representation it runs on.
 bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma" / "blk" / "cls" / "direct": force one implementation
     if (e && e[0] != 'c') return false;
@@ -447,7 +448,7 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     if ((cin & 3) || cout > 16 * kCMaxNT) return false;
     if ((uintptr_t)a->inp_features & 15) return false;
     if (e) return true;
-    return cin >= 12;
+    return cin >= 8;
 }
 
 int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {
