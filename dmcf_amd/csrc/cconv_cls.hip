@@ -63,7 +63,7 @@ __device__ __forceinline__ void xfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NTT>
+template <int NTT, bool NARROW>
 __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -83,8 +83,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
     const int mk = lane >> 4, mn = lane & 15;
     const float xm = (float)(lane & 3);
     const int widx = (lane >> 2) & 3;
-    // feature load roles: lane -> (slot in a group of 16, 4 channels)
-    const int fr = lane >> 2, fc4 = lane & 3;
+    // feature load roles: lane -> (slot, 4 channels); set per channel chunk
     // contraction roles
     const int mi = lane & 15, mg = lane >> 4;
     const uint32_t gs_lds = cls_lds_addr(Gs), fst_lds = cls_lds_addr(Fst);
@@ -97,6 +96,12 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int c0 = chunk * CCH;
         const int nch = min(CCH, cin - c0);
+        // Layers of at most 8 input channels stage 8 channels per slot: the features of a WHOLE ordered batch fit the staging,
+        // so a batch has one feature round and one splat instead of two.
+        constexpr bool narrow = NARROW;  // launched for layers of at most 8 input channels
+        const int fr = narrow ? lane >> 1 : lane >> 2, fc4 = narrow ? lane & 1 : lane & 3;
+        const int spi = narrow ? 32 : 16;     // slots per load instruction
+        const int fstride = narrow ? 8 : 16;  // staged floats per slot
         const bool fch_ok = c0 + 4 * fc4 < cin;
         const int fch = fch_ok ? c0 + 4 * fc4 : 0;
         // The batches of the wave's two points form ONE stream (point A's batches, then point B's): index, position and
@@ -216,13 +221,14 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                 if ((pos & 3) == 0) Cst[pos >> 2] = (unsigned char)(16 * cls + 12);  // see splat
             }
         };
-        // 16-byte feature loads of half h of the ordered batch: three groups of 16 slots, lane = (slot, 4 channels).
+        // 16-byte feature loads of half h of the ordered batch (narrow chunks: h = 0, the whole batch): three groups of 16
+        // (32) slots, lane = (slot, 4 channels).
         // Padding slots (index -1), slots past the batch and channels past cin read a block of zeros behind the packed
         // filter: unconditional loads, nothing for the compiler to wait on before it issues them.
         auto f_issue = [&](int h, f32x4 (&f)[3]) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const int jj = Jst[kHalfSlots * h + 16 * k + fr];  // -1: padding slot or past the batch
+                const int jj = Jst[kHalfSlots * h + spi * k + fr];  // -1: padding slot or past the batch
                 const float* src = p.inp_feat + (int64_t)jj * cin + fch;
                 f[k] = *(const f32x4*)((jj >= 0 && fch_ok) ? src : zero4);
             }
@@ -232,7 +238,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             f32x4 fi4 = {0.0f, 0.0f, 0.0f, 0.0f};
             if (symmetric && fch_ok) fi4 = *(const f32x4*)(p.inp_feat + (pt0 + wave + (t >= nbA ? kCWaves : 0)) * cin + fch);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (16 * k + fr) * 16 + 4 * fc4) = f[k] + fi4;
+            for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (spi * k + fr) * fstride + 4 * fc4) = f[k] + fi4;
         };
         // Splat of half h: the (at most 12) groups at fixed staging addresses -- no address arithmetic -- each into the tile
         // of its class.  The class of a group is wave uniform: the owner of a group's first slot left it in Cst (as the
@@ -256,6 +262,27 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                   "+v"(tl[8]), [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
                   [a] "=&v"(av), [sc] "=&s"(sc)
                 : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2)
+                : "vcc", "scc", "memory");
+        };
+        // the same for a whole batch staged with 8 channels per slot (columns 8..15 of the tiles repeat 0..7: never read)
+        auto splat8 = [&](int nslots) {
+            const int ng = nslots >> 2;  // wave uniform, <= 24
+            const uint32_t pw = gs_lds + (4 * mk + widx) * 4;
+            const uint32_t px = gs_lds + (16 + mk) * 4;
+            const uint32_t pf = fst_lds + (8 * mk + (mn & 7)) * 4;
+            const uint32_t* cw = (const uint32_t*)Cst;
+            uint32_t c[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) c[q] = __builtin_amdgcn_readfirstlane(cw[q]);
+            float xa, wa, fa, xb, wb, fb, av;
+            uint32_t sc;
+            asm volatile(
+#include "cconv_cls_splat8.inc"
+                : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]),
+                  "+v"(tl[8]), [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
+                  [a] "=&v"(av), [sc] "=&s"(sc)
+                : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c[0]), [c1] "s"(c[1]),
+                  [c2] "s"(c[2]), [c3] "s"(c[3]), [c4] "s"(c[4]), [c5] "s"(c[5])
                 : "vcc", "scc", "memory");
         };
         // Merge the 9 tiles into the point's B row and clear them.  D layout of 16x16x4: lane (group G = lane >> 4 =
@@ -308,35 +335,57 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             jA = jB;
             nvA = nvB;
             ld_pos(1, jA, px, py, pz);
-            for (int t = 0; t < NB; ++t) {
-                // here: (jA, nvA, px, py, pz) = batch t + 1.  Every wait on a load below finds that load the youngest one
-                // outstanding (or the younger ones long issued): the counter the hardware offers is in order.
-                const int nslots = oc.cb[9];
-                const bool two = nslots > kHalfSlots;
-                f_publish(t, ff);
-                ld_idx(t + 2, jB, nvB);
-                // ---- half 0 of this batch; the feature loads of half 1 fly meanwhile
-                if (two) f_issue(1, ff);
-                xfence();
-                splat(0, nslots);
-                // geometry + order of the next batch
-                const ClsRec nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
-                const Order on = order(cl);
-                push_index(jA, cl, on.pos);
-                xfence();
-                // ---- half 1; the positions of batch t + 2 and the feature loads of the next batch's half 0 fly meanwhile
-                if (two) f_publish(t, ff);
-                jA = jB;
-                nvA = nvB;
-                ld_pos(t + 2, jA, px, py, pz);
-                if (t + 1 < NB) f_issue(0, ff);
-                if (two) {
+            if constexpr (narrow) {
+                for (int t = 0; t < NB; ++t) {
+                    // here: (jA, nvA, px, py, pz) = batch t + 1.  One feature round per batch: the loads of batch t + 1 are
+                    // issued before the splat of batch t and published after it.
+                    const int nslots = oc.cb[9];
+                    f_publish(t, ff);
+                    ld_idx(t + 2, jB, nvB);
+                    const ClsRec nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
+                    const Order on = order(cl);
+                    push_index(jA, cl, on.pos);
+                    jA = jB;
+                    nvA = nvB;
+                    ld_pos(t + 2, jA, px, py, pz);
                     xfence();
-                    splat(1, nslots);
+                    if (t + 1 < NB) f_issue(0, ff);
+                    splat8(nslots);
+                    push_rec(nxt, cl, on.pos);
+                    oc = on;
+                    if (t == nbA - 1) merge(wave);
                 }
-                push_rec(nxt, cl, on.pos);
-                oc = on;
-                if (t == nbA - 1) merge(wave);
+            } else {
+                for (int t = 0; t < NB; ++t) {
+                    // here: (jA, nvA, px, py, pz) = batch t + 1.  Every wait on a load below finds that load the youngest one
+                    // outstanding (or the younger ones long issued): the counter the hardware offers is in order.
+                    const int nslots = oc.cb[9];
+                    const bool two = nslots > kHalfSlots;
+                    f_publish(t, ff);
+                    ld_idx(t + 2, jB, nvB);
+                    // ---- half 0 of this batch; the feature loads of half 1 fly meanwhile
+                    if (two) f_issue(1, ff);
+                    xfence();
+                    splat(0, nslots);
+                    // geometry + order of the next batch
+                    const ClsRec nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
+                    const Order on = order(cl);
+                    push_index(jA, cl, on.pos);
+                    xfence();
+                    // ---- half 1; the positions of batch t + 2 and the feature loads of the next batch's half 0 fly meanwhile
+                    if (two) f_publish(t, ff);
+                    jA = jB;
+                    nvA = nvB;
+                    ld_pos(t + 2, jA, px, py, pz);
+                    if (t + 1 < NB) f_issue(0, ff);
+                    if (two) {
+                        xfence();
+                        splat(1, nslots);
+                    }
+                    push_rec(nxt, cl, on.pos);
+                    oc = on;
+                    if (t == nbA - 1) merge(wave);
+                }
             }
         }
         merge(wave + kCWaves);
@@ -468,8 +517,13 @@ int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
-    const void* fn = NT <= 1 ? (const void*)cconv_cls_kernel<1>
-                             : (NT <= 2 ? (const void*)cconv_cls_kernel<2> : (const void*)cconv_cls_kernel<4>);
+    const void* fn;
+    if (p.cin <= 8)
+        fn = NT <= 1 ? (const void*)cconv_cls_kernel<1, true>
+                     : (NT <= 2 ? (const void*)cconv_cls_kernel<2, true> : (const void*)cconv_cls_kernel<4, true>);
+    else
+        fn = NT <= 1 ? (const void*)cconv_cls_kernel<1, false>
+                     : (NT <= 2 ? (const void*)cconv_cls_kernel<2, false> : (const void*)cconv_cls_kernel<4, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClsLds);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
