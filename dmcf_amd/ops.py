@@ -264,6 +264,11 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         need = m * stride
         g = max(1 << 16, 1 << max(need.bit_length() - 4, 0))
         cap = (need + g - 1) // g * g
+        # a caller that repeats this search every step passes the capacity it got last time: while that still fits (and
+        # is not grossly oversized) the request stays byte-identical, and the caching allocator answers it without a
+        # hipMalloc (a fresh 2 GB block costs 20-120 ms; m * stride hovers around a bucket edge for steps on end)
+        if capacity_hint is not None and need <= int(capacity_hint) <= 2 * cap:
+            cap = int(capacity_hint)
         index = torch.empty(cap, dtype=torch.int32, device=dev)
         dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
         counts = torch.empty(m, dtype=torch.int32, device=dev)

@@ -38,6 +38,7 @@ class _NeighborCache:
         # pair-count estimates from the previous step, by position in the step's sequence of distinct searches:
         # with them a step enqueues all its searches without a single host round trip (see search())
         self.hints = []
+        self.caps = {}  # slot -> entries of the padded buffers of the previous step (kept while they still fit)
         self.use_hints = False
         self.order = 0
         self.pending = []
@@ -105,7 +106,8 @@ class _NeighborCache:
             # Padded rows of (longest row of the previous step) * 1.25 + 8 entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
             # stride is detected at the end of the step (one sync) and the step is repeated with the exact search.
-            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint))
+            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(slot))
+            self.caps[slot] = getattr(res, "capacity", None)
         else:
             res = frs(points, queries, radius, hash_table=table)
         self.pending.append((slot, res))
