@@ -341,7 +341,8 @@ def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, kernel, cin, cout
         assert np.all(np.abs(y.astype(np.float64).sum(axis=0)) <= 2e-5 * np.abs(y).sum(axis=0) + 1e-6)
         return
     inp, out, feat, filt = _conv_inputs(oracle, 91, 6000, 333, cin, cout, (4, 4, 4), radius)
-    out = np.concatenate([out, np.float32([[9, 9, 9]])])  # a row without neighbours
+    # rows without neighbours: as the first and as the second point of a wave's pair (tile row r and r + 8), and last
+    out = np.concatenate([np.float32([[9, 9, 9]]), out[:40], np.float32([[9, 9, -9]]), out[40:], np.float32([[9, 9, 9]])])
     bias = rng.normal(size=cout).astype(np.float32)
     pimp = rng.uniform(0.5, 1.5, size=inp.shape[0]).astype(np.float32)
     nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
