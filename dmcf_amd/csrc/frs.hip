@@ -4,9 +4,11 @@
 // utils/tools/losses.py:296-298).  The Open3D structure behind that layer (spatial hash with ~64
 // points per bin, 8 corner bins per query) is NOT what is built here; only its result contract is
 // kept (see include/dmcf_hip.h).  MI355X-first choices:
-//   * cell edge ~= radius/2 (125-cell neighbourhood, ~27 % of candidates are hits, vs ~6.5 % for the
-//     reference's 2R cells; radius-sized or coarser cells when the grid would be too sparse or too big) and points re-ordered by cell into one float4 {x,y,z,index} array, so a
-//     query reads <= 25 contiguous x-runs with coalesced 16-B loads instead of chasing indices;
+//   * cell edge ~= radius/3 (then radius/2; radius-sized or coarser cells when the grid would be too sparse or too big) and
+//     points re-ordered by cell into one float4 {x,y,z,index} array, so a query reads <= 49 contiguous x-runs with
+//     coalesced 16-B loads instead of chasing indices; each run is trimmed to the chord of the search sphere in its row
+//     of cells (~45 % of the candidates are hits; 27 % for the untrimmed box of R/2 cells, ~6.5 % for the reference's 2R
+//     hash bins);
 //   * one 64-lane wavefront per query: lanes stride the flattened candidate list, hits are compacted
 //     with a ballot + mbcnt prefix (no atomics, no LDS), rows come out in a deterministic order;
 //   * everything that sizes the grid (bounding box, cell edge, dims) is computed on the device into a
@@ -14,6 +16,10 @@
 #include "cconv_common.h"  // window_value
 
 namespace dmcf {
+
+#ifndef FRS_CELL_DIV
+#define FRS_CELL_DIV 3  // preferred cells per radius (measured on the 1M box: 2 -> 3 cuts the 3e8-pair searches by 9 %, 4 needs two row batches)
+#endif
 
 struct FrsHeader {
     float origin[3];
@@ -130,15 +136,20 @@ __global__ void frs_finish_header(FrsHeader* h, int64_t table) {
         if (!(ext[a] >= 0.0f) || !isfinite(ext[a])) ext[a] = 0.0f;  // empty / non-finite input
         if (!isfinite(lo[a])) lo[a] = 0.0f;
     }
-    // Preferred cell edge R/2 (125-cell neighbourhood, ~27 % of the candidates are hits; R-sized cells give 15 %),
-    // unless the grid would be mostly empty (fewer than one point per two cells) or does not fit the table.
-    // Then R, then coarser.  "1.001": [q-R, q+R] spans at most 2s+1 cells of edge 1.001 R / s.
+    // Preferred cell edge R/3, then R/2 (the rows of cells are trimmed to the chord of the search sphere, so finer cells
+    // mean fewer candidates: ~45 % of them are hits at R/3; the untrimmed box of R-sized cells gives 15 %), unless the
+    // grid would be mostly empty (fewer than one point per two cells) or does not fit the table.  Then R, then coarser.
+    // "1.001": [q-R, q+R] spans at most 2s+1 cells of edge 1.001 R / s.
     int32_t d[3];
-    float cell = h->radius * 1.001f * 0.5f;
-    {
+    float cell = h->radius * 1.001f;
+    for (int div = FRS_CELL_DIV; div >= 2; --div) {
+        const float c = h->radius * 1.001f / (float)div;
         double prod = 1.0;
-        for (int a = 0; a < 3; ++a) prod *= floor((double)ext[a] / (double)cell) + 1.0;
-        if (prod > (double)table || (double)h->n_points < 0.5 * prod) cell = h->radius * 1.001f;
+        for (int a = 0; a < 3; ++a) prod *= floor((double)ext[a] / (double)c) + 1.0;
+        if (prod <= (double)table && (double)h->n_points >= 0.5 * prod) {
+            cell = c;
+            break;
+        }
     }
     for (int it = 0; it < 64; ++it) {
         double prod = 1.0;
@@ -264,15 +275,39 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
     if (!empty) {
         const int ny = hi[1] - lo[1] + 1, nz = hi[2] - lo[2] + 1;
         const bool ignore = (flags & DMCF_FRS_IGNORE_QUERY_POINT) != 0;
-        // (y,z) rows are taken 64 at a time (25 at most when the cell edge is ~R/2; more only for coarsened grids)
+        // (y,z) rows are taken 64 at a time (49 at most when the cell edge is ~R/3)
         for (int row0 = 0; row0 < ny * nz; row0 += kWave) {
             const int r = row0 + lane;
             int32_t start = 0, len = 0;
             if (r < ny * nz) {
                 const int cy = lo[1] + r % ny, cz = lo[2] + r / ny;
                 const int32_t base = (cz * h->dims[1] + cy) * h->dims[0];
-                start = (int32_t)cell_start[base + lo[0]];
-                len = (int32_t)cell_start[base + hi[0] + 1] - start;
+                // Trim the row to the chord of the search sphere: the box of cells around the query holds 15.6 R^3 of
+                // candidates for a 4.2 R^3 sphere.  gap = distance (in cells) from the query to the row's slab of cells along
+                // y / z -- the outermost cells also hold everything binned from beyond the grid, so they have no outer face --
+                // minus a slack far above the rounding of the binning; the x range then only covers the chord.  Still a
+                // superset of the neighbours: the distance test below decides.
+                auto gap = [&](int a, int c) -> float {
+                    const float u = (q[a] - h->origin[a]) * h->inv_cell[a];
+                    float g = 0.0f;
+                    if (c > 0) g = fmaxf(g, (float)c - u);
+                    if (c < h->dims[a] - 1) g = fmaxf(g, u - (float)(c + 1));
+                    g = fmaxf(g - (1e-3f + 1e-6f * fabsf(u)), 0.0f);
+                    return g * __builtin_amdgcn_rcpf(h->inv_cell[a]);  // 1 ulp: far inside the slack
+                };
+                const float dy = gap(1, cy), dz = gap(2, cz);
+                const float rs = radius * 1.0002f;
+                const float h2 = rs * rs - dy * dy - dz * dz;
+                if (h2 >= 0.0f) {
+                    const float hx = __builtin_amdgcn_sqrtf(h2) * 1.0001f;
+                    const float slack = 1e-4f * radius + 4.8e-7f * (fabsf(q[0]) + radius);
+                    const int xlo = max(cell_coord(q[0] - hx - slack, h->origin[0], h->inv_cell[0], h->dims[0]), lo[0]);
+                    const int xhi = min(cell_coord(q[0] + hx + slack, h->origin[0], h->inv_cell[0], h->dims[0]), hi[0]);
+                    if (xlo <= xhi) {
+                        start = (int32_t)cell_start[base + xlo];
+                        len = (int32_t)cell_start[base + xhi + 1] - start;
+                    }
+                }
             }
             // inclusive scan of run lengths across lanes (DPP: no LDS round trips)
             const int32_t incl = wave_inclusive_add(len);
