@@ -116,6 +116,8 @@ def main():
 
     for _ in range(args.warmup):
         state = step(state)
+    if os.environ.get("DMCF_BENCH_DEBUG"):
+        torch.cuda.reset_peak_memory_stats(dev)
     if rank == 0 and os.environ.get("DMCF_BENCH_NOTIMER") != "1":
         ops.timer = ops.LaunchTimer()
     barrier()
@@ -124,7 +126,10 @@ def main():
         state = step(state)
         if os.environ.get("DMCF_BENCH_DEBUG"):
             torch.cuda.synchronize(dev)
-            print(f"[debug] step done at {1e3 * (time.perf_counter() - t0):.1f} ms", file=sys.stderr, flush=True)
+            ms = torch.cuda.memory_stats(dev)
+            print(f"[debug] step done at {1e3 * (time.perf_counter() - t0):.1f} ms; reserved {ms['reserved_bytes.all.current'] / 2**30:.1f} GiB "
+                  f"(peak {ms['reserved_bytes.all.peak'] / 2**30:.1f}), allocated peak {ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB, "
+                  f"device mallocs {ms['num_device_alloc']}, frees {ms['num_device_free']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.timer = (ops.timer if ops.timer is not None else ops.LaunchTimer()), None

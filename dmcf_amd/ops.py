@@ -41,6 +41,12 @@ class NeighborSearchResult:
     def raw(self):
         return self._index_buf, self.neighbors_row_splits, self._dist_buf
 
+    def release(self):
+        """Drop the index / distance buffers (the per-step neighbour cache calls this once a list's last consumer has
+        enqueued its kernel: a 3e8-pair list is 2.4 GB, padded 3.4 GB).  Row splits / counts stay."""
+        self._index_buf = self._dist_buf = None
+        self._redo = None
+
     @property
     def total_ref(self):
         """0-dim device tensor holding P (no synchronisation)."""
@@ -96,6 +102,11 @@ class PaddedNeighborList(NeighborSearchResult):
     @property
     def total_ref(self):
         return self.row_count.sum()
+
+    def release(self):
+        super().release()
+        self._redo_exact = None
+        self._compact = None
 
     def overflowed(self, max_count):
         return max_count > self.stride

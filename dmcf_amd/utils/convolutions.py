@@ -39,6 +39,13 @@ class _NeighborCache:
         # with them a step enqueues all its searches without a single host round trip (see search())
         self.hints = []
         self.caps = {}  # slot -> entries of the padded buffers of the previous step (kept while they still fit)
+        # consumers per list: learnt in one step, used in the next to hand a list's buffers back to the allocator as soon
+        # as its last consumer has enqueued its kernel (12 lists of 2.4 - 3.4 GB each at 1M particles; all of them alive
+        # until the end of the step was 160 GB at 4M particles and sent the caching allocator into free / malloc cycles)
+        self.expect = {}
+        self.uses = {}
+        self.slot_of = {}
+        self.done = []
         self.use_hints = False
         self.order = 0
         self.pending = []
@@ -58,6 +65,13 @@ class _NeighborCache:
         self.depth -= 1
         if self.depth == 0:
             pending, self.pending = self.pending, []
+            self._flush()
+            for _, r in pending:  # layers keep their last list in .nns: do not let that pin the buffers into the next step
+                r.release()
+            if exc_type is None:
+                self.expect = dict(self.uses)
+            self.uses = {}
+            self.slot_of = {}
             self.lists.clear()
             self.tables.clear()
             self.geometries.clear()
@@ -86,15 +100,31 @@ class _NeighborCache:
     def _key(t):
         return (t.data_ptr(), tuple(t.shape), t._version)
 
+    def _flush(self):
+        for r in self.done:
+            r.release()
+        self.done = []
+
+    def _consumer(self, key, res):
+        """Count one consumer of the list; after the last one expected the list leaves the cache and its buffers are dropped
+        at the next request (by then the consumer -- layers run one after the other -- has enqueued its kernel)."""
+        slot = self.slot_of[key]
+        self.uses[slot] = self.uses.get(slot, 0) + 1
+        if self.expect.get(slot) == self.uses[slot]:
+            self.lists.pop(key, None)
+            self.done.append(res)
+
     def search(self, frs, points, queries, radius):
         if self.depth == 0:
             return frs(points, queries, radius)
+        self._flush()
         points = points.contiguous()
         queries = queries.contiguous()
         tkey = (self._key(points), float(radius))
         key = (tkey, self._key(queries), frs.ignore_query_point, frs.return_distances)
         hit = self.lists.get(key)
         if hit is not None:
+            self._consumer(key, hit)
             return hit
         table = self.tables.get(tkey)
         if table is None or table.n_queries_capacity < queries.shape[0]:
@@ -112,6 +142,8 @@ class _NeighborCache:
             res = frs(points, queries, radius, hash_table=table)
         self.pending.append((slot, res))
         self.lists[key] = res
+        self.slot_of[key] = slot
+        self._consumer(key, res)
         self.keepalive.append((points, queries))  # keep storage alive so data_ptr keys stay unique
         return res
 
@@ -368,11 +400,16 @@ class ContinuousConv(torch.nn.Module):
             if self.symmetric:
                 raise NotImplementedError("circular + symmetric kernels (filters must be 3 in the reference; "
                                           "no shipped config uses circular: True)")
+        # The reference keeps the operands of the last call for inspection (convolutions.py:398-413).  Inside a rollout
+        # step (neighbor_cache scope) that would pin every layer's neighbour list (GBs each) and activations into the
+        # next step: there only the small entries are kept.
+        in_step = _CACHE.depth > 0
         self._conv_values = {
             "filters": kernel, "out_positions": out_positions, "extents": extent, "offset": self.offset,
-            "inp_positions": inp_positions, "inp_features": inp_features, "inp_importance": inp_importance,
-            "neighbors_index": neighbors_index, "neighbors_row_splits": neighbors_row_splits,
-            "neighbors_importance": neighbors_value, "align_corners": self.align_corners,
+            "inp_positions": inp_positions, "inp_features": None if in_step else inp_features,
+            "inp_importance": inp_importance,
+            "neighbors_index": None if in_step else neighbors_index, "neighbors_row_splits": neighbors_row_splits,
+            "neighbors_importance": None if in_step else neighbors_value, "align_corners": self.align_corners,
             "coordinate_mapping": self.coordinate_mapping, "interpolation": self.interpolation,
             "normalize": self.normalize,
         }
@@ -401,10 +438,11 @@ class ContinuousConv(torch.nn.Module):
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
             bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref,
             neighbors_row_count=row_count)
-        self._conv_output = out_features
+        self._conv_output = None if in_step else out_features
         if self.use_dense_layer_for_center:  # :462-464
-            self._dense_output = inp_features @ self.dense
-            out_features = out_features + self._dense_output
+            dense_output = inp_features @ self.dense
+            self._dense_output = None if in_step else dense_output
+            out_features = out_features + dense_output
             if self.use_bias:
                 out_features = out_features + self.bias
         if self.activation is not None:
@@ -485,7 +523,7 @@ class PointSampling(torch.nn.Module):
                                 inp_importance=inp_importance, align_corners=False, coordinate_mapping="ball_to_cube_radial",
                                 interpolation="linear", normalize=self.normalize, n_pairs_ref=n_pairs_ref,
                                 neighbors_row_count=row_count)
-        self._conv_output = out
+        self._conv_output = None if _CACHE.depth > 0 else out  # see ContinuousConv.forward
         return out
 
     call = forward
