@@ -44,11 +44,38 @@ class CconvArgs(ctypes.Structure):
     ]
 
 
+class LatticeConvArgs(ctypes.Structure):
+    """struct dmcf_lattice_conv_args (include/dmcf_hip.h)."""
+    _fields_ = [
+        ("filters", ctypes.c_void_p),
+        ("filter_dims", ctypes.c_int32 * 5),
+        ("out_cells", ctypes.c_void_p),
+        ("n_out", ctypes.c_int64),
+        ("out_step", ctypes.c_int32),
+        ("inp_table", ctypes.c_void_p),
+        ("table_min", ctypes.c_int32 * 3),
+        ("table_dims", ctypes.c_int32 * 3),
+        ("voxel", ctypes.c_float * 3),
+        ("offsets", ctypes.c_void_p),
+        ("n_offsets", ctypes.c_int64),
+        ("inp_features", ctypes.c_void_p),
+        ("extent", ctypes.c_float),
+        ("window_fac", ctypes.c_float),
+        ("window", ctypes.c_int32),
+        ("coordinate_mapping", ctypes.c_int32),
+        ("interpolation", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+        ("bias", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+    ]
+
+
 # names every entry point include/dmcf_hip.h declares (tests/test_abi.py cross-checks against the header)
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
+    "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
     "dmcf_reduce_subarrays_sum",
     "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
     "dmcf_grid_pos_workspace_bytes", "dmcf_grid_pos_bounds", "dmcf_grid_pos_count", "dmcf_grid_pos_write",
@@ -99,6 +126,10 @@ def lib():
     L.dmcf_cconv_workspace_bytes.argtypes = [c.POINTER(CconvArgs)]
     L.dmcf_cconv_forward.restype = c.c_int
     L.dmcf_cconv_forward.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_lattice_conv_workspace_bytes.restype = c.c_size_t
+    L.dmcf_lattice_conv_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs)]
+    L.dmcf_lattice_conv_forward.restype = c.c_int
+    L.dmcf_lattice_conv_forward.argtypes = [c.POINTER(LatticeConvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_cconv_geometry_bytes.restype = c.c_size_t
     L.dmcf_cconv_geometry_bytes.argtypes = [c.c_int64]
     L.dmcf_cconv_geometry.restype = c.c_int

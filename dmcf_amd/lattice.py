@@ -1,0 +1,85 @@
+"""Bookkeeping for the lattice form of ContinuousConv (dmcf_lattice_conv_forward, csrc/cconv_lat.hip).
+
+``grid_pos`` (utils/tools/losses.py:136-181) returns ``float(cell) * voxel + center``: a regular lattice.  HRNet convolves
+between such point sets (models/hrnet.py:85-92) and, with ``centralize``, all scales of a step share one centre while their
+voxel sizes are ``voxel_size * stride`` (losses.py:266) -- integer multiples of each other.  ``ops.grid_pos`` registers what
+it knows about its result here; :func:`pair` tells :class:`ContinuousConv` whether two position tensors are such lattices
+and hands out the integer cells / the cell -> point table the kernel needs (built once per lattice and step).
+"""
+import collections
+import os
+
+import numpy as np
+import torch
+
+_REGISTRY = collections.OrderedDict()  # (data_ptr, n) -> LatticeInfo; the newest few lattices only
+_KEEP = 16
+
+
+class LatticeInfo:
+    def __init__(self, gpos, center, voxel, family, minp, dims):
+        self.gpos = gpos            # keeps the storage alive, so the registry key stays unique
+        self.version = gpos._version
+        self.center = center        # float32 [3] on the device
+        self.voxel = tuple(float(np.float32(v)) for v in voxel)
+        self.family = family        # lattices of one family share the centre exactly
+        self.minp = [int(v) for v in minp]  # (x, y, z) corner of a box of cells that holds every point
+        self.dims = [int(v) for v in dims]
+        self._cells = None
+        self._table = None
+
+    def cells(self):
+        """int32 [n, 3] (x, y, z): the integer lattice coordinates (exact: |gpos - center| / voxel is within 1e-4 of them)."""
+        if self._cells is None:
+            v = torch.tensor(self.voxel, dtype=torch.float32, device=self.gpos.device)
+            self._cells = torch.round((self.gpos - self.center) / v).to(torch.int32).contiguous()
+        return self._cells
+
+    def table(self):
+        """int32 [dz, dy, dx]: index of the point in each cell of the box, -1 where there is none."""
+        if self._table is None:
+            dx, dy, dz = self.dims
+            c = self.cells().long()
+            lin = ((c[:, 2] - self.minp[2]) * dy + (c[:, 1] - self.minp[1])) * dx + (c[:, 0] - self.minp[0])
+            t = torch.full((dz * dy * dx,), -1, dtype=torch.int32, device=self.gpos.device)
+            t[lin] = torch.arange(c.shape[0], dtype=torch.int32, device=self.gpos.device)
+            self._table = t.view(dz, dy, dx)
+        return self._table
+
+
+def register(gpos, center, voxel, family, minp, dims):
+    if gpos.shape[0] == 0 or any(not (float(v) > 1e-5) for v in voxel):
+        return  # empty, or a collapsed axis (2-D scenes): the neighbour-list form handles those
+    _REGISTRY[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims)
+    while len(_REGISTRY) > _KEEP:
+        _REGISTRY.popitem(last=False)
+
+
+def lookup(t):
+    info = _REGISTRY.get((t.data_ptr(), t.shape[0]))
+    if info is None or info.gpos._version != info.version or t.dim() != 2 or t.dtype != torch.float32 or not t.is_contiguous():
+        return None
+    return info
+
+
+def enabled():
+    return os.environ.get("DMCF_LATTICE_CONV", "1") != "0"
+
+
+class LatticePair:
+    def __init__(self, inp, out, step):
+        self.inp, self.out, self.step = inp, out, step
+
+
+def pair(inp_positions, out_positions):
+    """LatticePair if both tensors are registered lattices of one family and the output spacing is an integer multiple
+    (1, 2, ...) of the input spacing; None otherwise (then the neighbour-list form runs)."""
+    if not enabled():
+        return None
+    a, b = lookup(inp_positions), lookup(out_positions)
+    if a is None or b is None or a.family != b.family:
+        return None
+    step = round(b.voxel[0] / a.voxel[0])
+    if step < 1 or any(b.voxel[k] != step * a.voxel[k] for k in range(3)):
+        return None
+    return LatticePair(a, b, int(step))

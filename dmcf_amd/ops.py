@@ -15,6 +15,7 @@ fallback: calling these with CPU tensors or without the built library raises.
 import collections
 import ctypes
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -452,6 +453,71 @@ def cconv_geometry(kernel_dims, out_positions, extent, inp_positions, neighbors_
     return geo
 
 
+_STENCILS = {}
+
+
+def lattice_offsets(voxel, radius, device):
+    """int32 [S, 4] device tensor: the integer offsets d (x, y, z, 0) of input cells around an output cell with
+    |d * voxel| <= radius, decided like the search decides a pair (fp32, un-fused squared distance), ordered z, y, x."""
+    key = (tuple(float(v) for v in voxel), float(radius), str(device))
+    st = _STENCILS.get(key)
+    if st is None:
+        v = np.asarray(voxel, np.float32)
+        reach = [int(np.floor(radius / float(x))) + 1 if x > 0 else 0 for x in v]
+        ax = [np.arange(-r, r + 1, dtype=np.int32) for r in reach]
+        dz, dy, dx = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
+        x, y, z = dx.astype(np.float32) * v[0], dy.astype(np.float32) * v[1], dz.astype(np.float32) * v[2]
+        d2 = (x * x + y * y) + z * z
+        keep = d2 <= np.float32(radius) * np.float32(radius)
+        off = np.stack([dx[keep], dy[keep], dz[keep], np.zeros(int(keep.sum()), np.int32)], axis=1).astype(np.int32)
+        st = torch.from_numpy(np.ascontiguousarray(off)).to(device)
+        _STENCILS[key] = st
+    return st
+
+
+def lattice_conv(filters, out_cells, out_step, inp_table, table_min, voxel, extent, inp_features, window="poly6",
+                 window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
+                 interpolation="linear", bias=None, out=None, accumulate=False):
+    """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
+    ``out_cells`` int32 [n_out, 3] (x, y, z), ``inp_table`` int32 [dz, dy, dx] (input point index or -1) whose entry 0
+    is cell ``table_min`` (x, y, z), ``voxel`` the input lattice spacing (x, y, z)."""
+    L = _lib.lib()
+    dev = filters.device
+    n_out, cin, cout = out_cells.shape[0], filters.shape[3], filters.shape[4]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an out tensor")
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+    offsets = lattice_offsets(voxel, 0.5 * float(extent), dev)
+    filters, inp_features = filters.contiguous(), inp_features.contiguous()
+    a = _lib.LatticeConvArgs()
+    a.filters = _ptr(filters)
+    for k in range(5):
+        a.filter_dims[k] = int(filters.shape[k])
+    a.out_cells, a.n_out, a.out_step = _ptr(out_cells), n_out, int(out_step)
+    a.inp_table = _ptr(inp_table)
+    for k in range(3):
+        a.table_min[k] = int(table_min[k])
+        a.table_dims[k] = int(inp_table.shape[2 - k])
+        a.voxel[k] = float(voxel[k])
+    a.offsets, a.n_offsets = _ptr(offsets), int(offsets.shape[0])
+    a.inp_features = _ptr(inp_features)
+    a.extent, a.window_fac = float(extent), float(window_fac)
+    a.window = WINDOWS[window]
+    a.coordinate_mapping, a.interpolation = MAPPINGS[coordinate_mapping], INTERPOLATIONS[interpolation]
+    a.flags = (FLAG_ALIGN_CORNERS if align_corners else 0) | (FLAG_ACCUMULATE if accumulate else 0)
+    a.bias = _ptr(bias) if bias is not None else None
+    a.out = _ptr(out)
+    nbytes = L.dmcf_lattice_conv_workspace_bytes(ctypes.byref(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(L.dmcf_lattice_conv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
+    if timer is not None:
+        timer.end("cconv", dict(pairs=n_out * int(offsets.shape[0]), n_out=n_out, cin=int(cin), cout=int(cout),
+                                K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
+    return out
+
+
 def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
@@ -561,7 +627,9 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     common = (1 if centralize else 0,)
     _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, common[0], _ptr(cen) if cen is not None else None, int(pad),
                                       float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
-    cells = int(ws[24:32].view(torch.int64).item())  # header.cells (host round trip 1 of 2)
+    hdr = ws[0:32].cpu()  # header.minp, dims, cells (host round trip 1 of 2)
+    minp, dims = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
+    cells = int(hdr[24:32].view(torch.int64).item())
     if cells < 0:
         raise _lib.DmcfError("grid_pos: positions are not finite")
     if cells > GRID_MAX_CELLS:
@@ -574,6 +642,12 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     if total:
         _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
                                          _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
+        if centralize and center is None:
+            # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
+            # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
+            from . import lattice
+            lattice.register(out, ws[40:52].view(torch.float32).clone(), [float(v) for v in vs],
+                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims)
     return out
 
 

@@ -368,6 +368,23 @@ class ContinuousConv(torch.nn.Module):
             if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
                 window, neighbors_value = "explicit", user_neighbors_importance
         else:
+            lat = self._lattice_form(inp_features, inp_positions, out_positions, inp_importance,
+                                     fixed_radius_search_hash_table)
+            if lat is not None:
+                # both point sets are grid_pos lattices of this step: no search, no per-pair geometry
+                # (dmcf_lattice_conv_forward; DMCF_LATTICE_CONV=0 keeps the neighbour-list form)
+                self.nns = None
+                fuse_bias = self.use_bias and not self.use_dense_layer_for_center
+                offsets = ops.lattice_offsets(lat.inp.voxel, 0.5 * extent, inp_features.device)
+                self._n_out_last = out_positions.shape[0]
+                self._pairs_last = out_positions.shape[0] * int(offsets.shape[0])  # upper bound: cells, not points
+                out_features = ops.lattice_conv(
+                    self.kernel, lat.out.cells(), lat.step, lat.inp.table(), lat.inp.minp, lat.inp.voxel, extent,
+                    inp_features, window=self.window_function.name, window_fac=self.window_function.fac,
+                    align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
+                    interpolation=self.interpolation, bias=self.bias if fuse_bias else None)
+                self._conv_values, self._conv_output = None, (None if _CACHE.depth > 0 else out_features)
+                return self._finish(out_features, inp_features)
             radius = float(np.float32(0.5) * np.float32(extent))  # :353
             if fixed_radius_search_hash_table is not None:
                 self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
@@ -439,15 +456,29 @@ class ContinuousConv(torch.nn.Module):
             bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref,
             neighbors_row_count=row_count)
         self._conv_output = None if in_step else out_features
+        return self._finish(out_features, inp_features)
+
+    def _finish(self, out_features, inp_features):
         if self.use_dense_layer_for_center:  # :462-464
             dense_output = inp_features @ self.dense
-            self._dense_output = None if in_step else dense_output
+            self._dense_output = None if _CACHE.depth > 0 else dense_output
             out_features = out_features + dense_output
             if self.use_bias:
                 out_features = out_features + self.bias
         if self.activation is not None:
             out_features = self.activation(out_features)
         return out_features
+
+    def _lattice_form(self, inp_features, inp_positions, out_positions, inp_importance, hash_table):
+        """The LatticePair for this call if dmcf_lattice_conv_forward applies: both position tensors registered grid_pos
+        lattices of one family (dmcf_amd/lattice.py), a named window, none of the options that form needs a pair list for."""
+        from .. import lattice
+        if (hash_table is not None or inp_importance is not None or self.symmetric or self.circular or self.normalize
+                or not isinstance(self.window_function, WindowFunction) or self.radius_search_ignore_query_points
+                or self.radius_search_metric != "L2" or not inp_features.is_cuda
+                or self.in_channels not in (4, 8) or self.filters > 32):
+            return None
+        return lattice.pair(inp_positions, out_positions)
 
     call = forward
 

@@ -599,3 +599,56 @@ def test_padded_single_pass_search_and_conv(dev, monkeypatch, kernel, cin, cout,
     small = ops.fixed_radius_search(P, Q, radius, return_distances=True, row_stride=max(longest // 2, 1))
     assert small.overflowed(int(small.max_count)) and int(small.max_count) == longest
     assert torch.equal(small.neighbors_index, exact.neighbors_index)
+
+
+def _lattice(rng, dims, occupancy, voxel, center, step=1):
+    """Random subset of the cells of a lattice box -> (cells int32 [n, 3] (x, y, z), positions as grid_pos forms them:
+    float(cell) * voxel + center, utils/tools/losses.py:176-177)."""
+    g = np.stack(np.meshgrid(*[np.arange(d, dtype=np.int32) for d in dims], indexing="ij"), -1).reshape(-1, 3)
+    g = g[rng.random(g.shape[0]) < occupancy]
+    g = g[rng.permutation(g.shape[0])]
+    pos = g.astype(np.float32) * (np.float32(voxel) * np.float32(step)) + center.astype(np.float32)
+    return g, pos.astype(np.float32)
+
+
+@pytest.mark.parametrize("case", ["same", "fine_to_coarse", "coarse_same"])
+def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
+    """dmcf_lattice_conv_forward (stencil form for two aligned grid_pos lattices: no search, one [Cin x Cout] matrix per
+    integer offset) against the oracle and against the neighbour-list kernels on the same points."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(21)
+    h = 0.05
+    center = rng.uniform(-0.5, 0.5, size=3)
+    if case == "same":            # s1 -> s1, R = 0.2
+        cin, cout, radius, step = 8, 16, 0.2, 1
+        icell, ipos = _lattice(rng, (14, 12, 13), 0.85, h, center)
+        ocell, opos = icell[: icell.shape[0] // 2 + 7], ipos[: icell.shape[0] // 2 + 7]
+        voxel = [h] * 3
+    elif case == "fine_to_coarse":  # s1 -> s2, R = 0.4: outputs on every second cell
+        cin, cout, radius, step = 8, 8, 0.4, 2
+        icell, ipos = _lattice(rng, (20, 18, 16), 0.8, h, center)
+        ocell, opos = _lattice(rng, (10, 9, 8), 0.7, h, center, step=2)
+        voxel = [h] * 3
+    else:                          # s2 -> s2, R = 0.4, spacing 0.1
+        cin, cout, radius, step = 4, 8, 0.4, 1
+        icell, ipos = _lattice(rng, (12, 11, 10), 0.9, 2 * h, center)
+        ocell, opos = icell, ipos
+        voxel = [2 * h] * 3
+    feat = rng.normal(size=(ipos.shape[0], cin)).astype(np.float32)
+    filt = rng.uniform(-1, 1, size=(4, 4, 4, cin, cout)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    tmin = icell.min(axis=0)
+    tdim = icell.max(axis=0) - tmin + 1
+    table = np.full((tdim[2], tdim[1], tdim[0]), -1, np.int32)
+    table[icell[:, 2] - tmin[2], icell[:, 1] - tmin[1], icell[:, 0] - tmin[0]] = np.arange(icell.shape[0], dtype=np.int32)
+    y = ops.lattice_conv(_t(filt, dev), _t(np.ascontiguousarray(ocell), dev), step, _t(table, dev), tmin, voxel, 2 * radius,
+                         _t(feat, dev), window="poly6", bias=_t(bias, dev)).cpu().numpy()
+    nns = ops.fixed_radius_search(_t(ipos, dev), _t(opos, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    ref = oracle.continuous_conv(filt, opos, 2 * radius, ipos, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2),
+                                 f64=True) + bias
+    _close(y, ref)
+    z = ops.cconv_forward(_t(filt, dev), _t(opos, dev), 2 * radius, _t(ipos, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
+                          bias=_t(bias, dev)).cpu().numpy()
+    _close(y, z.astype(np.float64))
