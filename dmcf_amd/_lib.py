@@ -49,16 +49,17 @@ class LatticeConvArgs(ctypes.Structure):
     _fields_ = [
         ("filters", ctypes.c_void_p),
         ("filter_dims", ctypes.c_int32 * 5),
-        ("out_cells", ctypes.c_void_p),
+        ("inp_volume", ctypes.c_void_p),
+        ("inp_min", ctypes.c_int32 * 3),
+        ("inp_dims", ctypes.c_int32 * 3),
+        ("out_table", ctypes.c_void_p),
+        ("out_min", ctypes.c_int32 * 3),
+        ("out_dims", ctypes.c_int32 * 3),
         ("n_out", ctypes.c_int64),
         ("out_step", ctypes.c_int32),
-        ("inp_table", ctypes.c_void_p),
-        ("table_min", ctypes.c_int32 * 3),
-        ("table_dims", ctypes.c_int32 * 3),
         ("voxel", ctypes.c_float * 3),
         ("offsets", ctypes.c_void_p),
         ("n_offsets", ctypes.c_int64),
-        ("inp_features", ctypes.c_void_p),
         ("extent", ctypes.c_float),
         ("window_fac", ctypes.c_float),
         ("window", ctypes.c_int32),

@@ -7,13 +7,17 @@
 //     out_i = sum_d  W_d^T f_{cell(i) + d},     W_d[c][o] = window(d) * sum_{8 corners t} w_t(d) W[cell_t(d)][c][o]
 //
 // one [Cin x Cout] matrix per stencil offset (a few hundred to ~2000 offsets inside the radius), no neighbour search, no
-// per-pair geometry: a dense product over features gathered through a cell -> point table of the input lattice.
+// per-pair geometry: a 3-D convolution.  The caller lays the input features out by lattice cell (a dense volume over the
+// input lattice's bounding box, zeros in empty cells), so the operand rows of a tile are contiguous memory:
 //   lat_build_filters   one thread per element of the per-offset matrices, packed in MFMA B-fragment order
-//   lat_conv_kernel     tile = 16 output points (M of v_mfma_f32_16x16x4_f32), N = 16 output channels, K = 4 input channels
-//                       of one offset; the 4 waves of a workgroup split the stencil, 4 offsets in flight per wave (table
-//                       lookup -> feature gather are two dependent loads), partial sums reduced through LDS.
+//   lat_conv_kernel     tile = 16 consecutive output cells along x (M of v_mfma_f32_16x16x4_f32), N = 16 output channels,
+//                       K = 4 input channels of one offset.  Per offset and tile ONE load instruction (rows 32 B apart for
+//                       8 channels: 512 contiguous bytes, re-read from L1 as the stencil slides along x); the per-offset
+//                       matrices are staged through LDS in chunks and shared by the 4 waves x 2 tiles of a workgroup.  A
+//                       first version gathered rows through a cell -> point table in point order: 2.3 ms for the s1 -> s1
+//                       layer of the 1M-particle scene, bound by 9.5 GB of scattered 32-byte reads.
 // The offsets are nominal (d * voxel in fp32); the reference forms fl(x_in) - fl(x_out), which differs by ~1 ulp of |x|:
-// about 3e-6 of the output scale at |x| ~ 5.  Pairs at exactly the radius have window 0 either way.
+// up to 1e-5 of the output scale at |x| ~ 6.  Pairs at exactly the radius have window 0 either way.
 #include "cconv_common.h"
 
 namespace dmcf {
@@ -22,12 +26,13 @@ struct LatParams {
     const float* Wp;          // [S][KS][NT][64]
     const int32_t* stencil;   // [S][4]: dx, dy, dz of the input cell relative to out_cell * out_step
     int S, KS, NT, cin, cout;
-    const int32_t* out_cells;  // [n_out][3] (x, y, z)
-    int64_t n_out;
+    const float* vol;          // [idim z][y][x][cin]
+    int imin[3], idim[3];      // (x, y, z)
+    const int32_t* otab;       // [odim z][y][x]: output point index or -1
+    int omin[3], odim[3];
     int out_step;
-    const int32_t* table;      // [tdz][tdy][tdx]: input point index or -1
-    int tmin[3], tdim[3];      // (x, y, z)
-    const float* feat;
+    int tiles_x;               // ceil(odim x / 16)
+    int64_t ntiles;
     const float* bias;
     float* out;
     int flags;
@@ -70,38 +75,45 @@ __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict
     }
 }
 
-constexpr int kLatTW = 2;   // 16-point tiles per wave
+constexpr int kLatTW = 2;   // 16-cell tiles per wave
 constexpr int kLatCH = 32;  // stencil offsets per LDS chunk of the per-offset matrices
-#ifndef LAT_U
-#define LAT_U 4
-#endif
-constexpr int kLatU = LAT_U;  // offsets whose lookup -> gather chains are in flight together (x kLatTW tiles)
+constexpr int kLatU = 4;    // offsets whose loads are in flight together (x kLatTW tiles)
 
-// Workgroup = 4 waves x kLatTW tiles = 128 output points.  Every wave walks the WHOLE stencil for its own tiles (no
-// cross-wave reduction); the per-offset matrices are staged through LDS in chunks of kLatCH offsets and shared by the
-// waves.  Per offset and tile: one table lookup and one feature gather (KST consecutive channels per lane).
+// Workgroup = 4 waves x kLatTW tiles.  Every wave walks the whole stencil for its own tiles (no cross-wave reduction); the
+// per-offset matrices are staged through LDS in chunks of kLatCH offsets and shared by the waves.  The chunk's offsets sit
+// in the registers of lanes 0 .. kLatCH-1 (one 16-byte load per lane) and are broadcast with v_readlane: the first version
+// read them with scalar loads inside the loop, three dependent scalar-cache round trips per offset.
 template <int NTT, int KST>
 __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     __shared__ float Ws[kLatCH * KST * NTT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
-    int cx[kLatTW], cy[kLatTW], cz[kLatTW];
-    bool valid[kLatTW];
+    int oidx[kLatTW];       // output point of this lane's row (lanes of one row agree), -1: none, -2: tile without points
+    int64_t rowb[kLatTW];   // element offset of (z, y, x = this row) in the volume for offset (0, 0, 0)
+    int ix[kLatTW], iy[kLatTW], iz[kLatTW];
     f32x4 acc[kLatTW][NTT];
+    bool any = false;
 #pragma unroll
     for (int t = 0; t < kLatTW; ++t) {
-        const int64_t i = ((int64_t)blockIdx.x * 4 * kLatTW + wave * kLatTW + t) * 16 + m;
-        valid[t] = i < p.n_out;
-        cx[t] = cy[t] = cz[t] = 0;
-        if (valid[t]) {
-            cx[t] = p.out_cells[3 * i] * p.out_step - p.tmin[0];
-            cy[t] = p.out_cells[3 * i + 1] * p.out_step - p.tmin[1];
-            cz[t] = p.out_cells[3 * i + 2] * p.out_step - p.tmin[2];
+        const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * kLatTW + t;
+        oidx[t] = -1;
+        ix[t] = iy[t] = iz[t] = 0;
+        if (tile < p.ntiles) {
+            const int xb = (int)(tile % p.tiles_x);
+            const int y = (int)(tile / p.tiles_x % p.odim[1]), z = (int)(tile / ((int64_t)p.tiles_x * p.odim[1]));
+            const int xo = xb * 16 + m;
+            if (xo < p.odim[0]) oidx[t] = p.otab[((int64_t)z * p.odim[1] + y) * p.odim[0] + xo];
+            ix[t] = (p.omin[0] + xo) * p.out_step - p.imin[0];
+            iy[t] = (p.omin[1] + y) * p.out_step - p.imin[1];  // wave uniform per tile
+            iz[t] = (p.omin[2] + z) * p.out_step - p.imin[2];
         }
+        rowb[t] = (((int64_t)iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin + q * KST;
+        if (__ballot(oidx[t] >= 0) == 0) oidx[t] = -2;  // nothing to compute in this tile (the whole wave agrees)
+        any |= oidx[t] != -2;
 #pragma unroll
         for (int n = 0; n < NTT; ++n) acc[t][n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
-    const float* fq = p.feat + q * KST;
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
     for (int s0 = 0; s0 < p.S; s0 += kLatCH) {
         const int ns = min(kLatCH, p.S - s0);
         __syncthreads();
@@ -110,35 +122,30 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
             const int l = e & 63, n = (e >> 6) % NTT, ks = (e >> 6) / NTT % KST, so = (e >> 6) / (NTT * KST);
             Ws[e] = n < p.NT ? p.Wp[(((int64_t)(s0 + so) * KST + ks) * p.NT + n) * 64 + l] : 0.0f;
         }
+        const i32x4 dv = *(const i32x4*)(p.stencil + 4 * min(s0 + lane, p.S - 1));  // offset s0 + lane
+        const int64_t dof = (((int64_t)dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin;
+        const int dof_lo = (int)(uint32_t)dof, dof_hi = (int)(dof >> 32);
         __syncthreads();
+        if (!any) continue;
         for (int so = 0; so < ns; so += kLatU) {
-            // kLatU offsets x kLatTW tiles: independent lookup -> gather chains in flight together
-            int idx[kLatU][kLatTW];
-#pragma unroll
-            for (int u = 0; u < kLatU; ++u) {
-                const int s = s0 + so + u;  // wave uniform
-                const int dx = s < p.S ? p.stencil[4 * s] : 0, dy = s < p.S ? p.stencil[4 * s + 1] : 0,
-                          dz = s < p.S ? p.stencil[4 * s + 2] : 0;
-#pragma unroll
-                for (int t = 0; t < kLatTW; ++t) {
-                    const int x = cx[t] + dx, y = cy[t] + dy, z = cz[t] + dz;
-                    idx[u][t] = -1;
-                    if (so + u < ns && valid[t] && (unsigned)x < (unsigned)p.tdim[0] && (unsigned)y < (unsigned)p.tdim[1] &&
-                        (unsigned)z < (unsigned)p.tdim[2])
-                        idx[u][t] = p.table[((int64_t)z * p.tdim[1] + y) * p.tdim[0] + x];
-                }
-            }
             float fv[kLatU][kLatTW][KST];
 #pragma unroll
-            for (int u = 0; u < kLatU; ++u)
+            for (int u = 0; u < kLatU; ++u) {
+                const int sl = min(so + u, kLatCH - 1);  // wave uniform
+                const int dx = __builtin_amdgcn_readlane(dv.x, sl), dy = __builtin_amdgcn_readlane(dv.y, sl),
+                          dz = __builtin_amdgcn_readlane(dv.z, sl);
+                const int64_t doff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dof_hi, sl) << 32) |
+                                               (uint32_t)__builtin_amdgcn_readlane(dof_lo, sl));
 #pragma unroll
                 for (int t = 0; t < kLatTW; ++t) {
 #pragma unroll
                     for (int ks = 0; ks < KST; ++ks) fv[u][t][ks] = 0.0f;
-                    if (idx[u][t] >= 0) {
-                        const float* src = fq + (int64_t)idx[u][t] * p.cin;
+                    const bool rows_in = oidx[t] != -2 && so + u < ns && (unsigned)(iy[t] + dy) < (unsigned)p.idim[1] &&
+                                         (unsigned)(iz[t] + dz) < (unsigned)p.idim[2];  // wave uniform
+                    if (rows_in && (unsigned)(ix[t] + dx) < (unsigned)p.idim[0]) {
+                        const float* src = p.vol + rowb[t] + doff;
                         if constexpr (KST == 2) {
-                            const f32x2 v = *(const f32x2*)src;  // rows are 16-byte aligned (cin = 8), q * 2 floats in
+                            const f32x2 v = *(const f32x2*)src;  // rows are 32 bytes (cin = 8), q * 8 bytes in
                             fv[u][t][0] = v.x;
                             fv[u][t][1] = v.y;
                         } else {
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
                         }
                     }
                 }
+            }
 #pragma unroll
             for (int u = 0; u < kLatU; ++u) {
                 if (so + u < ns) {
@@ -156,29 +164,28 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
                         for (int n = 0; n < NTT; ++n) {
                             const float w = Ws[(((so + u) * KST + ks) * NTT + n) * 64 + lane];
 #pragma unroll
-                            for (int t = 0; t < kLatTW; ++t) {
+                            for (int t = 0; t < kLatTW; ++t)
                                 acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][t][ks], w, acc[t][n], 0, 0, 0);
-                            }
                         }
                 }
             }
         }
     }
-    // D layout: lane (rows 4 (lane >> 4) + r, column lane & 15)
+    // D layout: lane (rows 4 (lane >> 4) + r, column lane & 15); the row's output point sits in lane 4 q + r of oidx
 #pragma unroll
     for (int t = 0; t < kLatTW; ++t) {
-        const int64_t i0 = ((int64_t)blockIdx.x * 4 * kLatTW + wave * kLatTW + t) * 16;
+        if (oidx[t] == -2) continue;
 #pragma unroll
-        for (int n = 0; n < NTT; ++n) {
-            const int o = 16 * n + m;
-            if (o >= p.cout) continue;
+        for (int r = 0; r < 4; ++r) {
+            const int oi = __shfl(oidx[t], 4 * q + r, 64);
+            if (oi < 0) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int64_t ii = i0 + 4 * q + r;
-                if (ii >= p.n_out) continue;
+            for (int n = 0; n < NTT; ++n) {
+                const int o = 16 * n + m;
+                if (o >= p.cout) continue;
                 float v = acc[t][n][r];
                 if (p.bias) v += p.bias[o];
-                float* dst = p.out + ii * p.cout + o;
+                float* dst = p.out + (int64_t)oi * p.cout + o;
                 if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
                 *dst = v;
             }
@@ -196,10 +203,10 @@ static int lat_validate(const dmcf_lattice_conv_args* a) {
     for (int k = 0; k < 5; ++k)
         if (a->filter_dims[k] <= 0) return DMCF_EINVAL;
     if (a->n_out < 0 || a->n_offsets < 0 || a->out_step <= 0 || !(a->extent > 0.0f)) return DMCF_EINVAL;
-    if (a->n_out > 0 && (!a->filters || !a->out_cells || !a->out || !a->inp_table || !a->inp_features || (a->n_offsets > 0 && !a->offsets)))
+    if (a->n_out > 0 && (!a->filters || !a->out_table || !a->out || !a->inp_volume || (a->n_offsets > 0 && !a->offsets)))
         return DMCF_EINVAL;
     for (int k = 0; k < 3; ++k)
-        if (a->table_dims[k] <= 0 || !(a->voxel[k] >= 0.0f)) return DMCF_EINVAL;
+        if (a->inp_dims[k] <= 0 || a->out_dims[k] <= 0 || !(a->voxel[k] >= 0.0f)) return DMCF_EINVAL;
     if (a->flags & (DMCF_FLAG_SYMMETRIC | DMCF_FLAG_NORMALIZE)) return DMCF_EUNSUPPORTED;
     if (a->window == DMCF_WINDOW_EXPLICIT) return DMCF_EUNSUPPORTED;
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
@@ -250,13 +257,19 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
     p.Wp = packed;
     p.stencil = a->offsets;
     p.S = (int)a->n_offsets; p.KS = KS; p.NT = NT; p.cin = cin; p.cout = cout;
-    p.out_cells = a->out_cells; p.n_out = a->n_out; p.out_step = a->out_step;
-    p.table = a->inp_table;
-    for (int k = 0; k < 3; ++k) { p.tmin[k] = a->table_min[k]; p.tdim[k] = a->table_dims[k]; }
-    p.feat = a->inp_features; p.bias = a->bias; p.out = a->out; p.flags = a->flags;
-    const int64_t tiles = (a->n_out + 16 * 4 * kLatTW - 1) / (16 * 4 * kLatTW);
-    if (tiles > 0x7fffffff) return DMCF_EUNSUPPORTED;
-    const dim3 grid((unsigned)tiles), block(256);
+    p.vol = a->inp_volume;
+    p.otab = a->out_table;
+    for (int k = 0; k < 3; ++k) {
+        p.imin[k] = a->inp_min[k]; p.idim[k] = a->inp_dims[k];
+        p.omin[k] = a->out_min[k]; p.odim[k] = a->out_dims[k];
+    }
+    p.out_step = a->out_step;
+    p.tiles_x = (a->out_dims[0] + 15) / 16;
+    p.ntiles = (int64_t)p.tiles_x * a->out_dims[1] * a->out_dims[2];
+    p.bias = a->bias; p.out = a->out; p.flags = a->flags;
+    const int64_t groups = (p.ntiles + 4 * kLatTW - 1) / (4 * kLatTW);
+    if (groups > 0x7fffffff) return DMCF_EUNSUPPORTED;
+    const dim3 grid((unsigned)groups), block(256);
     if (KS == 1 && NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 1>), grid, block, 0, stream, p);
     else if (KS == 1) hipLaunchKernelGGL((lat_conv_kernel<2, 1>), grid, block, 0, stream, p);
     else if (NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 2>), grid, block, 0, stream, p);

@@ -26,6 +26,7 @@ class LatticeInfo:
         self.minp = [int(v) for v in minp]  # (x, y, z) corner of a box of cells that holds every point
         self.dims = [int(v) for v in dims]
         self._cells = None
+        self._lin = None
         self._table = None
 
     def cells(self):
@@ -35,16 +36,29 @@ class LatticeInfo:
             self._cells = torch.round((self.gpos - self.center) / v).to(torch.int32).contiguous()
         return self._cells
 
+    def lin(self):
+        """int64 [n]: the points' positions in a dense [dz, dy, dx] array over the box."""
+        if self._lin is None:
+            dx, dy, dz = self.dims
+            c = self.cells().long()
+            self._lin = ((c[:, 2] - self.minp[2]) * dy + (c[:, 1] - self.minp[1])) * dx + (c[:, 0] - self.minp[0])
+        return self._lin
+
     def table(self):
         """int32 [dz, dy, dx]: index of the point in each cell of the box, -1 where there is none."""
         if self._table is None:
             dx, dy, dz = self.dims
-            c = self.cells().long()
-            lin = ((c[:, 2] - self.minp[2]) * dy + (c[:, 1] - self.minp[1])) * dx + (c[:, 0] - self.minp[0])
             t = torch.full((dz * dy * dx,), -1, dtype=torch.int32, device=self.gpos.device)
-            t[lin] = torch.arange(c.shape[0], dtype=torch.int32, device=self.gpos.device)
+            t[self.lin()] = torch.arange(self.gpos.shape[0], dtype=torch.int32, device=self.gpos.device)
             self._table = t.view(dz, dy, dx)
         return self._table
+
+    def volume(self, features):
+        """float32 [dz, dy, dx, C]: ``features`` [n, C] by cell, zeros where there is no point."""
+        dx, dy, dz = self.dims
+        v = features.new_zeros((dz * dy * dx, features.shape[1]))
+        v[self.lin()] = features
+        return v.view(dz, dy, dx, features.shape[1])
 
 
 def register(gpos, center, voxel, family, minp, dims):

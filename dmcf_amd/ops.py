@@ -241,7 +241,19 @@ def pair_capacity(total):
     for the same few block sizes every step instead of a slightly different one each time (each new size is a
     hipMalloc of hundreds of MB: measured 12-18 GB of fresh allocations per step until sizes happened to repeat)."""
     x = int(total) + int(total) // 8 + 65536
-    g = max(1 << 16, 1 << max(x.bit_length() - 4, 0))
+    return _size_class(x)
+
+
+def _size_class(x):
+    """Buffer sizes (in 4-byte entries) the caching allocator can hand around: 1/8 of the enclosing power of two, and from
+    512 MB on whole multiples of 1 GB -- the big lists of a step then fall into two or three classes, a block freed by
+    one list fits the next one exactly instead of being split, and the pool stops growing after a step or two (with finer
+    classes the pool of the 1M-particle rollout was still growing -- a fresh 3 GB hipMalloc, 100 ms -- in its fifth step)."""
+    x = max(int(x), 1)
+    if x >= 1 << 27:
+        g = 1 << 28
+    else:
+        g = max(1 << 16, 1 << max(x.bit_length() - 4, 0))
     return (x + g - 1) // g * g
 
 
@@ -274,8 +286,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         stride = max(int(row_stride), 1)
         # allocation sizes in coarse buckets (see pair_capacity): the lattice point sets change size every step
         need = m * stride
-        g = max(1 << 16, 1 << max(need.bit_length() - 4, 0))
-        cap = (need + g - 1) // g * g
+        cap = _size_class(need)
         # a caller that repeats this search every step passes the capacity it got last time: while that still fits (and
         # is not grossly oversized) the request stays byte-identical, and the caching allocator answers it without a
         # hipMalloc (a fresh 2 GB block costs 20-120 ms; m * stride hovers around a bucket edge for steps on end)
@@ -475,33 +486,35 @@ def lattice_offsets(voxel, radius, device):
     return st
 
 
-def lattice_conv(filters, out_cells, out_step, inp_table, table_min, voxel, extent, inp_features, window="poly6",
+def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, out_step, n_out, voxel, extent, window="poly6",
                  window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
                  interpolation="linear", bias=None, out=None, accumulate=False):
     """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
-    ``out_cells`` int32 [n_out, 3] (x, y, z), ``inp_table`` int32 [dz, dy, dx] (input point index or -1) whose entry 0
-    is cell ``table_min`` (x, y, z), ``voxel`` the input lattice spacing (x, y, z)."""
+    ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
+    ``inp_min`` (x, y, z); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
+    entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z)."""
     L = _lib.lib()
     dev = filters.device
-    n_out, cin, cout = out_cells.shape[0], filters.shape[3], filters.shape[4]
+    cin, cout = filters.shape[3], filters.shape[4]
     if out is None:
         if accumulate:
             raise ValueError("accumulate=True needs an out tensor")
-        out = torch.empty((n_out, cout), dtype=torch.float32, device=dev)
+        out = torch.zeros((n_out, cout), dtype=torch.float32, device=dev)  # rows without a cell stay 0
     offsets = lattice_offsets(voxel, 0.5 * float(extent), dev)
-    filters, inp_features = filters.contiguous(), inp_features.contiguous()
+    filters = filters.contiguous()
+    if inp_volume.dim() != 4 or inp_volume.shape[3] != cin or not inp_volume.is_contiguous() or not out_table.is_contiguous():
+        raise ValueError("inp_volume must be a contiguous [dz, dy, dx, Cin] tensor, out_table a contiguous [dz, dy, dx] one")
     a = _lib.LatticeConvArgs()
     a.filters = _ptr(filters)
     for k in range(5):
         a.filter_dims[k] = int(filters.shape[k])
-    a.out_cells, a.n_out, a.out_step = _ptr(out_cells), n_out, int(out_step)
-    a.inp_table = _ptr(inp_table)
+    a.inp_volume, a.out_table = _ptr(inp_volume), _ptr(out_table)
     for k in range(3):
-        a.table_min[k] = int(table_min[k])
-        a.table_dims[k] = int(inp_table.shape[2 - k])
+        a.inp_min[k], a.inp_dims[k] = int(inp_min[k]), int(inp_volume.shape[2 - k])
+        a.out_min[k], a.out_dims[k] = int(out_min[k]), int(out_table.shape[2 - k])
         a.voxel[k] = float(voxel[k])
+    a.n_out, a.out_step = int(n_out), int(out_step)
     a.offsets, a.n_offsets = _ptr(offsets), int(offsets.shape[0])
-    a.inp_features = _ptr(inp_features)
     a.extent, a.window_fac = float(extent), float(window_fac)
     a.window = WINDOWS[window]
     a.coordinate_mapping, a.interpolation = MAPPINGS[coordinate_mapping], INTERPOLATIONS[interpolation]
@@ -513,7 +526,7 @@ def lattice_conv(filters, out_cells, out_step, inp_table, table_min, voxel, exte
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_lattice_conv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
     if timer is not None:
-        timer.end("cconv", dict(pairs=n_out * int(offsets.shape[0]), n_out=n_out, cin=int(cin), cout=int(cout),
+        timer.end("cconv", dict(pairs=int(n_out) * int(offsets.shape[0]), n_out=int(n_out), cin=int(cin), cout=int(cout),
                                 K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
     return out
 

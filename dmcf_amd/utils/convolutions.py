@@ -379,8 +379,9 @@ class ContinuousConv(torch.nn.Module):
                 self._n_out_last = out_positions.shape[0]
                 self._pairs_last = out_positions.shape[0] * int(offsets.shape[0])  # upper bound: cells, not points
                 out_features = ops.lattice_conv(
-                    self.kernel, lat.out.cells(), lat.step, lat.inp.table(), lat.inp.minp, lat.inp.voxel, extent,
-                    inp_features, window=self.window_function.name, window_fac=self.window_function.fac,
+                    self.kernel, lat.inp.volume(inp_features), lat.inp.minp, lat.out.table(), lat.out.minp, lat.step,
+                    out_positions.shape[0], lat.inp.voxel, extent,
+                    window=self.window_function.name, window_fac=self.window_function.fac,
                     align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
                     interpolation=self.interpolation, bias=self.bias if fuse_bias else None)
                 self._conv_values, self._conv_output = None, (None if _CACHE.depth > 0 else out_features)

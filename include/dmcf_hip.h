@@ -197,9 +197,10 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
  * coarse scales of the multi-scale models: models/hrnet.py:85-92 convolves between the outputs of grid_pos
  * (utils/tools/losses.py:136-181, via get_dilated_pos :266-272), which share one centre and whose voxel sizes are integer
  * multiples of each other.  Input point j sits at centre + inp_cell_j * voxel, output point i at
- * centre + out_cells[i] * out_step * voxel; every per-pair quantity of the operator depends only on the integer offset
- * d = inp_cell_j - out_cells[i] * out_step, so no neighbour list is needed: the caller passes the offsets inside the
- * radius and a dense cell -> input point table.  Same filters / extent / window / mapping / interpolation /
+ * centre + out_cell_i * out_step * voxel; every per-pair quantity of the operator depends only on the integer offset
+ * d = inp_cell_j - out_cell_i * out_step, so no neighbour list is needed: the caller passes the offsets inside the
+ * radius, the input features laid out by lattice cell (a dense volume over the bounding box of the input lattice) and
+ * a cell -> output point table of the output lattice.  Same filters / extent / window / mapping / interpolation /
  * ALIGN_CORNERS / bias / ACCUMULATE semantics as dmcf_cconv_forward; SYMMETRIC, NORMALIZE, DMCF_WINDOW_EXPLICIT and
  * importances are not supported (DMCF_EUNSUPPORTED: use the neighbour-list form).  Results agree with the neighbour-list
  * form to the rounding of the positions (the reference subtracts rounded positions, this form uses d * voxel).
@@ -207,16 +208,17 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
 typedef struct dmcf_lattice_conv_args {
     const float* filters;        /* [D,H,W,Cin,Cout] */
     int32_t filter_dims[5];
-    const int32_t* out_cells;    /* [n_out,3] (x,y,z) integer lattice coordinates of the output points */
-    int64_t n_out;
+    const float* inp_volume;     /* [inp_dims z][y][x][Cin]: the input features by lattice cell, zeros where no point is */
+    int32_t inp_min[3];          /* (x,y,z) cell of entry 0 of inp_volume, in units of the input lattice */
+    int32_t inp_dims[3];         /* (x,y,z) */
+    const int32_t* out_table;    /* [out_dims z][y][x]: index of the output point in that cell of the OUTPUT lattice, or -1 */
+    int32_t out_min[3];          /* (x,y,z) cell of entry 0 of out_table, in units of the output lattice */
+    int32_t out_dims[3];
+    int64_t n_out;               /* rows of `out` */
     int32_t out_step;            /* output spacing / input spacing (1: same lattice, 2: outputs on the coarser lattice) */
-    const int32_t* inp_table;    /* [table_dims z][y][x]: index of the input point in that cell, or -1 */
-    int32_t table_min[3];        /* (x,y,z) cell of table entry 0 */
-    int32_t table_dims[3];       /* (x,y,z) */
     float voxel[3];              /* (x,y,z) spacing of the input lattice */
     const int32_t* offsets;      /* [n_offsets,4]: (dx,dy,dz,0) with |d * voxel| <= extent / 2 */
     int64_t n_offsets;
-    const float* inp_features;   /* [n_inp,Cin] */
     float extent;
     float window_fac;
     int32_t window;              /* enum dmcf_window (applied to |d * voxel|^2 / radius^2) */
@@ -224,7 +226,7 @@ typedef struct dmcf_lattice_conv_args {
     int32_t interpolation;
     int32_t flags;               /* DMCF_FLAG_ALIGN_CORNERS | DMCF_FLAG_ACCUMULATE */
     const float* bias;           /* [Cout] or NULL */
-    float* out;                  /* [n_out,Cout] */
+    float* out;                  /* [n_out,Cout]; rows of points that are in out_table are written */
 } dmcf_lattice_conv_args;
 
 size_t dmcf_lattice_conv_workspace_bytes(const dmcf_lattice_conv_args* args);

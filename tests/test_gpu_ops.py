@@ -637,12 +637,16 @@ def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
     feat = rng.normal(size=(ipos.shape[0], cin)).astype(np.float32)
     filt = rng.uniform(-1, 1, size=(4, 4, 4, cin, cout)).astype(np.float32)
     bias = rng.normal(size=cout).astype(np.float32)
-    tmin = icell.min(axis=0)
-    tdim = icell.max(axis=0) - tmin + 1
-    table = np.full((tdim[2], tdim[1], tdim[0]), -1, np.int32)
-    table[icell[:, 2] - tmin[2], icell[:, 1] - tmin[1], icell[:, 0] - tmin[0]] = np.arange(icell.shape[0], dtype=np.int32)
-    y = ops.lattice_conv(_t(filt, dev), _t(np.ascontiguousarray(ocell), dev), step, _t(table, dev), tmin, voxel, 2 * radius,
-                         _t(feat, dev), window="poly6", bias=_t(bias, dev)).cpu().numpy()
+    imin = icell.min(axis=0) - 1  # boxes with a margin, as the candidate box of grid_pos has
+    idim = icell.max(axis=0) - imin + 2
+    vol = np.zeros((idim[2], idim[1], idim[0], cin), np.float32)
+    vol[icell[:, 2] - imin[2], icell[:, 1] - imin[1], icell[:, 0] - imin[0]] = feat
+    omin = ocell.min(axis=0)
+    odim = ocell.max(axis=0) - omin + 1
+    otab = np.full((odim[2], odim[1], odim[0]), -1, np.int32)
+    otab[ocell[:, 2] - omin[2], ocell[:, 1] - omin[1], ocell[:, 0] - omin[0]] = np.arange(ocell.shape[0], dtype=np.int32)
+    y = ops.lattice_conv(_t(filt, dev), _t(vol, dev), imin, _t(otab, dev), omin, step, ocell.shape[0], voxel, 2 * radius,
+                         window="poly6", bias=_t(bias, dev)).cpu().numpy()
     nns = ops.fixed_radius_search(_t(ipos, dev), _t(opos, dev), radius, return_distances=True)
     idx, rs, d = (x.cpu().numpy() for x in nns)
     ref = oracle.continuous_conv(filt, opos, 2 * radius, ipos, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2),

@@ -23,23 +23,32 @@ def cells(x, step):
     assert torch.all(c % step == 0)
     return (c // step).contiguous()
 
-def table_of(c):
-    tmin = c.amin(dim=0)
-    tdim = (c.amax(dim=0) - tmin + 1).tolist()
-    t = torch.full((tdim[2], tdim[1], tdim[0]), -1, dtype=torch.int32, device=dev)
-    d = (c - tmin).long()
-    t[d[:, 2], d[:, 1], d[:, 0]] = torch.arange(c.shape[0], dtype=torch.int32, device=dev)
-    return t, tmin.tolist()
+def box(c):
+    lo = c.amin(dim=0)
+    return lo.tolist(), (c.amax(dim=0) - lo + 1).tolist()
+
+def lin_of(c, lo, dim):
+    d = (c - torch.tensor(lo, device=dev, dtype=torch.int32)).long()
+    return (d[:, 2] * dim[1] + d[:, 1]) * dim[0] + d[:, 0]
 
 for name, inp, out, istep, ostep, R, cin, cout in [("s1->s1  8->16", s1, s1, 1, 1, 0.2, 8, 16), ("s1->s2  8->8 ", s1, s2, 1, 2, 0.4, 8, 8),
                                                    ("s2->s2  4->8 ", s2, s2, 2, 2, 0.4, 4, 8)]:
     feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
     W = torch.rand(4, 4, 4, cin, cout, device=dev, generator=g) - 0.5
     ic, oc = cells(inp, istep), cells(out, ostep)
-    t_tab = timed(lambda: table_of(ic))
-    tab, tmin = table_of(ic)
+    ilo, idim = box(ic)
+    olo, odim = box(oc)
+    il, ol = lin_of(ic, ilo, idim), lin_of(oc, olo, odim)
+    def prep():
+        vol = feat.new_zeros((idim[2] * idim[1] * idim[0], cin))
+        vol[il] = feat
+        tab = torch.full((odim[2] * odim[1] * odim[0],), -1, dtype=torch.int32, device=dev)
+        tab[ol] = torch.arange(oc.shape[0], dtype=torch.int32, device=dev)
+        return vol.view(idim[2], idim[1], idim[0], cin), tab.view(odim[2], odim[1], odim[0])
+    t_tab = timed(prep)
+    vol, tab = prep()
     voxel = [h * istep] * 3
-    f_lat = lambda: ops.lattice_conv(W, oc, ostep // istep, tab, tmin, voxel, 2 * R, feat, window="poly6")
+    f_lat = lambda: ops.lattice_conv(W, vol, ilo, tab, olo, ostep // istep, out.shape[0], voxel, 2 * R, window="poly6")
     y = f_lat()
     t_lat = timed(f_lat)
     t_search = timed(lambda: ops.fixed_radius_search(inp, out, R, return_distances=True))
@@ -49,5 +58,5 @@ for name, inp, out, istep, ostep, R, cin, cout in [("s1->s1  8->16", s1, s1, 1, 
     z = f_nl()
     t_nl = timed(f_nl)
     err = float((y - z).abs().max() / z.abs().max())
-    print(f"{name}: pairs {nns.neighbors_index.shape[0]/1e6:6.1f}M  lattice {t_lat:6.2f} ms (+ table {t_tab:5.2f})   neighbour list: "
+    print(f"{name}: pairs {nns.neighbors_index.shape[0]/1e6:6.1f}M  lattice {t_lat:6.2f} ms (+ volume / table {t_tab:5.2f})   neighbour list: "
           f"conv {t_nl:6.2f} ms + search {t_search:5.2f} ms   max diff {err:.1e}", flush=True)
