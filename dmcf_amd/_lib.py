@@ -56,7 +56,12 @@ class LatticeConvArgs(ctypes.Structure):
         ("out_min", ctypes.c_int32 * 3),
         ("out_dims", ctypes.c_int32 * 3),
         ("n_out", ctypes.c_int64),
-        ("out_step", ctypes.c_int32),
+        ("inp_step", ctypes.c_int32),
+        ("out_stride", ctypes.c_int32),
+        ("out_phase", ctypes.c_int32 * 3),
+        ("base_min", ctypes.c_int32 * 3),
+        ("base_dims", ctypes.c_int32 * 3),
+        ("rel_shift", ctypes.c_float * 3),
         ("voxel", ctypes.c_float * 3),
         ("offsets", ctypes.c_void_p),
         ("n_offsets", ctypes.c_int64),

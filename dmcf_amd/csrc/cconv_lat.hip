@@ -30,8 +30,9 @@ struct LatParams {
     int imin[3], idim[3];      // (x, y, z)
     const int32_t* otab;       // [odim z][y][x]: output point index or -1
     int omin[3], odim[3];
-    int out_step;
-    int tiles_x;               // ceil(odim x / 16)
+    int inp_step, out_stride, phase[3];
+    int amin[3], adim[3];      // box of the base vectors a: output cell a * out_stride + phase, input cell a * inp_step + d
+    int tiles_x;               // ceil(adim x / 16)
     int64_t ntiles;
     const float* bias;
     float* out;
@@ -40,7 +41,7 @@ struct LatParams {
 
 __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict__ W, float* __restrict__ Wp,
                                                          const int32_t* __restrict__ stencil, int S, int KS, int NT, CconvParams p,
-                                                         float vx, float vy, float vz) {
+                                                         float vx, float vy, float vz, float sx, float sy, float sz) {
     const int64_t total = (int64_t)S * KS * NT * 64;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = e;
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict
         const int c = q * KS + ks, o = nt * 16 + n;  // lane q of the A operand holds channels q * KS .. q * KS + KS - 1
         float v = 0.0f;
         if (c < p.cin && o < p.cout) {
-            float x = (float)stencil[4 * s] * vx, y = (float)stencil[4 * s + 1] * vy, z = (float)stencil[4 * s + 2] * vz;
+            float x = (float)stencil[4 * s] * vx - sx, y = (float)stencil[4 * s + 1] * vy - sy, z = (float)stencil[4 * s + 2] * vz - sz;
             const float d2 = (x * x + y * y) + z * z;
             const float a = window_value(p.window, d2, p.inv_r2, p.window_fac);
             filter_coords<true>(x, y, z, p);
@@ -100,12 +101,16 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
         ix[t] = iy[t] = iz[t] = 0;
         if (tile < p.ntiles) {
             const int xb = (int)(tile % p.tiles_x);
-            const int y = (int)(tile / p.tiles_x % p.odim[1]), z = (int)(tile / ((int64_t)p.tiles_x * p.odim[1]));
-            const int xo = xb * 16 + m;
-            if (xo < p.odim[0]) oidx[t] = p.otab[((int64_t)z * p.odim[1] + y) * p.odim[0] + xo];
-            ix[t] = (p.omin[0] + xo) * p.out_step - p.imin[0];
-            iy[t] = (p.omin[1] + y) * p.out_step - p.imin[1];  // wave uniform per tile
-            iz[t] = (p.omin[2] + z) * p.out_step - p.imin[2];
+            const int ax = p.amin[0] + xb * 16 + m, ay = p.amin[1] + (int)(tile / p.tiles_x % p.adim[1]),
+                      az = p.amin[2] + (int)(tile / ((int64_t)p.tiles_x * p.adim[1]));
+            const int ox = ax * p.out_stride + p.phase[0] - p.omin[0], oy = ay * p.out_stride + p.phase[1] - p.omin[1],
+                      oz = az * p.out_stride + p.phase[2] - p.omin[2];
+            if (xb * 16 + m < p.adim[0] && (unsigned)ox < (unsigned)p.odim[0] && (unsigned)oy < (unsigned)p.odim[1] &&
+                (unsigned)oz < (unsigned)p.odim[2])
+                oidx[t] = p.otab[((int64_t)oz * p.odim[1] + oy) * p.odim[0] + ox];
+            ix[t] = ax * p.inp_step - p.imin[0];
+            iy[t] = ay * p.inp_step - p.imin[1];  // wave uniform per tile
+            iz[t] = az * p.inp_step - p.imin[2];
         }
         rowb[t] = (((int64_t)iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin + q * KST;
         if (__ballot(oidx[t] >= 0) == 0) oidx[t] = -2;  // nothing to compute in this tile (the whole wave agrees)
@@ -202,11 +207,11 @@ static int lat_validate(const dmcf_lattice_conv_args* a) {
     if (!a) return DMCF_EINVAL;
     for (int k = 0; k < 5; ++k)
         if (a->filter_dims[k] <= 0) return DMCF_EINVAL;
-    if (a->n_out < 0 || a->n_offsets < 0 || a->out_step <= 0 || !(a->extent > 0.0f)) return DMCF_EINVAL;
+    if (a->n_out < 0 || a->n_offsets < 0 || a->inp_step <= 0 || a->out_stride <= 0 || !(a->extent > 0.0f)) return DMCF_EINVAL;
     if (a->n_out > 0 && (!a->filters || !a->out_table || !a->out || !a->inp_volume || (a->n_offsets > 0 && !a->offsets)))
         return DMCF_EINVAL;
     for (int k = 0; k < 3; ++k)
-        if (a->inp_dims[k] <= 0 || a->out_dims[k] <= 0 || !(a->voxel[k] >= 0.0f)) return DMCF_EINVAL;
+        if (a->inp_dims[k] <= 0 || a->out_dims[k] <= 0 || a->base_dims[k] <= 0 || !(a->voxel[k] >= 0.0f)) return DMCF_EINVAL;
     if (a->flags & (DMCF_FLAG_SYMMETRIC | DMCF_FLAG_NORMALIZE)) return DMCF_EUNSUPPORTED;
     if (a->window == DMCF_WINDOW_EXPLICIT) return DMCF_EUNSUPPORTED;
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
@@ -251,7 +256,8 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
         const int64_t total = (int64_t)lat_packed_floats(a);
         const unsigned g = (unsigned)((total + 255) / 256);
         hipLaunchKernelGGL(lat_build_filters, dim3(g < 4096u ? g : 4096u), dim3(256), 0, stream, a->filters, packed, a->offsets,
-                           (int)a->n_offsets, KS, NT, cp, a->voxel[0], a->voxel[1], a->voxel[2]);
+                           (int)a->n_offsets, KS, NT, cp, a->voxel[0], a->voxel[1], a->voxel[2], a->rel_shift[0], a->rel_shift[1],
+                           a->rel_shift[2]);
     }
     LatParams p;
     p.Wp = packed;
@@ -263,9 +269,15 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
         p.imin[k] = a->inp_min[k]; p.idim[k] = a->inp_dims[k];
         p.omin[k] = a->out_min[k]; p.odim[k] = a->out_dims[k];
     }
-    p.out_step = a->out_step;
-    p.tiles_x = (a->out_dims[0] + 15) / 16;
-    p.ntiles = (int64_t)p.tiles_x * a->out_dims[1] * a->out_dims[2];
+    p.inp_step = a->inp_step;
+    p.out_stride = a->out_stride;
+    for (int k = 0; k < 3; ++k) {
+        p.phase[k] = a->out_phase[k];
+        p.amin[k] = a->base_min[k];
+        p.adim[k] = a->base_dims[k];
+    }
+    p.tiles_x = (a->base_dims[0] + 15) / 16;
+    p.ntiles = (int64_t)p.tiles_x * a->base_dims[1] * a->base_dims[2];
     p.bias = a->bias; p.out = a->out; p.flags = a->flags;
     const int64_t groups = (p.ntiles + 4 * kLatTW - 1) / (4 * kLatTW);
     if (groups > 0x7fffffff) return DMCF_EUNSUPPORTED;

@@ -81,18 +81,49 @@ def enabled():
 
 
 class LatticePair:
-    def __init__(self, inp, out, step):
-        self.inp, self.out, self.step = inp, out, step
+    """``inp`` -> ``out`` with ``ratio`` = output spacing / input spacing: 1, 2, ... (outputs on the same or a coarser
+    lattice) or 0.5 (outputs on the 2x finer lattice)."""
+
+    def __init__(self, inp, out, ratio):
+        self.inp, self.out, self.ratio = inp, out, ratio
+
+    def conv(self, ops, kernel, inp_features, n_out, extent, **kw):
+        """The launches of dmcf_lattice_conv_forward for this pair (one; eight -- one per parity class of the output
+        cells -- when the outputs are on the finer lattice)."""
+        a, b = self.inp, self.out
+        vol = a.volume(inp_features)
+        if self.ratio >= 1:
+            return ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio), **kw)
+        out = None
+        lo = [b.minp[k] for k in range(3)]
+        hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
+        for pz in (0, 1):
+            for py in (0, 1):
+                for px in (0, 1):
+                    ph = (px, py, pz)
+                    # base vectors a with lo <= 2 a + phase <= hi
+                    bmin = [-((ph[k] - lo[k]) // 2) for k in range(3)]
+                    bmax = [(hi[k] - ph[k]) // 2 for k in range(3)]
+                    bdim = [bmax[k] - bmin[k] + 1 for k in range(3)]
+                    if min(bdim) <= 0:
+                        continue
+                    shift = [ph[k] * b.voxel[k] for k in range(3)]
+                    out = ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1,
+                                           out_stride=2, out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim,
+                                           out=out, **kw)
+        return out
 
 
 def pair(inp_positions, out_positions):
-    """LatticePair if both tensors are registered lattices of one family and the output spacing is an integer multiple
-    (1, 2, ...) of the input spacing; None otherwise (then the neighbour-list form runs)."""
+    """LatticePair if both tensors are registered lattices of one family and the spacings are in the ratio 1, 2, 3, ...
+    (outputs as fine or coarser) or 1/2 (outputs twice as fine); None otherwise (then the neighbour-list form runs)."""
     if not enabled():
         return None
     a, b = lookup(inp_positions), lookup(out_positions)
     if a is None or b is None or a.family != b.family:
         return None
+    if all(a.voxel[k] == 2.0 * b.voxel[k] for k in range(3)):
+        return LatticePair(a, b, 0.5)
     step = round(b.voxel[0] / a.voxel[0])
     if step < 1 or any(b.voxel[k] != step * a.voxel[k] for k in range(3)):
         return None

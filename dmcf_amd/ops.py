@@ -467,17 +467,17 @@ def cconv_geometry(kernel_dims, out_positions, extent, inp_positions, neighbors_
 _STENCILS = {}
 
 
-def lattice_offsets(voxel, radius, device):
-    """int32 [S, 4] device tensor: the integer offsets d (x, y, z, 0) of input cells around an output cell with
-    |d * voxel| <= radius, decided like the search decides a pair (fp32, un-fused squared distance), ordered z, y, x."""
-    key = (tuple(float(v) for v in voxel), float(radius), str(device))
+def lattice_offsets(voxel, radius, device, shift=(0.0, 0.0, 0.0)):
+    """int32 [S, 4] device tensor: the integer offsets d (x, y, z, 0) of input cells with |d * voxel - shift| <= radius,
+    decided like the search decides a pair (fp32, un-fused squared distance), ordered z, y, x."""
+    key = (tuple(float(v) for v in voxel), float(radius), tuple(float(v) for v in shift), str(device))
     st = _STENCILS.get(key)
     if st is None:
-        v = np.asarray(voxel, np.float32)
-        reach = [int(np.floor(radius / float(x))) + 1 if x > 0 else 0 for x in v]
+        v, sh = np.asarray(voxel, np.float32), np.asarray(shift, np.float32)
+        reach = [int(np.floor((radius + abs(float(c))) / float(x))) + 1 if x > 0 else 0 for x, c in zip(v, sh)]
         ax = [np.arange(-r, r + 1, dtype=np.int32) for r in reach]
         dz, dy, dx = np.meshgrid(ax[2], ax[1], ax[0], indexing="ij")
-        x, y, z = dx.astype(np.float32) * v[0], dy.astype(np.float32) * v[1], dz.astype(np.float32) * v[2]
+        x, y, z = dx.astype(np.float32) * v[0] - sh[0], dy.astype(np.float32) * v[1] - sh[1], dz.astype(np.float32) * v[2] - sh[2]
         d2 = (x * x + y * y) + z * z
         keep = d2 <= np.float32(radius) * np.float32(radius)
         off = np.stack([dx[keep], dy[keep], dz[keep], np.zeros(int(keep.sum()), np.int32)], axis=1).astype(np.int32)
@@ -486,13 +486,16 @@ def lattice_offsets(voxel, radius, device):
     return st
 
 
-def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, out_step, n_out, voxel, extent, window="poly6",
+def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step=1, out_stride=1,
+                 out_phase=(0, 0, 0), rel_shift=(0.0, 0.0, 0.0), base_min=None, base_dims=None, window="poly6",
                  window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
                  interpolation="linear", bias=None, out=None, accumulate=False):
     """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
     ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
     ``inp_min`` (x, y, z); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
-    entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z)."""
+    entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z).  The launch covers the output cells
+    ``a * out_stride + out_phase`` for the base vectors a of the box (``base_min``, ``base_dims``; default: the whole output
+    table with stride 1); their stencil is ``a * inp_step + d`` (see include/dmcf_hip.h)."""
     L = _lib.lib()
     dev = filters.device
     cin, cout = filters.shape[3], filters.shape[4]
@@ -500,10 +503,12 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, out_step, n_o
         if accumulate:
             raise ValueError("accumulate=True needs an out tensor")
         out = torch.zeros((n_out, cout), dtype=torch.float32, device=dev)  # rows without a cell stay 0
-    offsets = lattice_offsets(voxel, 0.5 * float(extent), dev)
+    offsets = lattice_offsets(voxel, 0.5 * float(extent), dev, rel_shift)
     filters = filters.contiguous()
     if inp_volume.dim() != 4 or inp_volume.shape[3] != cin or not inp_volume.is_contiguous() or not out_table.is_contiguous():
         raise ValueError("inp_volume must be a contiguous [dz, dy, dx, Cin] tensor, out_table a contiguous [dz, dy, dx] one")
+    if base_min is None:
+        base_min, base_dims = out_min, [int(out_table.shape[2 - k]) for k in range(3)]
     a = _lib.LatticeConvArgs()
     a.filters = _ptr(filters)
     for k in range(5):
@@ -512,8 +517,9 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, out_step, n_o
     for k in range(3):
         a.inp_min[k], a.inp_dims[k] = int(inp_min[k]), int(inp_volume.shape[2 - k])
         a.out_min[k], a.out_dims[k] = int(out_min[k]), int(out_table.shape[2 - k])
-        a.voxel[k] = float(voxel[k])
-    a.n_out, a.out_step = int(n_out), int(out_step)
+        a.out_phase[k], a.base_min[k], a.base_dims[k] = int(out_phase[k]), int(base_min[k]), int(base_dims[k])
+        a.rel_shift[k], a.voxel[k] = float(rel_shift[k]), float(voxel[k])
+    a.n_out, a.inp_step, a.out_stride = int(n_out), int(inp_step), int(out_stride)
     a.offsets, a.n_offsets = _ptr(offsets), int(offsets.shape[0])
     a.extent, a.window_fac = float(extent), float(window_fac)
     a.window = WINDOWS[window]
@@ -526,7 +532,8 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, out_step, n_o
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_lattice_conv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
     if timer is not None:
-        timer.end("cconv", dict(pairs=int(n_out) * int(offsets.shape[0]), n_out=int(n_out), cin=int(cin), cout=int(cout),
+        cells = int(base_dims[0]) * int(base_dims[1]) * int(base_dims[2])
+        timer.end("cconv", dict(pairs=cells * int(offsets.shape[0]), n_out=int(n_out), cin=int(cin), cout=int(cout),
                                 K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
     return out
 

@@ -375,12 +375,10 @@ class ContinuousConv(torch.nn.Module):
                 # (dmcf_lattice_conv_forward; DMCF_LATTICE_CONV=0 keeps the neighbour-list form)
                 self.nns = None
                 fuse_bias = self.use_bias and not self.use_dense_layer_for_center
-                offsets = ops.lattice_offsets(lat.inp.voxel, 0.5 * extent, inp_features.device)
                 self._n_out_last = out_positions.shape[0]
-                self._pairs_last = out_positions.shape[0] * int(offsets.shape[0])  # upper bound: cells, not points
-                out_features = ops.lattice_conv(
-                    self.kernel, lat.inp.volume(inp_features), lat.inp.minp, lat.out.table(), lat.out.minp, lat.step,
-                    out_positions.shape[0], lat.inp.voxel, extent,
+                self._pairs_last = 0  # no pair list in this form
+                out_features = lat.conv(
+                    ops, self.kernel, inp_features, out_positions.shape[0], extent,
                     window=self.window_function.name, window_fac=self.window_function.fac,
                     align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
                     interpolation=self.interpolation, bias=self.bias if fuse_bias else None)

@@ -197,8 +197,8 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
  * coarse scales of the multi-scale models: models/hrnet.py:85-92 convolves between the outputs of grid_pos
  * (utils/tools/losses.py:136-181, via get_dilated_pos :266-272), which share one centre and whose voxel sizes are integer
  * multiples of each other.  Input point j sits at centre + inp_cell_j * voxel, output point i at
- * centre + out_cell_i * out_step * voxel; every per-pair quantity of the operator depends only on the integer offset
- * d = inp_cell_j - out_cell_i * out_step, so no neighbour list is needed: the caller passes the offsets inside the
+ * centre + out_cell_i * (output spacing); every per-pair quantity of the operator depends only on the integer offset
+ * of the input cell from the output point, so no neighbour list is needed: the caller passes the offsets inside the
  * radius, the input features laid out by lattice cell (a dense volume over the bounding box of the input lattice) and
  * a cell -> output point table of the output lattice.  Same filters / extent / window / mapping / interpolation /
  * ALIGN_CORNERS / bias / ACCUMULATE semantics as dmcf_cconv_forward; SYMMETRIC, NORMALIZE, DMCF_WINDOW_EXPLICIT and
@@ -215,9 +215,19 @@ typedef struct dmcf_lattice_conv_args {
     int32_t out_min[3];          /* (x,y,z) cell of entry 0 of out_table, in units of the output lattice */
     int32_t out_dims[3];
     int64_t n_out;               /* rows of `out` */
-    int32_t out_step;            /* output spacing / input spacing (1: same lattice, 2: outputs on the coarser lattice) */
+    /* The launch covers the output cells  o = a * out_stride + out_phase  for the integer vectors a of the box
+     * [base_min, base_min + base_dims); the stencil of such a cell is the input cells  a * inp_step + d.
+     *   same lattice:            inp_step = out_stride = 1, phase 0;
+     *   outputs 2x coarser:      inp_step = 2, out_stride = 1, phase 0;
+     *   outputs 2x finer:        inp_step = 1, out_stride = 2, one launch per phase in {0,1}^3, and the output sits
+     *                            rel_shift = phase * (output spacing) away from the input cell a * inp_step. */
+    int32_t inp_step;
+    int32_t out_stride;
+    int32_t out_phase[3];
+    int32_t base_min[3], base_dims[3];
+    float rel_shift[3];          /* x_in - x_out = d * voxel - rel_shift */
     float voxel[3];              /* (x,y,z) spacing of the input lattice */
-    const int32_t* offsets;      /* [n_offsets,4]: (dx,dy,dz,0) with |d * voxel| <= extent / 2 */
+    const int32_t* offsets;      /* [n_offsets,4]: (dx,dy,dz,0) with |d * voxel - rel_shift| <= extent / 2 */
     int64_t n_offsets;
     float extent;
     float window_fac;

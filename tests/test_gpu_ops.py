@@ -611,42 +611,49 @@ def _lattice(rng, dims, occupancy, voxel, center, step=1):
     return g, pos.astype(np.float32)
 
 
-@pytest.mark.parametrize("case", ["same", "fine_to_coarse", "coarse_same"])
+@pytest.mark.parametrize("case", ["same", "fine_to_coarse", "coarse_same", "coarse_to_fine"])
 def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
     """dmcf_lattice_conv_forward (stencil form for two aligned grid_pos lattices: no search, one [Cin x Cout] matrix per
-    integer offset) against the oracle and against the neighbour-list kernels on the same points."""
-    from dmcf_amd import ops
+    integer offset; eight launches -- one per parity class of the output cells -- when the outputs are on the finer
+    lattice) against the oracle and against the neighbour-list kernels on the same points, through the bookkeeping of
+    dmcf_amd/lattice.py the layer uses."""
+    from dmcf_amd import lattice, ops
     rng = np.random.default_rng(21)
     h = 0.05
     center = rng.uniform(-0.5, 0.5, size=3)
     if case == "same":            # s1 -> s1, R = 0.2
-        cin, cout, radius, step = 8, 16, 0.2, 1
+        cin, cout, radius = 8, 16, 0.2
         icell, ipos = _lattice(rng, (14, 12, 13), 0.85, h, center)
         ocell, opos = icell[: icell.shape[0] // 2 + 7], ipos[: icell.shape[0] // 2 + 7]
-        voxel = [h] * 3
+        ivox, ovox = h, h
     elif case == "fine_to_coarse":  # s1 -> s2, R = 0.4: outputs on every second cell
-        cin, cout, radius, step = 8, 8, 0.4, 2
+        cin, cout, radius = 8, 8, 0.4
         icell, ipos = _lattice(rng, (20, 18, 16), 0.8, h, center)
         ocell, opos = _lattice(rng, (10, 9, 8), 0.7, h, center, step=2)
-        voxel = [h] * 3
-    else:                          # s2 -> s2, R = 0.4, spacing 0.1
-        cin, cout, radius, step = 4, 8, 0.4, 1
+        ivox, ovox = h, 2 * h
+    elif case == "coarse_same":    # s2 -> s2, R = 0.4, spacing 0.1
+        cin, cout, radius = 4, 8, 0.4
         icell, ipos = _lattice(rng, (12, 11, 10), 0.9, 2 * h, center)
         ocell, opos = icell, ipos
-        voxel = [2 * h] * 3
+        ivox, ovox = 2 * h, 2 * h
+    else:                          # s2 -> s1, R = 0.4: outputs on the finer lattice
+        cin, cout, radius = 4, 16, 0.4
+        icell, ipos = _lattice(rng, (10, 9, 8), 0.8, h, center, step=2)
+        ocell, opos = _lattice(rng, (19, 17, 15), 0.75, h, center)
+        ivox, ovox = 2 * h, h
     feat = rng.normal(size=(ipos.shape[0], cin)).astype(np.float32)
     filt = rng.uniform(-1, 1, size=(4, 4, 4, cin, cout)).astype(np.float32)
     bias = rng.normal(size=cout).astype(np.float32)
-    imin = icell.min(axis=0) - 1  # boxes with a margin, as the candidate box of grid_pos has
-    idim = icell.max(axis=0) - imin + 2
-    vol = np.zeros((idim[2], idim[1], idim[0], cin), np.float32)
-    vol[icell[:, 2] - imin[2], icell[:, 1] - imin[1], icell[:, 0] - imin[0]] = feat
-    omin = ocell.min(axis=0)
-    odim = ocell.max(axis=0) - omin + 1
-    otab = np.full((odim[2], odim[1], odim[0]), -1, np.int32)
-    otab[ocell[:, 2] - omin[2], ocell[:, 1] - omin[1], ocell[:, 0] - omin[0]] = np.arange(ocell.shape[0], dtype=np.int32)
-    y = ops.lattice_conv(_t(filt, dev), _t(vol, dev), imin, _t(otab, dev), omin, step, ocell.shape[0], voxel, 2 * radius,
-                         window="poly6", bias=_t(bias, dev)).cpu().numpy()
+    cen = _t(center.astype(np.float32), dev)
+
+    def info(cells, pos, vox):
+        lo = cells.min(axis=0) - 1  # a box with a margin, as the candidate box of grid_pos has
+        return lattice.LatticeInfo(_t(pos, dev), cen, [vox] * 3, "test", lo, cells.max(axis=0) - lo + 2)
+    a, b = info(icell, ipos, ivox), info(ocell, opos, ovox)
+    assert np.array_equal(a.cells().cpu().numpy(), icell) and np.array_equal(b.cells().cpu().numpy(), ocell)
+    ratio = 0.5 if case == "coarse_to_fine" else round(ovox / ivox)
+    y = lattice.LatticePair(a, b, ratio).conv(ops, _t(filt, dev), _t(feat, dev), opos.shape[0], 2 * radius, window="poly6",
+                                              bias=_t(bias, dev)).cpu().numpy()
     nns = ops.fixed_radius_search(_t(ipos, dev), _t(opos, dev), radius, return_distances=True)
     idx, rs, d = (x.cpu().numpy() for x in nns)
     ref = oracle.continuous_conv(filt, opos, 2 * radius, ipos, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2),

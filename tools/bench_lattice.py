@@ -48,7 +48,7 @@ for name, inp, out, istep, ostep, R, cin, cout in [("s1->s1  8->16", s1, s1, 1, 
     t_tab = timed(prep)
     vol, tab = prep()
     voxel = [h * istep] * 3
-    f_lat = lambda: ops.lattice_conv(W, vol, ilo, tab, olo, ostep // istep, out.shape[0], voxel, 2 * R, window="poly6")
+    f_lat = lambda: ops.lattice_conv(W, vol, ilo, tab, olo, out.shape[0], voxel, 2 * R, inp_step=ostep // istep, window="poly6")
     y = f_lat()
     t_lat = timed(f_lat)
     t_search = timed(lambda: ops.fixed_radius_search(inp, out, R, return_distances=True))
