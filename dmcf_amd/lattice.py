@@ -92,8 +92,10 @@ class LatticePair:
         cells -- when the outputs are on the finer lattice)."""
         a, b = self.inp, self.out
         vol = a.volume(inp_features)
+        fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
         if self.ratio >= 1:
-            return ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio), **kw)
+            return ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio),
+                                    fill=fill, **kw)
         out = None
         lo = [b.minp[k] for k in range(3)]
         hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
@@ -110,7 +112,7 @@ class LatticePair:
                     shift = [ph[k] * b.voxel[k] for k in range(3)]
                     out = ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1,
                                            out_stride=2, out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim,
-                                           out=out, **kw)
+                                           out=out, fill=fill, n_out_launch=n_out // 8, **kw)
         return out
 
 

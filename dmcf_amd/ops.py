@@ -489,7 +489,7 @@ def lattice_offsets(voxel, radius, device, shift=(0.0, 0.0, 0.0)):
 def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step=1, out_stride=1,
                  out_phase=(0, 0, 0), rel_shift=(0.0, 0.0, 0.0), base_min=None, base_dims=None, window="poly6",
                  window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
-                 interpolation="linear", bias=None, out=None, accumulate=False):
+                 interpolation="linear", bias=None, out=None, accumulate=False, fill=1.0, n_out_launch=None):
     """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
     ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
     ``inp_min`` (x, y, z); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
@@ -532,8 +532,11 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_lattice_conv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
     if timer is not None:
-        cells = int(base_dims[0]) * int(base_dims[1]) * int(base_dims[2])
-        timer.end("cconv", dict(pairs=cells * int(offsets.shape[0]), n_out=int(n_out), cin=int(cin), cout=int(cout),
+        # bench accounting (SURVEY 8d is per neighbour pair): the pairs the neighbour-list form would have had, estimated as
+        # outputs x stencil offsets x the fraction of occupied cells in the input lattice's box (``fill``; a slight
+        # under-estimate: the interior is denser than the box average)
+        no = int(n_out if n_out_launch is None else n_out_launch)
+        timer.end("cconv", dict(pairs=int(no * int(offsets.shape[0]) * float(fill)), n_out=no, cin=int(cin), cout=int(cout),
                                 K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
     return out
 
