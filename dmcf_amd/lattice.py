@@ -8,12 +8,27 @@ and hands out the integer cells / the cell -> point table the kernel needs (buil
 """
 import collections
 import os
+import threading
 
 import numpy as np
 import torch
 
-_REGISTRY = collections.OrderedDict()  # (data_ptr, n) -> LatticeInfo; the newest few lattices only
+_TLS = threading.local()  # per thread: the virtual ranks of dmcf_amd.parallel are threads, each with its own lattices
 _KEEP = 16
+
+
+def _registry():
+    """(data_ptr, n) -> LatticeInfo; the newest few lattices of this thread only."""
+    r = getattr(_TLS, "registry", None)
+    if r is None:
+        r = _TLS.registry = collections.OrderedDict()
+    return r
+
+
+def clear():
+    """Forget this thread's lattices (the per-step neighbour cache calls it when a step ends: the positions of the next
+    step are new tensors)."""
+    _registry().clear()
 
 
 class LatticeInfo:
@@ -64,13 +79,33 @@ class LatticeInfo:
 def register(gpos, center, voxel, family, minp, dims):
     if gpos.shape[0] == 0 or any(not (float(v) > 1e-5) for v in voxel):
         return  # empty, or a collapsed axis (2-D scenes): the neighbour-list form handles those
-    _REGISTRY[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims)
-    while len(_REGISTRY) > _KEEP:
-        _REGISTRY.popitem(last=False)
+    reg = _registry()
+    reg[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims)
+    while len(reg) > _KEEP:
+        reg.popitem(last=False)
+
+
+def register_points(pos, center, voxel, family, box=None):
+    """Register ANY float32 [n, 3] tensor of points of the lattice ``center + cell * voxel`` (a filtered grid_pos result,
+    owned + ghost points of a sharded step).  ``box`` = (minp, dims) of a box of cells known to hold them all; without it
+    the bounding box of the cells is found on the device (one small host round trip)."""
+    if pos.shape[0] == 0 or any(not (float(v) > 1e-5) for v in voxel) or not pos.is_cuda:
+        return
+    if box is None:
+        v = torch.tensor([float(np.float32(x)) for x in voxel], dtype=torch.float32, device=pos.device)
+        cells = torch.round((pos - center) / v).to(torch.int32)
+        lo, hi = cells.amin(dim=0), cells.amax(dim=0)
+        b = torch.cat([lo, hi - lo + 1]).tolist()
+        box = (b[0:3], b[3:6])
+    info = LatticeInfo(pos, center, voxel, family, box[0], box[1])
+    reg = _registry()
+    reg[(pos.data_ptr(), pos.shape[0])] = info
+    while len(reg) > _KEEP:
+        reg.popitem(last=False)
 
 
 def lookup(t):
-    info = _REGISTRY.get((t.data_ptr(), t.shape[0]))
+    info = _registry().get((t.data_ptr(), t.shape[0]))
     if info is None or info.gpos._version != info.version or t.dim() != 2 or t.dtype != torch.float32 or not t.is_contiguous():
         return None
     return info

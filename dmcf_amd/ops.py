@@ -15,6 +15,8 @@ fallback: calling these with CPU tensors or without the built library raises.
 import collections
 import ctypes
 
+import threading
+
 import numpy as np
 import torch
 
@@ -634,6 +636,14 @@ class GridTooSparse(RuntimeError):
     the caller uses the sort-based device formulation instead."""
 
 
+_GRID_TLS = threading.local()
+
+
+def grid_pos_last_box():
+    """(minp, dims) of the integer box of cells of this thread's last :func:`grid_pos` call."""
+    return _GRID_TLS.last_box
+
+
 def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     """Lattice points of ``grid_pos`` (utils/tools/losses.py:136-181) via dmcf_grid_pos_bounds/_count/_write.
     ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean)."""
@@ -665,6 +675,8 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     if total:
         _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
                                          _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
+        _GRID_TLS.last_box = (minp, dims)  # integer box of cells holding every lattice point of this call (per thread:
+        # the virtual ranks of dmcf_amd.parallel are threads)
         if centralize and center is None:
             # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
             # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)

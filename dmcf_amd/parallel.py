@@ -33,11 +33,14 @@ in the CPU tests).
 """
 import threading
 
+import math
+
 import numpy as np
 import torch
 
 from .utils.convolutions import neighbor_cache
 from . import ops
+from . import lattice
 from .utils.tools.losses import grid_pos
 
 
@@ -236,6 +239,10 @@ class ShardedSimulator:
         if plan is None:
             plan = GhostPlan(self.comm, self.decomp, self._sets[name], width)
             self._plans[key] = plan
+            lat = self._lattices.get(name)
+            if lat is not None:
+                box = lat[2]  # the union of all ranks' boxes: owned + ghost points
+                lattice.register_points(plan.pos_ext, lat[0], lat[1], ("sharded", lat[0].data_ptr()), box)
         return plan
 
     def _conv(self, layer, feats_owned, inp, out, extent):
@@ -271,7 +278,7 @@ class ShardedSimulator:
     def _step(self, state):
         m, comm = self.model, self.comm
         dev = state["pos"].device
-        self._plans, self._sets = {}, {}
+        self._plans, self._sets, self._lattices = {}, {}, {}
         pos0, vel0, acc = state["pos"], state["vel"], state.get("acc")
         box_all, bfeats_all = state["box"], state["box_normals"]
         if "grav_eqvar" in m.transformation:
@@ -333,6 +340,20 @@ class ShardedSimulator:
             name = f"s{si}"
             self._sets[name] = g
             names.append(name)
+            if center is not None and g.is_cuda:
+                # all lattices of the step share the agreed centre: the layers between them (and their owned + ghost
+                # inputs, see _plan) can take the lattice form of ContinuousConv (dmcf_amd/lattice.py)
+                box = ops.grid_pos_last_box()  # of the candidates' lattice: holds the owned points
+                # the ghost copies a layer adds to this set come from other ranks' lattices: the union of all ranks' boxes
+                # (one tiny all-reduce, here where the queue is empty anyway) holds owned and ghost points alike.  Only the
+                # INPUT volumes are that large (zero-filled, 4 B x Cin per cell); the kernel walks the output box.
+                lo, dims = list(box[0]), list(box[1])
+                ext = torch.tensor([v for k in range(3) for v in (-lo[k], lo[k] + dims[k] - 1)], dtype=torch.int64, device=dev)
+                ext = comm.all_reduce(ext, "max").tolist()
+                for k in range(3):
+                    lo[k], dims[k] = -ext[2 * k], ext[2 * k + 1] + ext[2 * k] + 1
+                self._lattices[name] = (center, [float(v) for v in vs], (lo, dims))
+                lattice.register_points(g, center, vs, ("sharded", center.data_ptr()), (lo, dims))
 
         out = self._forward(names, feats, filter_extent, n_fluid)
 

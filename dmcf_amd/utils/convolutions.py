@@ -72,6 +72,8 @@ class _NeighborCache:
                 self.expect = dict(self.uses)
             self.uses = {}
             self.slot_of = {}
+            from .. import lattice
+            lattice.clear()
             self.lists.clear()
             self.tables.clear()
             self.geometries.clear()
