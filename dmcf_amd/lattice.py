@@ -32,8 +32,9 @@ def clear():
 
 
 class LatticeInfo:
-    def __init__(self, gpos, center, voxel, family, minp, dims):
+    def __init__(self, gpos, center, voxel, family, minp, dims, keep=None):
         self.gpos = gpos            # keeps the storage alive, so the registry key stays unique
+        self.keep = keep            # ... and whatever the family key points at (the source positions / the centre)
         self.version = gpos._version
         self.center = center        # float32 [3] on the device
         self.voxel = tuple(float(np.float32(v)) for v in voxel)
@@ -76,16 +77,16 @@ class LatticeInfo:
         return v.view(dz, dy, dx, features.shape[1])
 
 
-def register(gpos, center, voxel, family, minp, dims):
+def register(gpos, center, voxel, family, minp, dims, keep=None):
     if gpos.shape[0] == 0 or any(not (float(v) > 1e-5) for v in voxel):
         return  # empty, or a collapsed axis (2-D scenes): the neighbour-list form handles those
     reg = _registry()
-    reg[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims)
+    reg[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims, keep)
     while len(reg) > _KEEP:
         reg.popitem(last=False)
 
 
-def register_points(pos, center, voxel, family, box=None):
+def register_points(pos, center, voxel, family, box=None, keep=None):
     """Register ANY float32 [n, 3] tensor of points of the lattice ``center + cell * voxel`` (a filtered grid_pos result,
     owned + ghost points of a sharded step).  ``box`` = (minp, dims) of a box of cells known to hold them all; without it
     the bounding box of the cells is found on the device (one small host round trip)."""
@@ -97,7 +98,7 @@ def register_points(pos, center, voxel, family, box=None):
         lo, hi = cells.amin(dim=0), cells.amax(dim=0)
         b = torch.cat([lo, hi - lo + 1]).tolist()
         box = (b[0:3], b[3:6])
-    info = LatticeInfo(pos, center, voxel, family, box[0], box[1])
+    info = LatticeInfo(pos, center, voxel, family, box[0], box[1], keep if keep is not None else center)
     reg = _registry()
     reg[(pos.data_ptr(), pos.shape[0])] = info
     while len(reg) > _KEEP:

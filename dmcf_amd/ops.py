@@ -681,8 +681,9 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
             # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
             # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
             from . import lattice
+            # (the entry keeps ``pos`` alive: its address + version identify the family for as long as the entry exists)
             lattice.register(out, ws[40:52].view(torch.float32).clone(), [float(v) for v in vs],
-                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims)
+                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims, keep=pos)
     return out
 
 
