@@ -65,6 +65,7 @@ class LatticeConvArgs(ctypes.Structure):
         ("voxel", ctypes.c_float * 3),
         ("offsets", ctypes.c_void_p),
         ("n_offsets", ctypes.c_int64),
+        ("reach", ctypes.c_int32 * 3),
         ("extent", ctypes.c_float),
         ("window_fac", ctypes.c_float),
         ("window", ctypes.c_int32),

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     int oidx[kLatTW];       // output point of this lane's row (lanes of one row agree), -1: none, -2: tile without points
-    int64_t rowb[kLatTW];   // element offset of (z, y, x = this row) in the volume for offset (0, 0, 0)
+    int rowb[kLatTW];       // byte offset of (z, y, x = this row) in the volume for offset (0, 0, 0)
     int ix[kLatTW], iy[kLatTW], iz[kLatTW];
     f32x4 acc[kLatTW][NTT];
     bool any = false;
@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     for (int t = 0; t < kLatTW; ++t) {
         const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * kLatTW + t;
         oidx[t] = -1;
-        ix[t] = iy[t] = iz[t] = 0;
+        ix[t] = p.amin[0] * p.inp_step - p.imin[0];  // (tiles past the end read the first tile's cells and write nothing)
+        iy[t] = p.amin[1] * p.inp_step - p.imin[1];
+        iz[t] = p.amin[2] * p.inp_step - p.imin[2];
         if (tile < p.ntiles) {
             const int xb = (int)(tile % p.tiles_x);
             const int ax = p.amin[0] + xb * 16 + m, ay = p.amin[1] + (int)(tile / p.tiles_x % p.adim[1]),
@@ -112,7 +114,7 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
             iy[t] = ay * p.inp_step - p.imin[1];  // wave uniform per tile
             iz[t] = az * p.inp_step - p.imin[2];
         }
-        rowb[t] = (((int64_t)iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin + q * KST;
+        rowb[t] = (((iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin + q * KST) * 4;
         if (__ballot(oidx[t] >= 0) == 0) oidx[t] = -2;  // nothing to compute in this tile (the whole wave agrees)
         any |= oidx[t] != -2;
 #pragma unroll
@@ -122,59 +124,61 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     for (int s0 = 0; s0 < p.S; s0 += kLatCH) {
         const int ns = min(kLatCH, p.S - s0);
         __syncthreads();
-        for (int e = threadIdx.x; e < ns * KST * NTT * 64; e += 256) {
+        const int nsu = (ns + kLatU - 1) / kLatU * kLatU;  // the inner loop takes kLatU offsets at a time, unconditionally:
+        for (int e = threadIdx.x; e < nsu * KST * NTT * 64; e += 256) {  // ... the chunk is padded with zero matrices
             // chunk layout [offset][ks][n < NTT][64]; the packed array has NT (<= NTT) tiles per K step
             const int l = e & 63, n = (e >> 6) % NTT, ks = (e >> 6) / NTT % KST, so = (e >> 6) / (NTT * KST);
-            Ws[e] = n < p.NT ? p.Wp[(((int64_t)(s0 + so) * KST + ks) * p.NT + n) * 64 + l] : 0.0f;
+            Ws[e] = (so < ns && n < p.NT) ? p.Wp[(((int64_t)(s0 + so) * KST + ks) * p.NT + n) * 64 + l] : 0.0f;
         }
         const i32x4 dv = *(const i32x4*)(p.stencil + 4 * min(s0 + lane, p.S - 1));  // offset s0 + lane
-        const int64_t dof = (((int64_t)dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin;
-        const int dof_lo = (int)(uint32_t)dof, dof_hi = (int)(dof >> 32);
+        // element offset of the cell at that stencil offset; the volume is padded so that every row + offset is inside it
+        // (checked on the host): no bounds tests, 32-bit offsets from a scalar base
+        const int dof = ((dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin * 4;  // bytes
         __syncthreads();
         if (!any) continue;
-        for (int so = 0; so < ns; so += kLatU) {
-            float fv[kLatU][kLatTW][KST];
+        // software pipeline: the loads of the next kLatU offsets are issued before the products of the current ones
+        auto gather = [&](int so, float (&fv)[kLatU][kLatTW][KST]) {
 #pragma unroll
             for (int u = 0; u < kLatU; ++u) {
-                const int sl = min(so + u, kLatCH - 1);  // wave uniform
-                const int dx = __builtin_amdgcn_readlane(dv.x, sl), dy = __builtin_amdgcn_readlane(dv.y, sl),
-                          dz = __builtin_amdgcn_readlane(dv.z, sl);
-                const int64_t doff = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readlane(dof_hi, sl) << 32) |
-                                               (uint32_t)__builtin_amdgcn_readlane(dof_lo, sl));
+                const int doff = __builtin_amdgcn_readlane(dof, min(so + u, kLatCH - 1));  // wave uniform (a valid offset always)
 #pragma unroll
                 for (int t = 0; t < kLatTW; ++t) {
+                    const float* src = (const float*)((const char*)p.vol + (size_t)(uint32_t)(rowb[t] + doff));
+                    if constexpr (KST == 2) {
+                        const f32x2 v = *(const f32x2*)src;  // rows are 32 bytes (cin = 8), q * 8 bytes in
+                        fv[u][t][0] = v.x;
+                        fv[u][t][1] = v.y;
+                    } else {
 #pragma unroll
-                    for (int ks = 0; ks < KST; ++ks) fv[u][t][ks] = 0.0f;
-                    const bool rows_in = oidx[t] != -2 && so + u < ns && (unsigned)(iy[t] + dy) < (unsigned)p.idim[1] &&
-                                         (unsigned)(iz[t] + dz) < (unsigned)p.idim[2];  // wave uniform
-                    if (rows_in && (unsigned)(ix[t] + dx) < (unsigned)p.idim[0]) {
-                        const float* src = p.vol + rowb[t] + doff;
-                        if constexpr (KST == 2) {
-                            const f32x2 v = *(const f32x2*)src;  // rows are 32 bytes (cin = 8), q * 8 bytes in
-                            fv[u][t][0] = v.x;
-                            fv[u][t][1] = v.y;
-                        } else {
-#pragma unroll
-                            for (int ks = 0; ks < KST; ++ks) fv[u][t][ks] = src[ks];
-                        }
+                        for (int ks = 0; ks < KST; ++ks) fv[u][t][ks] = src[ks];
                     }
                 }
             }
+        };
+        auto products = [&](int so, const float (&fv)[kLatU][kLatTW][KST]) {
 #pragma unroll
             for (int u = 0; u < kLatU; ++u) {
-                if (so + u < ns) {
 #pragma unroll
-                    for (int ks = 0; ks < KST; ++ks)
+                for (int ks = 0; ks < KST; ++ks)
 #pragma unroll
-                        for (int n = 0; n < NTT; ++n) {
-                            const float w = Ws[(((so + u) * KST + ks) * NTT + n) * 64 + lane];
+                    for (int n = 0; n < NTT; ++n) {
+                        const float w = Ws[(((so + u) * KST + ks) * NTT + n) * 64 + lane];
 #pragma unroll
-                            for (int t = 0; t < kLatTW; ++t)
-                                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][t][ks], w, acc[t][n], 0, 0, 0);
-                        }
-                }
+                        for (int t = 0; t < kLatTW; ++t)
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][t][ks], w, acc[t][n], 0, 0, 0);
+                    }
             }
+        };
+        float fa[kLatU][kLatTW][KST], fb[kLatU][kLatTW][KST];
+        gather(0, fa);
+        int so = 0;
+        for (; so + 2 * kLatU <= nsu; so += 2 * kLatU) {
+            gather(so + kLatU, fb);
+            products(so, fa);
+            gather(so + 2 * kLatU, fa);  // past the chunk: a valid offset, the values are not used
+            products(so + kLatU, fb);
         }
+        if (so < nsu) products(so, fa);
     }
     // D layout: lane (rows 4 (lane >> 4) + r, column lane & 15); the row's output point sits in lane 4 q + r of oidx
 #pragma unroll
@@ -259,6 +263,13 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
                            (int)a->n_offsets, KS, NT, cp, a->voxel[0], a->voxel[1], a->voxel[2], a->rel_shift[0], a->rel_shift[1],
                            a->rel_shift[2]);
     }
+    for (int k = 0; k < 3; ++k) {  // every cell a * inp_step + d the launch can touch lies inside the volume
+        const int64_t ext = k == 0 ? (int64_t)((a->base_dims[0] + 15) / 16) * 16 : a->base_dims[k];
+        const int64_t lo = (int64_t)a->base_min[k] * a->inp_step - a->reach[k];
+        const int64_t hi = ((int64_t)a->base_min[k] + ext - 1) * a->inp_step + a->reach[k];
+        if (a->reach[k] < 0 || lo < a->inp_min[k] || hi > (int64_t)a->inp_min[k] + a->inp_dims[k] - 1) return DMCF_EINVAL;
+    }
+    if ((int64_t)a->inp_dims[0] * a->inp_dims[1] * a->inp_dims[2] * cin > 0x1fffffff) return DMCF_EUNSUPPORTED;  // 32-bit byte offsets
     LatParams p;
     p.Wp = packed;
     p.stencil = a->offsets;

@@ -43,6 +43,7 @@ class LatticeInfo:
         self.dims = [int(v) for v in dims]
         self._cells = None
         self._lin = None
+        self._vlin = {}
         self._table = None
 
     def cells(self):
@@ -52,13 +53,18 @@ class LatticeInfo:
             self._cells = torch.round((self.gpos - self.center) / v).to(torch.int32).contiguous()
         return self._cells
 
-    def lin(self):
-        """int64 [n]: the points' positions in a dense [dz, dy, dx] array over the box."""
-        if self._lin is None:
-            dx, dy, dz = self.dims
-            c = self.cells().long()
-            self._lin = ((c[:, 2] - self.minp[2]) * dy + (c[:, 1] - self.minp[1])) * dx + (c[:, 0] - self.minp[0])
-        return self._lin
+    def lin(self, minp=None, dims=None):
+        """int64 [n]: the points' positions in a dense [dz, dy, dx] array over the box (default: the lattice's own box)."""
+        own = minp is None
+        if own and self._lin is not None:
+            return self._lin
+        minp, dims = (self.minp, self.dims) if own else (minp, dims)
+        dx, dy, dz = dims
+        c = self.cells().long()
+        lin = ((c[:, 2] - minp[2]) * dy + (c[:, 1] - minp[1])) * dx + (c[:, 0] - minp[0])
+        if own:
+            self._lin = lin
+        return lin
 
     def table(self):
         """int32 [dz, dy, dx]: index of the point in each cell of the box, -1 where there is none."""
@@ -69,11 +75,16 @@ class LatticeInfo:
             self._table = t.view(dz, dy, dx)
         return self._table
 
-    def volume(self, features):
-        """float32 [dz, dy, dx, C]: ``features`` [n, C] by cell, zeros where there is no point."""
-        dx, dy, dz = self.dims
+    def volume(self, features, minp=None, dims=None):
+        """float32 [dz, dy, dx, C]: ``features`` [n, C] by cell over the box (default: the lattice's own), zeros where there
+        is no point.  The box must hold every point."""
+        key = None if minp is None else (tuple(minp), tuple(dims))
+        lin = self._vlin.get(key)
+        if lin is None:
+            lin = self._vlin[key] = self.lin(minp, dims)
+        dx, dy, dz = self.dims if minp is None else dims
         v = features.new_zeros((dz * dy * dx, features.shape[1]))
-        v[self.lin()] = features
+        v[lin] = features
         return v.view(dz, dy, dx, features.shape[1])
 
 
@@ -127,14 +138,17 @@ class LatticePair:
         """The launches of dmcf_lattice_conv_forward for this pair (one; eight -- one per parity class of the output
         cells -- when the outputs are on the finer lattice)."""
         a, b = self.inp, self.out
-        vol = a.volume(inp_features)
+        radius, dev = 0.5 * float(extent), inp_features.device
         fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
         if self.ratio >= 1:
-            return ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio),
-                                    fill=fill, **kw)
+            step = int(self.ratio)
+            vmin, vdim = ops.lattice_volume_box(b.minp, b.dims, step, ops.lattice_reach(a.voxel, radius, dev), a.minp, a.dims)
+            return ops.lattice_conv(kernel, a.volume(inp_features, vmin, vdim), vmin, b.table(), b.minp, n_out, a.voxel, extent,
+                                    inp_step=step, fill=fill, **kw)
         out = None
         lo = [b.minp[k] for k in range(3)]
         hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
+        launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
         for pz in (0, 1):
             for py in (0, 1):
                 for px in (0, 1):
@@ -146,9 +160,16 @@ class LatticePair:
                     if min(bdim) <= 0:
                         continue
                     shift = [ph[k] * b.voxel[k] for k in range(3)]
-                    out = ops.lattice_conv(kernel, vol, a.minp, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1,
-                                           out_stride=2, out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim,
-                                           out=out, fill=fill, n_out_launch=n_out // 8, **kw)
+                    m, d = ops.lattice_volume_box(bmin, bdim, 1, ops.lattice_reach(a.voxel, radius, dev, shift))
+                    vlo = [min(vlo[k], m[k]) for k in range(3)]
+                    vhi = [max(vhi[k], m[k] + d[k] - 1) for k in range(3)]
+                    launches.append((ph, bmin, bdim, shift))
+        vdim = [vhi[k] - vlo[k] + 1 for k in range(3)]
+        vol = a.volume(inp_features, vlo, vdim)  # one volume that serves all eight launches
+        for ph, bmin, bdim, shift in launches:
+            out = ops.lattice_conv(kernel, vol, vlo, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
+                                   out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim, out=out, fill=fill,
+                                   n_out_launch=n_out // 8, **kw)
         return out
 
 

@@ -483,9 +483,32 @@ def lattice_offsets(voxel, radius, device, shift=(0.0, 0.0, 0.0)):
         d2 = (x * x + y * y) + z * z
         keep = d2 <= np.float32(radius) * np.float32(radius)
         off = np.stack([dx[keep], dy[keep], dz[keep], np.zeros(int(keep.sum()), np.int32)], axis=1).astype(np.int32)
-        st = torch.from_numpy(np.ascontiguousarray(off)).to(device)
+        rch = [int(np.abs(off[:, k]).max()) if off.shape[0] else 0 for k in range(3)]
+        st = (torch.from_numpy(np.ascontiguousarray(off)).to(device), rch)
         _STENCILS[key] = st
-    return st
+    return st[0]
+
+
+def lattice_reach(voxel, radius, device, shift=(0.0, 0.0, 0.0)):
+    """max |d| per axis (x, y, z) over :func:`lattice_offsets`: how far around the cells it covers a launch reads the input
+    volume (the volume handed to :func:`lattice_conv` must be padded with zero cells that far)."""
+    lattice_offsets(voxel, radius, device, shift)
+    return list(_STENCILS[(tuple(float(v) for v in voxel), float(radius), tuple(float(v) for v in shift), str(device))][1])
+
+
+def lattice_volume_box(base_min, base_dims, inp_step, reach, points_min=None, points_dims=None):
+    """(min, dims) (x, y, z) of the box of input cells a launch of :func:`lattice_conv` over the base box can touch -- its x
+    extent rounded up to whole 16-cell tiles -- united with the box of the input points."""
+    lo, hi = [], []
+    for k in range(3):
+        ext = (int(base_dims[k]) + 15) // 16 * 16 if k == 0 else int(base_dims[k])
+        l = int(base_min[k]) * inp_step - int(reach[k])
+        h = (int(base_min[k]) + ext - 1) * inp_step + int(reach[k])
+        if points_min is not None:
+            l, h = min(l, int(points_min[k])), max(h, int(points_min[k]) + int(points_dims[k]) - 1)
+        lo.append(l)
+        hi.append(h)
+    return lo, [hi[k] - lo[k] + 1 for k in range(3)]
 
 
 def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step=1, out_stride=1,
@@ -494,7 +517,7 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
                  interpolation="linear", bias=None, out=None, accumulate=False, fill=1.0, n_out_launch=None):
     """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
     ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
-    ``inp_min`` (x, y, z); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
+    ``inp_min`` (x, y, z), padded so that it holds every cell ``a * inp_step + d`` of the launch (:func:`lattice_volume_box`); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
     entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z).  The launch covers the output cells
     ``a * out_stride + out_phase`` for the base vectors a of the box (``base_min``, ``base_dims``; default: the whole output
     table with stride 1); their stencil is ``a * inp_step + d`` (see include/dmcf_hip.h)."""
@@ -523,6 +546,8 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
         a.rel_shift[k], a.voxel[k] = float(rel_shift[k]), float(voxel[k])
     a.n_out, a.inp_step, a.out_stride = int(n_out), int(inp_step), int(out_stride)
     a.offsets, a.n_offsets = _ptr(offsets), int(offsets.shape[0])
+    for k, r in enumerate(lattice_reach(voxel, 0.5 * float(extent), dev, rel_shift)):
+        a.reach[k] = r
     a.extent, a.window_fac = float(extent), float(window_fac)
     a.window = WINDOWS[window]
     a.coordinate_mapping, a.interpolation = MAPPINGS[coordinate_mapping], INTERPOLATIONS[interpolation]

@@ -229,6 +229,10 @@ typedef struct dmcf_lattice_conv_args {
     float voxel[3];              /* (x,y,z) spacing of the input lattice */
     const int32_t* offsets;      /* [n_offsets,4]: (dx,dy,dz,0) with |d * voxel - rel_shift| <= extent / 2 */
     int64_t n_offsets;
+    int32_t reach[3];            /* max |d| per axis over `offsets`.  The volume must hold EVERY cell the launch can touch --
+                                  * a * inp_step + d for a in the base box (its x extent rounded up to a multiple of 16)
+                                  * and |d| <= reach -- so the kernel reads without bounds checks (DMCF_EINVAL otherwise):
+                                  * the caller pads the volume with zero cells */
     float extent;
     float window_fac;
     int32_t window;              /* enum dmcf_window (applied to |d * voxel|^2 / radius^2) */

@@ -38,6 +38,9 @@ for name, inp, out, istep, ostep, R, cin, cout in [("s1->s1  8->16", s1, s1, 1, 
     ic, oc = cells(inp, istep), cells(out, ostep)
     ilo, idim = box(ic)
     olo, odim = box(oc)
+    voxel = [h * istep] * 3
+    step = ostep // istep
+    ilo, idim = ops.lattice_volume_box(olo, odim, step, ops.lattice_reach(voxel, R, dev), ilo, idim)  # padded
     il, ol = lin_of(ic, ilo, idim), lin_of(oc, olo, odim)
     def prep():
         vol = feat.new_zeros((idim[2] * idim[1] * idim[0], cin))
