@@ -83,6 +83,7 @@ SYMBOLS = [
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
     "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
+    "dmcf_lattice_conv_batch_workspace_bytes", "dmcf_lattice_conv_forward_batch",
     "dmcf_reduce_subarrays_sum",
     "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
     "dmcf_grid_pos_workspace_bytes", "dmcf_grid_pos_bounds", "dmcf_grid_pos_count", "dmcf_grid_pos_write",
@@ -137,6 +138,10 @@ def lib():
     L.dmcf_lattice_conv_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs)]
     L.dmcf_lattice_conv_forward.restype = c.c_int
     L.dmcf_lattice_conv_forward.argtypes = [c.POINTER(LatticeConvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_lattice_conv_batch_workspace_bytes.restype = c.c_size_t
+    L.dmcf_lattice_conv_batch_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32]
+    L.dmcf_lattice_conv_forward_batch.restype = c.c_int
+    L.dmcf_lattice_conv_forward_batch.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_cconv_geometry_bytes.restype = c.c_size_t
     L.dmcf_cconv_geometry_bytes.argtypes = [c.c_int64]
     L.dmcf_cconv_geometry.restype = c.c_int

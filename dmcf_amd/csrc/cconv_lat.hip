@@ -85,7 +85,7 @@ constexpr int kLatU = 4;    // offsets whose loads are in flight together (x kLa
 // in the registers of lanes 0 .. kLatCH-1 (one 16-byte load per lane) and are broadcast with v_readlane: the first version
 // read them with scalar loads inside the loop, three dependent scalar-cache round trips per offset.
 template <int NTT, int KST>
-__global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
+__device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t group) {
     __shared__ float Ws[kLatCH * KST * NTT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     bool any = false;
 #pragma unroll
     for (int t = 0; t < kLatTW; ++t) {
-        const int64_t tile = ((int64_t)blockIdx.x * 4 + wave) * kLatTW + t;
+        const int64_t tile = (group * 4 + wave) * kLatTW + t;
         oidx[t] = -1;
         ix[t] = p.amin[0] * p.inp_step - p.imin[0];  // (tiles past the end read the first tile's cells and write nothing)
         iy[t] = p.amin[1] * p.inp_step - p.imin[1];
@@ -202,6 +202,27 @@ __global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
     }
 }
 
+template <int NTT, int KST>
+__global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
+    lat_conv_body<NTT, KST>(p, blockIdx.x);
+}
+
+// several launches that share volume, filter shape and output (the eight parity classes of a coarse -> fine layer) as one
+// grid: each is too small to fill the chip alone (1.5k workgroups walking ~270 offsets: 0.19 ms each, 8x their matrix time)
+constexpr int kLatMaxParts = 8;
+struct LatBatch {
+    LatParams part[kLatMaxParts];
+    int64_t first[kLatMaxParts + 1];  // first workgroup of each part
+    int n;
+};
+
+template <int NTT, int KST>
+__global__ __launch_bounds__(256) void lat_conv_batch_kernel(const LatBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int64_t)blockIdx.x >= b.first[i + 1]) ++i;
+    lat_conv_body<NTT, KST>(b.part[i], (int64_t)blockIdx.x - b.first[i]);
+}
+
 static size_t lat_packed_floats(const dmcf_lattice_conv_args* a) {
     const int KS = (a->filter_dims[3] + 3) / 4, NT = (a->filter_dims[4] + 15) / 16;
     return (size_t)a->n_offsets * KS * NT * 64;
@@ -225,24 +246,19 @@ static int lat_validate(const dmcf_lattice_conv_args* a) {
 
 }  // namespace dmcf
 
-using namespace dmcf;
+namespace dmcf {
 
-extern "C" {
-
-size_t dmcf_lattice_conv_workspace_bytes(const dmcf_lattice_conv_args* a) {
-    if (lat_validate(a) != DMCF_OK) return 256;
-    return 256 + align_up(lat_packed_floats(a) * sizeof(float), 256);
-}
-
-int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, size_t workspace_bytes, dmcf_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    int rc = lat_validate(a);
-    if (rc != DMCF_OK) return rc;
-    if (a->n_out == 0) return DMCF_OK;
-    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
-    if (workspace_bytes < dmcf_lattice_conv_workspace_bytes(a)) return DMCF_EWORKSPACE;
+// validates one launch, enqueues its filter build into `packed`, fills the kernel parameters
+static int lat_prepare(const dmcf_lattice_conv_args* a, float* packed, hipStream_t stream, LatParams& p, int64_t& groups) {
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
     const int KS = (cin + 3) / 4, NT = (cout + 15) / 16;
+    for (int k = 0; k < 3; ++k) {  // every cell a * inp_step + d the launch can touch lies inside the volume
+        const int64_t ext = k == 0 ? (int64_t)((a->base_dims[0] + 15) / 16) * 16 : a->base_dims[k];
+        const int64_t lo = (int64_t)a->base_min[k] * a->inp_step - a->reach[k];
+        const int64_t hi = ((int64_t)a->base_min[k] + ext - 1) * a->inp_step + a->reach[k];
+        if (a->reach[k] < 0 || lo < a->inp_min[k] || hi > (int64_t)a->inp_min[k] + a->inp_dims[k] - 1) return DMCF_EINVAL;
+    }
+    if ((int64_t)a->inp_dims[0] * a->inp_dims[1] * a->inp_dims[2] * cin > 0x1fffffff) return DMCF_EUNSUPPORTED;  // 32-bit byte offsets
     CconvParams cp = {};
     cp.sz = a->filter_dims[0]; cp.sy = a->filter_dims[1]; cp.sx = a->filter_dims[2];
     cp.K = cp.sx * cp.sy * cp.sz;
@@ -255,7 +271,6 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
     cp.mapping = a->coordinate_mapping;
     cp.interp = a->interpolation;
     cp.flags = a->flags;
-    float* packed = (float*)workspace;
     if (a->n_offsets > 0) {
         const int64_t total = (int64_t)lat_packed_floats(a);
         const unsigned g = (unsigned)((total + 255) / 256);
@@ -263,14 +278,6 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
                            (int)a->n_offsets, KS, NT, cp, a->voxel[0], a->voxel[1], a->voxel[2], a->rel_shift[0], a->rel_shift[1],
                            a->rel_shift[2]);
     }
-    for (int k = 0; k < 3; ++k) {  // every cell a * inp_step + d the launch can touch lies inside the volume
-        const int64_t ext = k == 0 ? (int64_t)((a->base_dims[0] + 15) / 16) * 16 : a->base_dims[k];
-        const int64_t lo = (int64_t)a->base_min[k] * a->inp_step - a->reach[k];
-        const int64_t hi = ((int64_t)a->base_min[k] + ext - 1) * a->inp_step + a->reach[k];
-        if (a->reach[k] < 0 || lo < a->inp_min[k] || hi > (int64_t)a->inp_min[k] + a->inp_dims[k] - 1) return DMCF_EINVAL;
-    }
-    if ((int64_t)a->inp_dims[0] * a->inp_dims[1] * a->inp_dims[2] * cin > 0x1fffffff) return DMCF_EUNSUPPORTED;  // 32-bit byte offsets
-    LatParams p;
     p.Wp = packed;
     p.stencil = a->offsets;
     p.S = (int)a->n_offsets; p.KS = KS; p.NT = NT; p.cin = cin; p.cout = cout;
@@ -279,24 +286,90 @@ int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, 
     for (int k = 0; k < 3; ++k) {
         p.imin[k] = a->inp_min[k]; p.idim[k] = a->inp_dims[k];
         p.omin[k] = a->out_min[k]; p.odim[k] = a->out_dims[k];
-    }
-    p.inp_step = a->inp_step;
-    p.out_stride = a->out_stride;
-    for (int k = 0; k < 3; ++k) {
         p.phase[k] = a->out_phase[k];
         p.amin[k] = a->base_min[k];
         p.adim[k] = a->base_dims[k];
     }
+    p.inp_step = a->inp_step;
+    p.out_stride = a->out_stride;
     p.tiles_x = (a->base_dims[0] + 15) / 16;
     p.ntiles = (int64_t)p.tiles_x * a->base_dims[1] * a->base_dims[2];
     p.bias = a->bias; p.out = a->out; p.flags = a->flags;
-    const int64_t groups = (p.ntiles + 4 * kLatTW - 1) / (4 * kLatTW);
+    groups = (p.ntiles + 4 * kLatTW - 1) / (4 * kLatTW);
+    return DMCF_OK;
+}
+
+}  // namespace dmcf
+
+using namespace dmcf;
+
+extern "C" {
+
+size_t dmcf_lattice_conv_workspace_bytes(const dmcf_lattice_conv_args* a) {
+    if (lat_validate(a) != DMCF_OK) return 256;
+    return 256 + align_up(lat_packed_floats(a) * sizeof(float), 256);
+}
+
+size_t dmcf_lattice_conv_batch_workspace_bytes(const dmcf_lattice_conv_args* parts, int32_t n_parts) {
+    size_t total = 256;
+    for (int i = 0; parts && i < n_parts; ++i)
+        if (lat_validate(parts + i) == DMCF_OK) total += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
+    return total;
+}
+
+int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, size_t workspace_bytes, dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc = lat_validate(a);
+    if (rc != DMCF_OK) return rc;
+    if (a->n_out == 0) return DMCF_OK;
+    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
+    if (workspace_bytes < dmcf_lattice_conv_workspace_bytes(a)) return DMCF_EWORKSPACE;
+    LatParams p;
+    int64_t groups;
+    rc = lat_prepare(a, (float*)workspace, stream, p, groups);
+    if (rc != DMCF_OK) return rc;
     if (groups > 0x7fffffff) return DMCF_EUNSUPPORTED;
     const dim3 grid((unsigned)groups), block(256);
-    if (KS == 1 && NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 1>), grid, block, 0, stream, p);
-    else if (KS == 1) hipLaunchKernelGGL((lat_conv_kernel<2, 1>), grid, block, 0, stream, p);
-    else if (NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 2>), grid, block, 0, stream, p);
+    if (p.KS == 1 && p.NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 1>), grid, block, 0, stream, p);
+    else if (p.KS == 1) hipLaunchKernelGGL((lat_conv_kernel<2, 1>), grid, block, 0, stream, p);
+    else if (p.NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 2>), grid, block, 0, stream, p);
     else hipLaunchKernelGGL((lat_conv_kernel<2, 2>), grid, block, 0, stream, p);
+    return check_launch();
+}
+
+int dmcf_lattice_conv_forward_batch(const dmcf_lattice_conv_args* parts, int32_t n_parts, void* workspace, size_t workspace_bytes,
+                                    dmcf_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!parts || n_parts < 1 || n_parts > kLatMaxParts) return DMCF_EINVAL;
+    for (int i = 0; i < n_parts; ++i) {
+        const int rc = lat_validate(parts + i);
+        if (rc != DMCF_OK) return rc;
+        if (parts[i].filter_dims[3] != parts[0].filter_dims[3] || parts[i].filter_dims[4] != parts[0].filter_dims[4])
+            return DMCF_EINVAL;  // one kernel instantiation for the whole grid
+    }
+    if (parts[0].n_out == 0) return DMCF_OK;
+    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
+    if (workspace_bytes < dmcf_lattice_conv_batch_workspace_bytes(parts, n_parts)) return DMCF_EWORKSPACE;
+    LatBatch b;
+    b.n = n_parts;
+    char* ws = (char*)workspace;
+    int64_t first = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        int64_t groups;
+        const int rc = lat_prepare(parts + i, (float*)ws, stream, b.part[i], groups);
+        if (rc != DMCF_OK) return rc;
+        ws += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
+        b.first[i] = first;
+        first += groups;
+    }
+    for (int i = n_parts; i <= kLatMaxParts; ++i) b.first[i] = first;
+    if (first > 0x7fffffff) return DMCF_EUNSUPPORTED;
+    const dim3 grid((unsigned)first), block(256);
+    const int KS = b.part[0].KS, NT = b.part[0].NT;
+    if (KS == 1 && NT == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<1, 1>), grid, block, 0, stream, b);
+    else if (KS == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<2, 1>), grid, block, 0, stream, b);
+    else if (NT == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<1, 2>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((lat_conv_batch_kernel<2, 2>), grid, block, 0, stream, b);
     return check_launch();
 }
 

@@ -135,8 +135,8 @@ class LatticePair:
         self.inp, self.out, self.ratio = inp, out, ratio
 
     def conv(self, ops, kernel, inp_features, n_out, extent, **kw):
-        """The launches of dmcf_lattice_conv_forward for this pair (one; eight -- one per parity class of the output
-        cells -- when the outputs are on the finer lattice)."""
+        """The launch of dmcf_lattice_conv_forward for this pair (outputs on the finer lattice: the eight parity classes
+        of the output cells, each with its own stencil, as one dmcf_lattice_conv_forward_batch grid)."""
         a, b = self.inp, self.out
         radius, dev = 0.5 * float(extent), inp_features.device
         fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
@@ -145,7 +145,6 @@ class LatticePair:
             vmin, vdim = ops.lattice_volume_box(b.minp, b.dims, step, ops.lattice_reach(a.voxel, radius, dev), a.minp, a.dims)
             return ops.lattice_conv(kernel, a.volume(inp_features, vmin, vdim), vmin, b.table(), b.minp, n_out, a.voxel, extent,
                                     inp_step=step, fill=fill, **kw)
-        out = None
         lo = [b.minp[k] for k in range(3)]
         hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
         launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
@@ -166,11 +165,9 @@ class LatticePair:
                     launches.append((ph, bmin, bdim, shift))
         vdim = [vhi[k] - vlo[k] + 1 for k in range(3)]
         vol = a.volume(inp_features, vlo, vdim)  # one volume that serves all eight launches
-        for ph, bmin, bdim, shift in launches:
-            out = ops.lattice_conv(kernel, vol, vlo, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
-                                   out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim, out=out, fill=fill,
-                                   n_out_launch=n_out // 8, **kw)
-        return out
+        parts = [dict(out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim) for ph, bmin, bdim, shift in launches]
+        return ops.lattice_conv(kernel, vol, vlo, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
+                                parts=parts, fill=fill, **kw)
 
 
 def pair(inp_positions, out_positions):

@@ -511,27 +511,12 @@ def lattice_volume_box(base_min, base_dims, inp_step, reach, points_min=None, po
     return lo, [hi[k] - lo[k] + 1 for k in range(3)]
 
 
-def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step=1, out_stride=1,
-                 out_phase=(0, 0, 0), rel_shift=(0.0, 0.0, 0.0), base_min=None, base_dims=None, window="poly6",
-                 window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
-                 interpolation="linear", bias=None, out=None, accumulate=False, fill=1.0, n_out_launch=None):
-    """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
-    ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
-    ``inp_min`` (x, y, z), padded so that it holds every cell ``a * inp_step + d`` of the launch (:func:`lattice_volume_box`); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
-    entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z).  The launch covers the output cells
-    ``a * out_stride + out_phase`` for the base vectors a of the box (``base_min``, ``base_dims``; default: the whole output
-    table with stride 1); their stencil is ``a * inp_step + d`` (see include/dmcf_hip.h)."""
-    L = _lib.lib()
+def _lattice_args(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step, out_stride, out_phase,
+                  rel_shift, base_min, base_dims, window, window_fac, align_corners, coordinate_mapping, interpolation, bias,
+                  out, accumulate):
+    """dmcf_lattice_conv_args for one launch; returns (args, tensors to keep alive, number of stencil offsets)."""
     dev = filters.device
-    cin, cout = filters.shape[3], filters.shape[4]
-    if out is None:
-        if accumulate:
-            raise ValueError("accumulate=True needs an out tensor")
-        out = torch.zeros((n_out, cout), dtype=torch.float32, device=dev)  # rows without a cell stay 0
     offsets = lattice_offsets(voxel, 0.5 * float(extent), dev, rel_shift)
-    filters = filters.contiguous()
-    if inp_volume.dim() != 4 or inp_volume.shape[3] != cin or not inp_volume.is_contiguous() or not out_table.is_contiguous():
-        raise ValueError("inp_volume must be a contiguous [dz, dy, dx, Cin] tensor, out_table a contiguous [dz, dy, dx] one")
     if base_min is None:
         base_min, base_dims = out_min, [int(out_table.shape[2 - k]) for k in range(3)]
     a = _lib.LatticeConvArgs()
@@ -554,16 +539,57 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
     a.flags = (FLAG_ALIGN_CORNERS if align_corners else 0) | (FLAG_ACCUMULATE if accumulate else 0)
     a.bias = _ptr(bias) if bias is not None else None
     a.out = _ptr(out)
-    nbytes = L.dmcf_lattice_conv_workspace_bytes(ctypes.byref(a))
+    return a, (offsets,), int(offsets.shape[0])
+
+
+def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step=1, out_stride=1,
+                 out_phase=(0, 0, 0), rel_shift=(0.0, 0.0, 0.0), base_min=None, base_dims=None, window="poly6",
+                 window_fac=1.0, align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving",
+                 interpolation="linear", bias=None, out=None, accumulate=False, fill=1.0, n_out_launch=None, parts=None):
+    """dmcf_lattice_conv_forward: continuous_conv between two aligned regular lattices without a neighbour list.
+    ``inp_volume`` float32 [dz, dy, dx, Cin]: the input features by cell (zeros where no point is), entry 0 = input cell
+    ``inp_min`` (x, y, z), padded so that it holds every cell ``a * inp_step + d`` of the launch (:func:`lattice_volume_box`); ``out_table`` int32 [dz, dy, dx]: output point index per cell of the output lattice (-1: none),
+    entry 0 = output cell ``out_min``; ``voxel`` the input lattice spacing (x, y, z).  The launch covers the output cells
+    ``a * out_stride + out_phase`` for the base vectors a of the box (``base_min``, ``base_dims``; default: the whole output
+    table with stride 1); their stencil is ``a * inp_step + d`` (see include/dmcf_hip.h).
+    ``parts``: a list of up to 8 dicts (out_phase, rel_shift, base_min, base_dims) that replace those four arguments and
+    run as ONE grid (dmcf_lattice_conv_forward_batch); every part writes rows of its own."""
+    L = _lib.lib()
+    dev = filters.device
+    cin, cout = filters.shape[3], filters.shape[4]
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an out tensor")
+        out = torch.zeros((n_out, cout), dtype=torch.float32, device=dev)  # rows without a cell stay 0
+    filters = filters.contiguous()
+    if inp_volume.dim() != 4 or inp_volume.shape[3] != cin or not inp_volume.is_contiguous() or not out_table.is_contiguous():
+        raise ValueError("inp_volume must be a contiguous [dz, dy, dx, Cin] tensor, out_table a contiguous [dz, dy, dx] one")
+    if parts is None:
+        parts = [dict(out_phase=out_phase, rel_shift=rel_shift, base_min=base_min, base_dims=base_dims)]
+    arr = (_lib.LatticeConvArgs * len(parts))()
+    keep, n_off = [], 0
+    for i, pt in enumerate(parts):
+        arr[i], k, no = _lattice_args(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel, extent, inp_step, out_stride,
+                                      pt["out_phase"], pt["rel_shift"], pt["base_min"], pt["base_dims"], window, window_fac,
+                                      align_corners, coordinate_mapping, interpolation, bias, out, accumulate)
+        keep.append(k)
+        n_off += no
+    if len(parts) == 1:
+        nbytes = L.dmcf_lattice_conv_workspace_bytes(arr)
+    else:
+        nbytes = L.dmcf_lattice_conv_batch_workspace_bytes(arr, len(parts))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     t0 = timer.begin() if timer is not None else None
-    _lib.check(L.dmcf_lattice_conv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
+    if len(parts) == 1:
+        _lib.check(L.dmcf_lattice_conv_forward(arr, _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward")
+    else:
+        _lib.check(L.dmcf_lattice_conv_forward_batch(arr, len(parts), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward_batch")
     if timer is not None:
         # bench accounting (SURVEY 8d is per neighbour pair): the pairs the neighbour-list form would have had, estimated as
         # outputs x stencil offsets x the fraction of occupied cells in the input lattice's box (``fill``; a slight
-        # under-estimate: the interior is denser than the box average)
+        # under-estimate: the interior is denser than the box average); the parts of a batch split the outputs evenly
         no = int(n_out if n_out_launch is None else n_out_launch)
-        timer.end("cconv", dict(pairs=int(no * int(offsets.shape[0]) * float(fill)), n_out=no, cin=int(cin), cout=int(cout),
+        timer.end("cconv", dict(pairs=int(no * (n_off / len(parts)) * float(fill)), n_out=no, cin=int(cin), cout=int(cout),
                                 K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
     return out
 

@@ -246,6 +246,11 @@ typedef struct dmcf_lattice_conv_args {
 size_t dmcf_lattice_conv_workspace_bytes(const dmcf_lattice_conv_args* args);
 int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* args, void* workspace, size_t workspace_bytes,
                               dmcf_stream_t stream);
+/* Up to 8 launches of the same layer (same filters, volume, output; e.g. the eight parity classes of outputs on the finer
+ * lattice) as ONE grid: each alone is too small to fill the chip. */
+size_t dmcf_lattice_conv_batch_workspace_bytes(const dmcf_lattice_conv_args* parts, int32_t n_parts);
+int dmcf_lattice_conv_forward_batch(const dmcf_lattice_conv_args* parts, int32_t n_parts, void* workspace,
+                                    size_t workspace_bytes, dmcf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * o3dml.ops.reduce_subarrays_sum(values, row_splits) (models/pbf_model.py:450-453):
