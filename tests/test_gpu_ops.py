@@ -196,11 +196,13 @@ def test_cconv_option_matrix(oracle, dev, mapping, interp, align, normalize):
         _close(y, ref, 2e-5)
 
 
-def test_cconv_bias_accumulate_and_empty_rows(oracle, dev):
+@pytest.mark.parametrize("cin", [8, 4])  # cls / LDS splat kernel; whole tiles (16 outputs) without a pair
+def test_cconv_bias_accumulate_and_empty_rows(oracle, dev, cin):
     from dmcf_amd import ops
     radius = 0.25
-    inp, out, feat, filt = _conv_inputs(oracle, 13, 500, 300, 8, 16, (4, 4, 4), radius)
-    out = np.concatenate([out, np.float32([[9, 9, 9], [-9, 0, 0]])])
+    inp, out, feat, filt = _conv_inputs(oracle, 13, 500, 300, cin, 16, (4, 4, 4), radius)
+    far = np.float32([[9, 9, 9]]) + np.arange(40, dtype=np.float32)[:, None]
+    out = np.concatenate([out[:100], far, out[100:], far, np.float32([[9, 9, 9], [-9, 0, 0]])])  # whole tiles without a pair
     bias = np.random.default_rng(1).normal(size=16).astype(np.float32)
     nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
     idx, rs, d = (x.cpu().numpy() for x in nns)
@@ -212,6 +214,7 @@ def test_cconv_bias_accumulate_and_empty_rows(oracle, dev):
     y = ops.cconv_forward(*args, bias=_t(bias, dev), **kw).cpu().numpy()
     _close(y, ref + bias)
     assert np.array_equal(y[-2:], np.stack([bias, bias]))  # rows without neighbours: exactly the bias
+    assert np.array_equal(y[100:140], np.tile(bias, (40, 1)))
     acc = torch.full((out.shape[0], 16), 2.0, device=dev)
     ops.cconv_forward(*args, out=acc, accumulate=True, **kw)
     _close(acc.cpu().numpy(), ref + 2.0)
