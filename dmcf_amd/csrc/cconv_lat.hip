@@ -11,8 +11,8 @@
 // input lattice's bounding box, zeros in empty cells), so the operand rows of a tile are contiguous memory:
 //   lat_build_filters   one thread per element of the per-offset matrices, packed in MFMA B-fragment order
 //   lat_conv_kernel     tile = 16 consecutive output cells along x (M of v_mfma_f32_16x16x4_f32), N = 16 output channels,
-//                       K = 4 input channels of one offset.  Per offset and tile ONE load instruction (rows 32 B apart for
-//                       8 channels: 512 contiguous bytes, re-read from L1 as the stencil slides along x); the per-offset
+//                       K = 4 stencil offsets of one input channel.  Per 4 offsets and tile one 16-byte load per lane and
+//                       4 input channels (the stencil slides along x: the rows are re-read from L1); the per-offset
 //                       matrices are staged through LDS in chunks and shared by the 4 waves x 2 tiles of a workgroup.  A
 //                       first version gathered rows through a cell -> point table in point order: 2.3 ms for the s1 -> s1
 //                       layer of the 1M-particle scene, bound by 9.5 GB of scattered 32-byte reads.
@@ -23,7 +23,7 @@
 namespace dmcf {
 
 struct LatParams {
-    const float* Wp;          // [S][KS][NT][64]
+    const float* Wp;          // [ceil(S / 4)][4 KS][NT][64]
     const int32_t* stencil;   // [S][4]: dx, dy, dz of the input cell relative to out_cell * out_step
     int S, KS, NT, cin, cout;
     const float* vol;          // [idim z][y][x][cin]
@@ -42,17 +42,18 @@ struct LatParams {
 __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict__ W, float* __restrict__ Wp,
                                                          const int32_t* __restrict__ stencil, int S, int KS, int NT, CconvParams p,
                                                          float vx, float vy, float vz, float sx, float sy, float sz) {
-    const int64_t total = (int64_t)S * KS * NT * 64;
+    // [group of 4 offsets][channel c < 4 KS][NT][lane = (q, n)]: the B operand of the product for channel c of the offsets
+    // 4 g .. 4 g + 3 (lane (q, n) holds W_{4g+q}[c][16 nt + n]); offsets past S are zero matrices
+    const int64_t total = (int64_t)((S + 3) / 4) * 4 * KS * NT * 64;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         int64_t t = e;
         const int n = (int)(t & 15); t >>= 4;
         const int q = (int)(t & 3); t >>= 2;
         const int nt = (int)(t % NT); t /= NT;
-        const int ks = (int)(t % KS); t /= KS;
-        const int s = (int)t;
-        const int c = q * KS + ks, o = nt * 16 + n;  // lane q of the A operand holds channels q * KS .. q * KS + KS - 1
+        const int c = (int)(t % (4 * KS)); t /= 4 * KS;
+        const int s = (int)t * 4 + q, o = nt * 16 + n;
         float v = 0.0f;
-        if (c < p.cin && o < p.cout) {
+        if (s < S && c < p.cin && o < p.cout) {
             float x = (float)stencil[4 * s] * vx - sx, y = (float)stencil[4 * s + 1] * vy - sy, z = (float)stencil[4 * s + 2] * vz - sz;
             const float d2 = (x * x + y * y) + z * z;
             const float a = window_value(p.window, d2, p.inv_r2, p.window_fac);
@@ -78,17 +79,21 @@ __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict
 
 constexpr int kLatTW = 2;   // 16-cell tiles per wave
 constexpr int kLatCH = 32;  // stencil offsets per LDS chunk of the per-offset matrices
-constexpr int kLatU = 4;    // offsets whose loads are in flight together (x kLatTW tiles)
+constexpr int kLatG = kLatCH / 4;
 
 // Workgroup = 4 waves x kLatTW tiles.  Every wave walks the whole stencil for its own tiles (no cross-wave reduction); the
-// per-offset matrices are staged through LDS in chunks of kLatCH offsets and shared by the waves.  The chunk's offsets sit
-// in the registers of lanes 0 .. kLatCH-1 (one 16-byte load per lane) and are broadcast with v_readlane: the first version
-// read them with scalar loads inside the loop, three dependent scalar-cache round trips per offset.
+// per-offset matrices are staged through LDS in chunks of kLatCH offsets and shared by the waves.
+// One v_mfma_f32_16x16x4_f32 multiplies the 16 cells of a tile with FOUR STENCIL OFFSETS of one input channel (k = offset):
+// lane (m, q) loads all channels of cell m at offset 4 g + q with one 16-byte load per 4 channels, and register c of that
+// load is the A operand of the product for channel c.  (The first version had k = 4 channels of one offset: one 4-byte
+// load per lane, tile and offset -- four times the load instructions for the same bytes, and the coarse -> fine layer ran at
+// 4x its matrix time, bound by the rate of the address unit.)
 template <int NTT, int KST>
 __device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t group) {
     __shared__ float Ws[kLatCH * KST * NTT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
+    constexpr int C = 4 * KST;
     int oidx[kLatTW];       // output point of this lane's row (lanes of one row agree), -1: none, -2: tile without points
     int rowb[kLatTW];       // byte offset of (z, y, x = this row) in the volume for offset (0, 0, 0)
     int ix[kLatTW], iy[kLatTW], iz[kLatTW];
@@ -114,71 +119,60 @@ __device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t 
             iy[t] = ay * p.inp_step - p.imin[1];  // wave uniform per tile
             iz[t] = az * p.inp_step - p.imin[2];
         }
-        rowb[t] = (((iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin + q * KST) * 4;
+        rowb[t] = ((iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin * 4;
         if (__ballot(oidx[t] >= 0) == 0) oidx[t] = -2;  // nothing to compute in this tile (the whole wave agrees)
         any |= oidx[t] != -2;
 #pragma unroll
         for (int n = 0; n < NTT; ++n) acc[t][n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int NG = (p.S + 3) / 4;
     for (int s0 = 0; s0 < p.S; s0 += kLatCH) {
-        const int ns = min(kLatCH, p.S - s0);
+        const int g0 = s0 / 4, ng = min(kLatG, NG - g0);
         __syncthreads();
-        const int nsu = (ns + kLatU - 1) / kLatU * kLatU;  // the inner loop takes kLatU offsets at a time, unconditionally:
-        for (int e = threadIdx.x; e < nsu * KST * NTT * 64; e += 256) {  // ... the chunk is padded with zero matrices
-            // chunk layout [offset][ks][n < NTT][64]; the packed array has NT (<= NTT) tiles per K step
-            const int l = e & 63, n = (e >> 6) % NTT, ks = (e >> 6) / NTT % KST, so = (e >> 6) / (NTT * KST);
-            Ws[e] = (so < ns && n < p.NT) ? p.Wp[(((int64_t)(s0 + so) * KST + ks) * p.NT + n) * 64 + l] : 0.0f;
+        for (int e = threadIdx.x; e < ng * C * NTT * 64; e += 256) {
+            // chunk layout [group][c][n < NTT][64]; the packed array has NT (<= NTT) tiles per channel
+            const int l = e & 63, n = (e >> 6) % NTT, gc = (e >> 6) / NTT;
+            Ws[e] = n < p.NT ? p.Wp[(((int64_t)g0 * C + gc) * p.NT + n) * 64 + l] : 0.0f;
         }
-        const i32x4 dv = *(const i32x4*)(p.stencil + 4 * min(s0 + lane, p.S - 1));  // offset s0 + lane
-        // element offset of the cell at that stencil offset; the volume is padded so that every row + offset is inside it
-        // (checked on the host): no bounds tests, 32-bit offsets from a scalar base
-        const int dof = ((dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin * 4;  // bytes
+        // byte offset of the cell at stencil offset s0 + l in lane l < kLatCH (past S: the last offset, whose matrix is zero);
+        // the volume is padded so that every row + offset is inside it (checked on the host): no bounds tests
+        const i32x4 dv = *(const i32x4*)(p.stencil + 4 * min(s0 + (lane & (kLatCH - 1)), p.S - 1));
+        const int dof = ((dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin * 4;
+        int dofg[kLatG];  // ... and of this lane's offset 4 g + q of each group
+#pragma unroll
+        for (int g = 0; g < kLatG; ++g) dofg[g] = __shfl(dof, 4 * g + q, 64);
         __syncthreads();
         if (!any) continue;
-        // software pipeline: the loads of the next kLatU offsets are issued before the products of the current ones
-        auto gather = [&](int so, float (&fv)[kLatU][kLatTW][KST]) {
+        f32x4 f[3][kLatTW][KST];
+        auto gather = [&](int g, f32x4 (&fv)[kLatTW][KST]) {
 #pragma unroll
-            for (int u = 0; u < kLatU; ++u) {
-                const int doff = __builtin_amdgcn_readlane(dof, min(so + u, kLatCH - 1));  // wave uniform (a valid offset always)
+            for (int t = 0; t < kLatTW; ++t) {
+                const f32x4* src = (const f32x4*)((const char*)p.vol + (size_t)(uint32_t)(rowb[t] + dofg[g]));
 #pragma unroll
-                for (int t = 0; t < kLatTW; ++t) {
-                    const float* src = (const float*)((const char*)p.vol + (size_t)(uint32_t)(rowb[t] + doff));
-                    if constexpr (KST == 2) {
-                        const f32x2 v = *(const f32x2*)src;  // rows are 32 bytes (cin = 8), q * 8 bytes in
-                        fv[u][t][0] = v.x;
-                        fv[u][t][1] = v.y;
-                    } else {
+                for (int ks = 0; ks < KST; ++ks) fv[t][ks] = src[ks];
+            }
+        };
+        auto products = [&](int g, const f32x4 (&fv)[kLatTW][KST]) {
 #pragma unroll
-                        for (int ks = 0; ks < KST; ++ks) fv[u][t][ks] = src[ks];
-                    }
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int n = 0; n < NTT; ++n) {
+                    const float w = Ws[((g * C + c) * NTT + n) * 64 + lane];
+#pragma unroll
+                    for (int t = 0; t < kLatTW; ++t)
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[t][c >> 2][c & 3], w, acc[t][n], 0, 0, 0);
                 }
-            }
         };
-        auto products = [&](int so, const float (&fv)[kLatU][kLatTW][KST]) {
+        // software pipeline, two groups of loads ahead of the products (groups past ng repeat a valid offset, unused)
+        gather(0, f[0]);
+        gather(1, f[1]);
 #pragma unroll
-            for (int u = 0; u < kLatU; ++u) {
-#pragma unroll
-                for (int ks = 0; ks < KST; ++ks)
-#pragma unroll
-                    for (int n = 0; n < NTT; ++n) {
-                        const float w = Ws[(((so + u) * KST + ks) * NTT + n) * 64 + lane];
-#pragma unroll
-                        for (int t = 0; t < kLatTW; ++t)
-                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[u][t][ks], w, acc[t][n], 0, 0, 0);
-                    }
-            }
-        };
-        float fa[kLatU][kLatTW][KST], fb[kLatU][kLatTW][KST];
-        gather(0, fa);
-        int so = 0;
-        for (; so + 2 * kLatU <= nsu; so += 2 * kLatU) {
-            gather(so + kLatU, fb);
-            products(so, fa);
-            gather(so + 2 * kLatU, fa);  // past the chunk: a valid offset, the values are not used
-            products(so + kLatU, fb);
+        for (int g = 0; g < kLatG; ++g) {
+            if (g >= ng) break;
+            if (g + 2 < kLatG) gather(g + 2, f[(g + 2) % 3]);
+            products(g, f[g % 3]);
         }
-        if (so < nsu) products(so, fa);
     }
     // D layout: lane (rows 4 (lane >> 4) + r, column lane & 15); the row's output point sits in lane 4 q + r of oidx
 #pragma unroll
@@ -225,7 +219,7 @@ __global__ __launch_bounds__(256) void lat_conv_batch_kernel(const LatBatch b) {
 
 static size_t lat_packed_floats(const dmcf_lattice_conv_args* a) {
     const int KS = (a->filter_dims[3] + 3) / 4, NT = (a->filter_dims[4] + 15) / 16;
-    return (size_t)a->n_offsets * KS * NT * 64;
+    return (size_t)((a->n_offsets + 3) / 4) * 4 * KS * NT * 64;
 }
 
 static int lat_validate(const dmcf_lattice_conv_args* a) {
