@@ -90,7 +90,7 @@ constexpr int kLatG = kLatCH / 4;
 // 4x its matrix time, bound by the rate of the address unit.)
 template <int NTT, int KST>
 __device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t group) {
-    __shared__ float Ws[kLatCH * KST * NTT * 64];
+    __shared__ __attribute__((aligned(16))) float Ws[2][kLatCH * KST * NTT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     constexpr int C = 4 * KST;
@@ -127,52 +127,75 @@ __device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t 
     }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int NG = (p.S + 3) / 4;
-    for (int s0 = 0; s0 < p.S; s0 += kLatCH) {
+    // The matrices of chunk k + 1 are fetched into registers before the products of chunk k and stored to the other LDS
+    // buffer after them: one barrier per chunk, and the L2 latency of the fetch hides behind the matrix instructions.
+    constexpr int kQuads = kLatCH * KST * NTT * 64 / 4 / 256;  // 16-byte pieces of a chunk per thread
+    f32x4 wr[kQuads];
+    i32x4 dv;
+    auto fetch = [&](int s0) {
         const int g0 = s0 / 4, ng = min(kLatG, NG - g0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < ng * C * NTT * 64; e += 256) {
+#pragma unroll
+        for (int i = 0; i < kQuads; ++i) {
             // chunk layout [group][c][n < NTT][64]; the packed array has NT (<= NTT) tiles per channel
+            const int e = (threadIdx.x + 256 * i) * 4;
             const int l = e & 63, n = (e >> 6) % NTT, gc = (e >> 6) / NTT;
-            Ws[e] = n < p.NT ? p.Wp[(((int64_t)g0 * C + gc) * p.NT + n) * 64 + l] : 0.0f;
+            wr[i] = (gc < ng * C && n < p.NT) ? *(const f32x4*)(p.Wp + (((int64_t)g0 * C + gc) * p.NT + n) * 64 + l)
+                                              : (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
-        // byte offset of the cell at stencil offset s0 + l in lane l < kLatCH (past S: the last offset, whose matrix is zero);
-        // the volume is padded so that every row + offset is inside it (checked on the host): no bounds tests
-        const i32x4 dv = *(const i32x4*)(p.stencil + 4 * min(s0 + (lane & (kLatCH - 1)), p.S - 1));
+        // stencil offset s0 + l in lane l < kLatCH (past S: the last offset, whose matrix is zero)
+        dv = *(const i32x4*)(p.stencil + 4 * min(s0 + (lane & (kLatCH - 1)), p.S - 1));
+    };
+    auto stash = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kQuads; ++i) *(f32x4*)(Ws[buf] + (threadIdx.x + 256 * i) * 4) = wr[i];
+    };
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int s0 = 0, k = 0; s0 < p.S; s0 += kLatCH, ++k) {
+        const int ng = min(kLatG, NG - s0 / 4);
+        const float* Wc = Ws[k & 1];
+        // byte offset of the cell at this lane's stencil offset; the volume is padded so that every row + offset is inside
+        // it (checked on the host): no bounds tests
         const int dof = ((dv.z * p.idim[1] + dv.y) * p.idim[0] + dv.x) * p.cin * 4;
         int dofg[kLatG];  // ... and of this lane's offset 4 g + q of each group
 #pragma unroll
         for (int g = 0; g < kLatG; ++g) dofg[g] = __shfl(dof, 4 * g + q, 64);
-        __syncthreads();
-        if (!any) continue;
-        f32x4 f[3][kLatTW][KST];
-        auto gather = [&](int g, f32x4 (&fv)[kLatTW][KST]) {
+        const bool more = s0 + kLatCH < p.S;
+        if (more) fetch(s0 + kLatCH);
+        if (any) {
+            f32x4 f[3][kLatTW][KST];
+            auto gather = [&](int g, f32x4 (&fv)[kLatTW][KST]) {
 #pragma unroll
-            for (int t = 0; t < kLatTW; ++t) {
-                const f32x4* src = (const f32x4*)((const char*)p.vol + (size_t)(uint32_t)(rowb[t] + dofg[g]));
+                for (int t = 0; t < kLatTW; ++t) {
+                    const f32x4* src = (const f32x4*)((const char*)p.vol + (size_t)(uint32_t)(rowb[t] + dofg[g]));
 #pragma unroll
-                for (int ks = 0; ks < KST; ++ks) fv[t][ks] = src[ks];
-            }
-        };
-        auto products = [&](int g, const f32x4 (&fv)[kLatTW][KST]) {
-#pragma unroll
-            for (int c = 0; c < C; ++c)
-#pragma unroll
-                for (int n = 0; n < NTT; ++n) {
-                    const float w = Ws[((g * C + c) * NTT + n) * 64 + lane];
-#pragma unroll
-                    for (int t = 0; t < kLatTW; ++t)
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[t][c >> 2][c & 3], w, acc[t][n], 0, 0, 0);
+                    for (int ks = 0; ks < KST; ++ks) fv[t][ks] = src[ks];
                 }
-        };
-        // software pipeline, two groups of loads ahead of the products (groups past ng repeat a valid offset, unused)
-        gather(0, f[0]);
-        gather(1, f[1]);
+            };
+            auto products = [&](int g, const f32x4 (&fv)[kLatTW][KST]) {
 #pragma unroll
-        for (int g = 0; g < kLatG; ++g) {
-            if (g >= ng) break;
-            if (g + 2 < kLatG) gather(g + 2, f[(g + 2) % 3]);
-            products(g, f[g % 3]);
+                for (int c = 0; c < C; ++c)
+#pragma unroll
+                    for (int n = 0; n < NTT; ++n) {
+                        const float w = Wc[((g * C + c) * NTT + n) * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < kLatTW; ++t)
+                            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(fv[t][c >> 2][c & 3], w, acc[t][n], 0, 0, 0);
+                    }
+            };
+            // software pipeline, two groups of loads ahead of the products (groups past ng repeat a valid offset, unused)
+            gather(0, f[0]);
+            gather(1, f[1]);
+#pragma unroll
+            for (int g = 0; g < kLatG; ++g) {
+                if (g >= ng) break;
+                if (g + 2 < kLatG) gather(g + 2, f[(g + 2) % 3]);
+                products(g, f[g % 3]);
+            }
         }
+        if (more) stash((k + 1) & 1);
+        __syncthreads();
     }
     // D layout: lane (rows 4 (lane >> 4) + r, column lane & 15); the row's output point sits in lane 4 q + r of oidx
 #pragma unroll
