@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                         x = gx - ox;
                         y = gy - oy;
                         z = gz - oz;
-                        a = window_value(p.window, gA.w, p.inv_r2, p.window_fac);
+                        a = window_value(p.window, p.nval ? gA.w : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
                         nsum += a;
                         if (p.inp_imp) a *= p.inp_imp[jA];
                         filter_coords<GENERIC>(x, y, z, p);
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void cconv_geometry_kernel(const CconvParams p
     for (int64_t pp = rb + lane; pp < re; pp += 64) {
         const int j = p.idx[pp];
         float x = p.inp_pos[3 * (int64_t)j] - ox, y = p.inp_pos[3 * (int64_t)j + 1] - oy, z = p.inp_pos[3 * (int64_t)j + 2] - oz;
-        const float a = window_value(p.window, p.nval ? p.nval[pp] : 0.0f, p.inv_r2, p.window_fac);
+        const float a = window_value(p.window, p.nval ? p.nval[pp] : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
         filter_coords<false>(x, y, z, p);
         int bx, by, bz;
         float w0, wx1, wy1, wz1;
@@ -524,7 +524,7 @@ static int validate(const dmcf_cconv_args* a, bool forward = true) {
     if (a->n_out > 0) {
         if (!a->out_positions || !a->neighbors_row_splits) return DMCF_EINVAL;
         if (forward && (!a->filters || !a->out || !a->inp_features)) return DMCF_EINVAL;
-        if (a->window != DMCF_WINDOW_NONE && !a->neighbors_value) return DMCF_EINVAL;
+        if (a->window == DMCF_WINDOW_EXPLICIT && !a->neighbors_value) return DMCF_EINVAL;
     }
     return DMCF_OK;
 }

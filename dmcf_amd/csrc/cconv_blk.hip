@@ -156,7 +156,7 @@ __global__ __launch_bounds__(kBThreads, BLK_OCC) void cconv_blk_kernel(const Cco
                         x -= ox;
                         y -= oy;
                         z -= oz;
-                        float a = window_value(p.window, nv, p.inv_r2, p.window_fac);
+                        float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
                         if (p.inp_imp) a *= p.inp_imp[j];
                         filter_coords<false>(x, y, z, p);
                         c.x = fminf(3.0f, fmaxf(0.0f, x));

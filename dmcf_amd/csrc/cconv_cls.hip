@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                 x -= pp ? oxs[1] : oxs[0];
                 y -= pp ? oys[1] : oys[0];
                 z -= pp ? ozs[1] : ozs[0];
-                float a = window_value(p.window, nv, p.inv_r2, p.window_fac);
+                float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
                 if (p.inp_imp) a *= p.inp_imp[j];
                 filter_coords<false>(x, y, z, p);
                 c.x = fminf(3.0f, fmaxf(0.0f, x));

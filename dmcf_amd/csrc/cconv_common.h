@@ -124,6 +124,13 @@ __device__ __forceinline__ void filter_coords(float& x, float& y, float& z, cons
     }
 }
 
+// Squared length of a pair's relative position x_in - x_out, bit for bit what the search returns for the pair (frs.hip:
+// dist2_unfused of the same two positions).  neighbors_value == NULL with a distance window: the kernels evaluate the window
+// on this, and the lists need no distance array (half the bytes the search writes and one load stream less here).
+__device__ __forceinline__ float rel_dist2(float x, float y, float z) {
+    return __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+}
+
 // window functions of utils/tools/losses.py:8-44 on q = d^2 / R^2
 __device__ __forceinline__ float window_value(int window, float v, float inv_r2, float fac) {
     if (window == DMCF_WINDOW_NONE) return 1.0f;

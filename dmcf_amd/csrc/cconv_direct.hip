@@ -155,7 +155,7 @@ __global__ __launch_bounds__(1024, 1) void cconv_direct_kernel(const DirectParam
                     x = gx - ox;
                     y = gy - oy;
                     z = gz - oz;
-                    a = window_value(p.window, nvA, p.inv_r2, p.window_fac);
+                    a = window_value(p.window, p.nval ? nvA : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
                     nsum += a;
                     if (p.inp_imp) a *= p.inp_imp[jA];
                     filter_coords<GENERIC>(x, y, z, p);

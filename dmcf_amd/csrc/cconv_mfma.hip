@@ -126,7 +126,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                         x -= ox;
                         y -= oy;
                         z -= oz;
-                        a = window_value(p.window, nv, p.inv_r2, p.window_fac);
+                        a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
                         nsum += a;
                         if (p.inp_imp) a *= p.inp_imp[j];
                         filter_coords<GENERIC>(x, y, z, p);

@@ -366,6 +366,13 @@ class FixedRadiusSearch:
 
     call = __call__
 
+    def index_only(self):
+        """The same search without the distance output (for callers that re-form d^2 from the positions)."""
+        twin = getattr(self, "_index_only", None)
+        if twin is None:
+            twin = self._index_only = FixedRadiusSearch(self.metric, self.ignore_query_point, False, self.max_hash_table_size)
+        return twin
+
 
 def _empty(t):
     return t is None or (isinstance(t, torch.Tensor) and t.numel() == 0)
@@ -393,13 +400,14 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     if window not in WINDOWS:
         raise NotImplementedError(f"window {window!r}")
     if window is not None:
-        if _empty(neighbors_value) and neighbors_index.numel() > 0:
-            raise ValueError("window given but no per-neighbour values")
-        if neighbors_value is None:
-            neighbors_value = torch.empty(0, dtype=torch.float32, device=filters.device)
-        neighbors_value = _dev_f32(neighbors_value, "neighbors_value")
-        if neighbors_value.shape[0] != neighbors_index.shape[0]:
-            raise ValueError("neighbors_value and neighbors_index disagree on the number of pairs")
+        if _empty(neighbors_value):
+            if window == "explicit" and neighbors_index.numel() > 0:
+                raise ValueError("explicit window but no per-neighbour values")
+            neighbors_value = None  # distance windows: the kernel re-forms d^2 from the positions (as the search does)
+        else:
+            neighbors_value = _dev_f32(neighbors_value, "neighbors_value")
+            if neighbors_value.shape[0] != neighbors_index.shape[0]:
+                raise ValueError("neighbors_value and neighbors_index disagree on the number of pairs")
     inp_importance = None if _empty(inp_importance) else _dev_f32(inp_importance, "inp_importance")
     if bias is not None:
         bias = _dev_f32(bias, "bias")
@@ -418,7 +426,7 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     a.inp_importance = None if inp_importance is None else inp_importance.data_ptr()
     a.neighbors_index = neighbors_index.data_ptr()
     a.neighbors_row_splits = neighbors_row_splits.data_ptr()
-    a.neighbors_value = None if window is None else neighbors_value.data_ptr()
+    a.neighbors_value = None if window is None or neighbors_value is None else neighbors_value.data_ptr()
     a.extent = float(extent)
     a.window_fac = float(window_fac)
     a.window = WINDOWS[window]

@@ -116,9 +116,14 @@ class _NeighborCache:
             self.lists.pop(key, None)
             self.done.append(res)
 
-    def search(self, frs, points, queries, radius):
+    def search(self, frs, points, queries, radius, distances=True):
+        """``distances=False``: the caller evaluates its window in the kernel, which re-forms d^2 from the positions
+        (dmcf_hip.h, neighbors_value == NULL) -- inside a step the list then carries no distance array: half the bytes the
+        search writes, half the memory of the list."""
         if self.depth == 0:
             return frs(points, queries, radius)
+        if not distances and frs.return_distances:
+            frs = frs.index_only()
         self._flush()
         points = points.contiguous()
         queries = queries.contiguous()
@@ -391,7 +396,8 @@ class ContinuousConv(torch.nn.Module):
                 self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
                                                     hash_table=fixed_radius_search_hash_table)
             else:
-                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
+                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius,
+                                         distances=not isinstance(self.window_function, WindowFunction))
             # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
             row_count = getattr(self.nns, "row_count", None)  # padded rows of the single-pass search
@@ -533,7 +539,8 @@ class PointSampling(torch.nn.Module):
                 self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
                                                     hash_table=fixed_radius_search_hash_table)
             else:
-                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius)
+                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius,
+                                         distances=not isinstance(self.window_function, WindowFunction))
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
             row_count = getattr(self.nns, "row_count", None)
             n_pairs_ref = self.nns.total_ref

@@ -135,7 +135,9 @@ enum dmcf_window {
     DMCF_WINDOW_NONE = 0,       /* a_p = 1; neighbors_value ignored (may be NULL) */
     DMCF_WINDOW_EXPLICIT = 1,   /* a_p = neighbors_value[p] (user supplied importance) */
     /* a_p = w(q), q = neighbors_value[p] / radius^2, neighbors_value = squared distances
-     * (utils/convolutions.py:359-362, 375-379; formulas utils/tools/losses.py:8-44) */
+     * (utils/convolutions.py:359-362, 375-379; formulas utils/tools/losses.py:8-44).
+     * neighbors_value == NULL: the squared distance is re-formed from the two positions, with the operations and the order
+     * dmcf_frs_search uses for the distances it returns -- bit-identical results, and the list needs no distance array. */
     DMCF_WINDOW_POLY6 = 2,
     DMCF_WINDOW_CUBIC = 3,
     DMCF_WINDOW_LINEAR = 4,
@@ -159,7 +161,7 @@ typedef struct dmcf_cconv_args {
     const float* inp_importance; /* [n_inp] or NULL (always NULL in DMCF: models/hrnet.py:91-92) */
     const int32_t* neighbors_index;       /* [P] */
     const int64_t* neighbors_row_splits;  /* [n_out+1] */
-    const float* neighbors_value;         /* [P] squared distances or importances, see dmcf_window */
+    const float* neighbors_value;         /* [P] squared distances (or NULL) or importances, see dmcf_window */
     float extent;              /* scalar filter extent (diameter); radius = extent/2 */
     float window_fac;          /* multiplier of the window function ("fac", losses.py:8), normally 1 */
     int32_t window;            /* enum dmcf_window */

@@ -302,6 +302,33 @@ def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, m
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "direct"])
+@pytest.mark.parametrize("window,sym", [("poly6", False), ("cubic", False), ("peak", True)])
+def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel, window, sym):
+    """neighbors_value = None with a distance window: the kernels re-form d^2 from the two positions exactly as the search
+    does, so a list without distances gives the same bits as one with them (include/dmcf_hip.h, dmcf_window)."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    pos = (torch.rand(3000, 3, generator=g) * 2.0 + 5.0).to(dev)  # |x| ~ 6: rounding of the differences matters
+    out = pos if sym else (torch.rand(1700, 3, generator=g) * 2.0 + 5.0).to(dev)
+    cin, cout = (8, 3) if kernel == "direct" or sym else (8, 16)
+    feat = torch.randn(3000, cin, generator=g).to(dev)
+    k = (torch.rand((4, 2, 4) if sym else (4, 4, 4), generator=g)[..., None, None] * torch.randn(cin, cout, generator=g)).to(dev)
+    radius = 0.25
+    nns = ops.fixed_radius_search(pos, out, radius, ignore_query_point=sym, return_distances=True)
+    bare = ops.fixed_radius_search(pos, out, radius, ignore_query_point=sym, return_distances=False)
+    assert bare.neighbors_distance.numel() == 0 and torch.equal(bare.neighbors_index, nns.neighbors_index)
+    kw = dict(window=window, symmetric=sym, sym_axis=1)
+    a = ops.cconv_forward(k, out, 2 * radius, pos, feat, nns.neighbors_index, nns.neighbors_row_splits,
+                          neighbors_value=nns.neighbors_distance, **kw)
+    b = ops.cconv_forward(k, out, 2 * radius, pos, feat, bare.neighbors_index, bare.neighbors_row_splits,
+                          neighbors_value=bare.neighbors_distance, **kw)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    with pytest.raises(ValueError):
+        ops.cconv_forward(k, out, 2 * radius, pos, feat, bare.neighbors_index, bare.neighbors_row_splits, window="explicit")
+
+
 @pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
