@@ -61,11 +61,14 @@ class HRNet(PBFNet):
         ext = None
         for layer in range(len(self.convs)):
             ans = []
+            # relu(x_{inp_scale}) is formed once per layer, not once per (scale, inp_scale) as the reference does (:85): the
+            # same values, two thirds fewer elementwise kernels
+            relu_in = [torch.relu(t) for t in ans_convs[-1]]
             for scale in range(len(self.convs[layer])):
                 importance = self.part_scale if scale == 0 else 1.0
                 inp = []
                 for inp_scale in range(len(ans_convs[-1])):
-                    feats = torch.relu(ans_convs[-1][inp_scale])  # :85
+                    feats = relu_in[inp_scale]  # :85
                     if self.dens_norm and dens is not None and inp_scale < len(dens):  # :87-89
                         feats = torch.cat([feats, feats / dens[inp_scale] ** 2], dim=-1)
                     ext = filter_extent[max(inp_scale, scale)]

@@ -34,6 +34,7 @@ in the CPU tests).
 import threading
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -197,7 +198,10 @@ class GhostPlan:
 
     def __init__(self, comm, decomp, pos_owned, width):
         self.comm = comm
+        self.decomp = decomp
         width = float(width) * (1.0 + 1e-5) + 1e-6  # superset slack; the search re-tests distances exactly
+        self.width = width
+        self._in_wide = {}
         empty = torch.zeros(0, dtype=torch.int64, device=pos_owned.device)
         self.send_idx = [empty if r == comm.rank else torch.nonzero(decomp.within(pos_owned, r, width)).reshape(-1)
                          for r in range(comm.world)]
@@ -213,6 +217,29 @@ class GhostPlan:
             return feats_owned
         recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx], recv_counts=self.recv_counts)
         return torch.cat([feats_owned] + recv, dim=0).contiguous()
+
+    def index_in(self, wide):
+        """Rows of ``wide``'s ghosts (a plan of the same point set with a larger width) that are this plan's ghosts, in this
+        plan's order: the senders picked their rows with ``decomp.within(pos, this rank, width)`` in ascending row order, and
+        the same test on the same received positions picks the same rows here -- no communication."""
+        idx = self._in_wide.get(id(wide))
+        if idx is None:
+            parts, off = [], 0
+            for cnt in wide.recv_counts:
+                g = wide.ghost_pos[off:off + cnt]
+                parts.append(torch.nonzero(self.decomp.within(g, self.comm.rank, self.width)).reshape(-1) + off)
+                off += cnt
+            idx = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=wide.ghost_pos.device)
+            if idx.shape[0] != self.ghost_pos.shape[0] or (os.environ.get("DMCF_SHARD_CHECK") == "1"
+                                                           and not torch.equal(wide.ghost_pos[idx], self.ghost_pos)):
+                raise RuntimeError("ghost plans of one point set are not nested")
+            self._in_wide[id(wide)] = idx
+            self._wide_keep = wide  # id() stays unique while the plan lives
+        return idx
+
+    def extend_from(self, wide, wide_ext):
+        """``extend`` without communication, from the same features already extended by the wider plan."""
+        return torch.cat([wide_ext[:self.n_owned], wide_ext[self.n_owned:][self.index_in(wide)]], dim=0)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -245,11 +272,20 @@ class ShardedSimulator:
                 lattice.register_points(plan.pos_ext, lat[0], lat[1], ("sharded", lat[0].data_ptr()), box)
         return plan
 
-    def _conv(self, layer, feats_owned, inp, out, extent):
-        """layer(feats, pos[inp] -> pos[out]) with inputs extended by the ghosts within extent/2."""
+    def _conv(self, layer, feats_owned, inp, out, extent, share=None):
+        """layer(feats, pos[inp] -> pos[out]) with inputs extended by the ghosts within extent/2.
+        ``share`` = dict(width=...) common to all the layers that read the SAME features: the ghost rows travel once, at the
+        largest width any of them needs, and the narrower sets are subsets of those rows (GhostPlan.index_in)."""
         plan = self._plan(inp, 0.5 * float(extent))
-        feats_ext = plan.extend(feats_owned)
-        self.exchanged_rows += feats_ext.shape[0] - feats_owned.shape[0]
+        if share is None or self.comm.world == 1:
+            feats_ext = plan.extend(feats_owned)
+            self.exchanged_rows += feats_ext.shape[0] - feats_owned.shape[0]
+        else:
+            wide = self._plan(inp, share["width"])
+            if "ext" not in share:
+                share["ext"] = wide.extend(feats_owned)
+                self.exchanged_rows += share["ext"].shape[0] - feats_owned.shape[0]
+            feats_ext = share["ext"] if plan is wide else plan.extend_from(wide, share["ext"])
         return layer(feats_ext, plan.pos_ext, self._sets[out], extent, None)
 
     def _global_sum(self, t64):
@@ -391,17 +427,23 @@ class ShardedSimulator:
             ans_convs = [[feats]]
             for layer in range(len(m.convs)):
                 ans = []
-                for scale in range(len(m.convs[layer])):
+                relu_in = [torch.relu(t) for t in ans_convs[-1]]  # once per layer (see models/hrnet.py)
+                # every output scale reads the same relu(x_{inp_scale}): one ghost exchange per input scale and layer, at
+                # the largest radius of the layer, instead of one per (scale, inp_scale)
+                n_scales = len(m.convs[layer])
+                shares = [dict(width=0.5 * float(max(filter_extent[max(i, s)] for s in range(n_scales))))
+                          for i in range(len(relu_in))]
+                for scale in range(n_scales):
                     if len(m.convs[layer][scale]) != 1:
                         raise NotImplementedError("k > 0 sub-layers (hrnet.py:120-131) are unused by shipped configs")
                     importance = m.part_scale if scale == 0 else 1.0
                     inp = []
                     for inp_scale in range(len(ans_convs[-1])):
-                        f = torch.relu(ans_convs[-1][inp_scale])
+                        f = relu_in[inp_scale]
                         ext = filter_extent[max(inp_scale, scale)]
                         conv_in = f if importance == 1.0 else f * importance
                         ans_conv = self._conv(m.convs[layer][scale][0][inp_scale], conv_in, names[inp_scale],
-                                              names[scale], ext)
+                                              names[scale], ext, share=shares[inp_scale] if conv_in is f else None)
                         if scale == inp_scale:
                             ans_conv = ans_conv + m.denses[layer][scale][0][inp_scale](f)
                             if ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:

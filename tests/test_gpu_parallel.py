@@ -43,8 +43,9 @@ def _assemble(parts, n):
 
 
 @pytest.mark.parametrize("world", [2, 4])
-def test_virtual_ranks_match_single_rank_on_gpu(world):
+def test_virtual_ranks_match_single_rank_on_gpu(world, monkeypatch):
     from dmcf_amd import parallel
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")  # narrow ghost sets must be the expected rows of the widest one
     from tools import scenes
     assert torch.cuda.is_available()
     dev = torch.device("cuda:0")

@@ -78,6 +78,7 @@ def test_virtual_ranks_equal_single_rank(monkeypatch):
     import shims
     from dmcf_amd import parallel
     shims.install(monkeypatch)
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")  # verify that the narrow ghost sets are the expected rows of the widest one
     scene = _scene()
     n = scene["pos"].shape[0]
     ref = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2))
