@@ -505,15 +505,20 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     return cin >= 8;
 }
 
+int cconv_cls_pack(const dmcf_cconv_args* a, float* packed, hipStream_t stream) {
+    const int cin = a->filter_dims[3], cout = a->filter_dims[4];
+    const int nchunks = (cin + CCH - 1) / CCH, NT = (cout + 15) / 16;
+    const int64_t total = (int64_t)cconv_cls_packed_floats(cin, cout);
+    const unsigned g = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_filter_cls, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, cin, cout, nchunks,
+                       NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
+    return nchunks;
+}
+
 int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {
-    const int nchunks = (p.cin + CCH - 1) / CCH, NT = (p.cout + 15) / 16;
+    const int NT = (p.cout + 15) / 16;
     float* packed = (float*)workspace;
-    {
-        const int64_t total = (int64_t)cconv_cls_packed_floats(p.cin, p.cout);
-        const unsigned g = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(pack_filter_cls, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, p.cin, p.cout,
-                           nchunks, NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
-    }
+    const int nchunks = cconv_cls_pack(a, packed, stream);
     p.Wp = packed;
     p.NT = NT;
     p.nchunks = nchunks;

@@ -235,6 +235,10 @@ int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
 bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_cls_packed_floats(int cin, int cout);
 int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+int cconv_cls_pack(const dmcf_cconv_args* a, float* packed, hipStream_t stream);  // enqueues the packing, returns the chunk count
+// cconv_z3.hip
+bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+int cconv_z3_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
 
 // cconv_direct.hip

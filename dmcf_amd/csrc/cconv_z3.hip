@@ -1,0 +1,420 @@
+// CConv for 4x4x4 filters and 17 .. 32 input channels in ONE pass over the neighbour list: PLANE-SORTED splat on
+// v_mfma_f32_32x32x2_f32, two neighbour pairs x 32 channels per instruction.
+//
+// cconv_cls.hip holds the 64-cell x 16-channel B_i of an output point in 36 VGPRs (9 class tiles) and walks the list once
+// per 16 channels; its time is mostly per-batch work that does not depend on the channel count (index / position loads,
+// geometry, ordering, staging), so a 24-channel layer costs two full walks (11.2 ms for the 3e8-pair 24 -> 8 layer against
+// 5.8 ms for 16 -> 16).  Here the pairs are ordered by their base PLANE bz only (3 classes); the pairs of a class touch the
+// 32 cells (z' in 0..1, y in 0..3, x in 0..3) of the planes (bz, bz + 1) and the splat is
+//
+//     D[m = (z', y, x)][n = channel] += sum_k A[m][k] F[k][n],    A[m][k] = w_k[z'] * hat(Y_k - y) * hat(X_k - x),
+//
+// k = 2 pairs of the class, n = 32 channels: three 32 x 32 tiles = 48 VGPRs hold B_i for all 32 channels.  16 clocks of
+// matrix core per pair and 16 channels -- twice the class-sorted form, which spends them on two walks instead.
+//
+// B_i of a point is 8 KB: a 16-point tile does not fit the LDS next to the staging.  So a wave owns ONE point (16 waves,
+// 1024 threads, one workgroup per CU, the same 16 waves per CU as the other kernels), keeps the merged B_i in registers and
+// hands it to the contraction in two halves of 16 channels through the 64 KB B tile the other kernels use.
+//
+// Per 61-pair batch (61 pairs + at most 3 padding slots = 64 slots = 32 instructions): geometry (lane = pair), order by
+// plane with 3 ballots, {X, Y, w0, w1} and the index to the pair's slot, feature rows of half a batch at a time by 16-byte
+// loads (lane = (slot, 4 channels)) into a 4 KB staging area, one ds_read per operand and instruction.
+#include <stdlib.h>
+
+#include "cconv_common.h"
+
+namespace dmcf {
+
+constexpr int kZWaves = 16;
+constexpr int kZThreads = 64 * kZWaves;
+constexpr int ZTM = kZWaves;      // output points per workgroup = rows of the B tile
+constexpr int kZRow = 1024;       // floats per B row: k' = (z * 4 + y) * 64 + channel * 4 + x (16 channels)
+constexpr int kZPairs = 61;       // pairs per batch
+constexpr int kZSlots = 64;       // + padding to even class sizes
+constexpr int kZRec = 12;         // floats per slot record: X, -, -, -, wy[z'][y] (8)
+constexpr int kZWaveF = kZSlots * kZRec + kZSlots;  // per wave outside the B tile: records + indices
+constexpr int kZMaxNT = 4;
+constexpr int kZNoPair = 3;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void zfence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float zhat(float d) { return __builtin_amdgcn_fmed3f(1.0f - fabsf(d), 0.0f, 1.0f); }
+
+template <int NTT>
+__global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cin = p.cin, cout = p.cout;
+    float* Bt = smem;                                    // [ZTM][kZRow], 4-float groups XOR-swizzled by the row
+    float* Fst = Bt + wave * kZRow;                      // [32 slots][32 channels]: this wave's B row, free until the merge
+    float* Rec = smem + ZTM * kZRow + wave * kZWaveF;    // [64 slots][kZRec]
+    int* Jst = (int*)(Rec + kZSlots * kZRec);            // [64 slots] neighbour index, -1: padding
+    const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
+    if (tile >= p.ntiles) return;
+    const int64_t pt0 = (int64_t)tile * ZTM;
+
+    // splat roles (A / B operands of 32x32x2): row m = lane & 31 = (z', y, x), pair k = lane >> 5, channel lane & 31
+    const int hk = lane >> 5, jn = lane & 31;
+    const float xm = (float)(lane & 3);
+    const int zc = (lane >> 4) & 1;
+    // feature load roles: lane -> (slot lane >> 3 of a group of 8, channels 4 (lane & 7) ..)
+    const int fr = lane >> 3, fc4 = lane & 7;
+    const bool fch_ok = 4 * fc4 < cin;
+    const float* zero4 = p.Wp + (size_t)p.nchunks * 64 * (4 * p.NT * 16 * 4);
+    const char* featB = (const char*)(p.inp_feat + (fch_ok ? 4 * fc4 : 0));
+    const uint32_t rowB = (uint32_t)cin * 4u;
+    // contraction roles
+    const int mi = lane & 15, mg = lane >> 4;
+
+    // this wave's point
+    const int64_t i = pt0 + wave;
+    int64_t rb = 0;
+    int nt = 0;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (i < p.n_out) {
+        rb = p.rs[i];
+        int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
+        if (re > p.pair_cap) re = rb;
+        nt = (int)min(re - rb, (int64_t)0x7fffff00);
+        ox = p.out_pos[3 * i];
+        oy = p.out_pos[3 * i + 1];
+        oz = p.out_pos[3 * i + 2];
+    }
+    // the point is the wave's: keep its row start, length and position in scalar registers (addresses then are a scalar base
+    // plus a 32-bit lane offset instead of 64-bit vector arithmetic)
+    rb = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rb >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rb);
+    nt = __builtin_amdgcn_readfirstlane(nt);
+    ox = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ox)));
+    oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oy)));
+    oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oz)));
+    const int NB = (nt + kZPairs - 1) / kZPairs;
+    const int32_t* idx_row = p.idx + rb;
+    const float* nval_row = p.nval ? p.nval + rb : nullptr;
+
+    f32x16 t0, t1, t2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t0[r] = t1[r] = t2[r] = 0.0f;
+
+    auto where = [&](int t, int& o) -> bool {
+        o = kZPairs * t + lane;
+        return t < NB && lane < kZPairs && o < nt;
+    };
+    auto ld_idx = [&](int t, int& j, float& nv) {
+        int o;
+        j = 0;
+        nv = 0.0f;
+        if (where(t, o)) {
+            j = idx_row[(uint32_t)o];
+            if (nval_row) nv = nval_row[(uint32_t)o];
+        }
+    };
+    auto ld_pos = [&](int t, int j, float& x, float& y, float& z) {
+        int o;
+        x = y = z = 0.0f;
+        if (where(t, o)) {
+            const float* q = (const float*)((const char*)p.inp_pos + (size_t)((uint32_t)j * 12u));  // n_inp * 12 < 2^32: launch check
+            x = q[0];
+            y = q[1];
+            z = q[2];
+        }
+    };
+    auto geom = [&](int t, int j, float nv, float x, float y, float z, int& cls) -> f32x4 {
+        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+        cls = kZNoPair;
+        int o;
+        if (where(t, o)) {
+            x -= ox;
+            y -= oy;
+            z -= oz;
+            float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+            if (p.inp_imp) a *= p.inp_imp[j];
+            filter_coords<false>(x, y, z, p);
+            c.x = fminf(3.0f, fmaxf(0.0f, x));
+            c.y = fminf(3.0f, fmaxf(0.0f, y));
+            z = fminf(3.0f, fmaxf(0.0f, z));
+            const float zf = fminf(floorf(z), 2.0f), fz = z - zf;
+            cls = (int)zf;
+            c.z = a * (1.0f - fz);
+            c.w = a * fz;
+        }
+        return c;
+    };
+    // Ordered batch: plane class c occupies slots [cb[c], cb[c + 1]), an even number; the lanes of a class keep their order.
+    struct Order {
+        int pos;
+        int cb[4];
+    };
+    auto order = [&](int cls) -> Order {
+        Order o;
+        o.pos = 0;
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const uint64_t m = __ballot(cls == c);
+            const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, base));
+            o.pos = cls == c ? rank : o.pos;
+            o.cb[c] = base;
+            base += (__builtin_popcountll(m) + 1) & ~1;
+        }
+        o.cb[3] = base;
+        return o;
+    };
+    auto push_index = [&](int j, int cls, int pos) {
+        Jst[lane] = -1;
+        zfence();
+        if (cls != kZNoPair) Jst[pos] = j;
+    };
+    // record of a slot: X and the eight products w[z'] * hat(Y - y) -- formed here once per pair (lane = pair), so that the
+    // splat's A operand is one subtract, one clamp and one multiply per instruction
+    auto push_rec = [&](const f32x4& c, int cls, int pos) {
+        float* r = Rec + kZRec * lane;
+        r[0] = 0.0f;
+        *(f32x4*)(r + 4) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0
+        *(f32x4*)(r + 8) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        zfence();
+        if (cls != kZNoPair) {
+            const f32x4 hy = {zhat(c.y), zhat(c.y - 1.0f), zhat(c.y - 2.0f), zhat(c.y - 3.0f)};
+            r = Rec + kZRec * pos;
+            r[0] = c.x;
+            *(f32x4*)(r + 4) = c.z * hy;
+            *(f32x4*)(r + 8) = c.w * hy;
+        }
+    };
+    // feature rows of half h of the ordered batch: four groups of 8 slots, lane = (slot, 4 channels); padding slots and
+    // channels past cin read a block of zeros behind the packed filter (unconditional loads)
+    auto f_issue = [&](int h, f32x4 (&f)[4]) {
+        int jj[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) jj[k] = Jst[32 * h + 8 * k + fr];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const char* src = featB + (uint64_t)(uint32_t)jj[k] * rowB;
+            f[k] = *(const f32x4*)((jj[k] >= 0 && fch_ok) ? src : (const char*)zero4);
+        }
+    };
+    auto f_publish = [&](const f32x4 (&f)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) *(f32x4*)(Fst + (8 * k + fr) * 32 + 4 * fc4) = f[k];
+    };
+    // groups [g0, g1) of half h, all of one plane class, into that class's tile
+    const float* prx = Rec + kZRec * hk;
+    const float* prw = Rec + kZRec * hk + 4 + 4 * zc + ((lane >> 2) & 3);
+    const float* prf = Fst + 32 * hk + jn;
+    auto run = [&](f32x16& tl, int g0, int g1, int h) {
+        const float* qx = prx + 2 * kZRec * g0;
+        const float* qw = prw + 2 * kZRec * g0;
+        const float* qf = prf - 32 * 32 * h + 64 * g0;
+        int n = g1 - g0;
+        // four groups at a time: twelve reads at immediate offsets, then three VALU operations per matrix instruction
+        for (; n >= 4; n -= 4) {
+            float x[4], w[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                x[u] = qx[2 * kZRec * u];
+                w[u] = qw[2 * kZRec * u];
+                b[u] = qf[64 * u];
+            }
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = w[u] * zhat(x[u] - xm);
+            // the four dependent matrix instructions back to back: an instruction of this wave between two of them costs
+            // ~40 clocks of the matrix pipe (MI355X_MICROARCH.md)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], tl, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            qx += 8 * kZRec;
+            qw += 8 * kZRec;
+            qf += 256;
+        }
+        for (; n > 0; --n) {
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(qw[0] * zhat(qx[0] - xm), qf[0], tl, 0, 0, 0);
+            qx += 2 * kZRec;
+            qw += 2 * kZRec;
+            qf += 64;
+        }
+    };
+    auto splat = [&](int h, const Order& o) {
+        const int lo = 16 * h, hi = min(16 * h + 16, o.cb[3] >> 1);
+        __builtin_amdgcn_s_setprio(3);  // the wave that reaches its splat first gets the matrix pipe: -3 .. 7 %
+        run(t0, max(lo, o.cb[0] >> 1), min(hi, o.cb[1] >> 1), h);
+        run(t1, max(lo, o.cb[1] >> 1), min(hi, o.cb[2] >> 1), h);
+        run(t2, max(lo, o.cb[2] >> 1), min(hi, o.cb[3] >> 1), h);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (NB > 0) {
+        int jA, jB, cl;
+        float nvA, nvB, px, py, pz;
+        ld_idx(0, jA, nvA);
+        ld_idx(1, jB, nvB);
+        ld_pos(0, jA, px, py, pz);
+        const f32x4 first = geom(0, jA, nvA, px, py, pz, cl);
+        Order oc = order(cl);
+        f32x4 ff[4];
+        push_index(jA, cl, oc.pos);
+        push_rec(first, cl, oc.pos);
+        zfence();
+        f_issue(0, ff);
+        jA = jB;
+        nvA = nvB;
+        ld_pos(1, jA, px, py, pz);
+        for (int t = 0; t < NB; ++t) {
+            // here: (jA, nvA, px, py, pz) = batch t + 1, ff = the features of half 0 of batch t
+            const bool two = oc.cb[3] > 32;
+            f_publish(ff);
+            ld_idx(t + 2, jB, nvB);
+            if (two) f_issue(1, ff);
+            zfence();
+            splat(0, oc);
+            // geometry + order of the next batch; its indices replace this batch's (all read by now)
+            const f32x4 nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
+            const Order on = order(cl);
+            zfence();
+            push_index(jA, cl, on.pos);
+            zfence();
+            if (two) f_publish(ff);
+            jA = jB;
+            nvA = nvB;
+            ld_pos(t + 2, jA, px, py, pz);
+            if (t + 1 < NB) f_issue(0, ff);
+            if (two) {
+                zfence();
+                splat(1, oc);
+            }
+            zfence();
+            push_rec(nxt, cl, on.pos);
+            oc = on;
+        }
+    }
+
+    // B_i of this lane's channel jn, rows y = 2 yb + hk: D layout of 32x32x2 is lane (rows 8 b + 4 (lane >> 5) + r, column
+    // lane & 31), register 4 b + r; with m = z' * 16 + y * 4 + x that is z' = b >> 1, y = 2 (b & 1) + hk, x = r.  Planes
+    // shared by two classes are added here, in registers: no read-modify-write in LDS.
+    f32x4 T[4][2];
+#pragma unroll
+    for (int yb = 0; yb < 2; ++yb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            T[0][yb][r] = t0[4 * yb + r];
+            T[1][yb][r] = t0[4 * (2 + yb) + r] + t1[4 * yb + r];
+            T[2][yb][r] = t1[4 * (2 + yb) + r] + t2[4 * yb + r];
+            T[3][yb][r] = t2[4 * (2 + yb) + r];
+        }
+
+    f32x4 acc[NTT];
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+    float* Brow = Bt + wave * kZRow;
+    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+        const int nch = min(16, cin - 16 * chunk);
+        if ((jn >> 4) == chunk) {
+            const int col = ((jn & 15) ^ (wave & 15)) << 2;
+#pragma unroll
+            for (int z = 0; z < 4; ++z)
+#pragma unroll
+                for (int yb = 0; yb < 2; ++yb) *(f32x4*)(Brow + (z * 4 + 2 * yb + hk) * 64 + col) = T[z][yb];
+        }
+        __syncthreads();
+        // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4; blocks of channels past the chunk's end are skipped
+        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
+        const int nq = (nch + 3) >> 2;
+        for (int t = wave; t < 16 * nq; t += kZWaves) {
+            const int blk = (t / nq) * 4 + t % nq;
+            const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+#pragma unroll
+            for (int n = 0; n < NTT; ++n) {
+                if (n < p.NT) {
+                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- cross-wave reduction + epilogue ----------------
+    float* red = Bt;  // [kZWaves][16][16*NT]
+    const int ncol = 16 * p.NT;
+#pragma unroll
+    for (int n = 0; n < NTT; ++n) {
+        if (n < p.NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * 16 + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < ZTM * cout; e += kZThreads) {
+        const int ptt = e / cout, o = e % cout;
+        const int64_t ii = pt0 + ptt;
+        if (ii >= p.n_out) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < kZWaves; ++w) v += red[((size_t)w * 16 + ptt) * ncol + o];
+        if (p.bias) v += p.bias[o];
+        float* dst = p.out + ii * cout + o;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        *dst = v;
+    }
+}
+
+static constexpr size_t kZ3Lds = (size_t)(ZTM * kZRow + kZWaves * kZWaveF) * sizeof(float);
+
+// Same filters and flags as cconv_cls.hip, without the antisymmetric form; 17 .. 32 input channels.
+bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
+    const char* e = getenv("DMCF_CCONV_KERNEL");  // "z3": force, anything else: never
+    if (e && e[0] != 'z') return false;
+    if (dx != 4 || dy != 4 || dz != 4) return false;
+    if (a->geometry || (a->flags & DMCF_FLAG_SYMMETRIC)) return false;
+    if (a->coordinate_mapping != DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING || a->interpolation != DMCF_INTERP_LINEAR ||
+        !(a->flags & DMCF_FLAG_ALIGN_CORNERS) || (a->flags & DMCF_FLAG_NORMALIZE))
+        return false;
+    const int cin = a->filter_dims[3], cout = a->filter_dims[4];
+    if ((cin & 3) || cin > 32 || cout > 16 * kZMaxNT) return false;
+    if ((uintptr_t)a->inp_features & 15) return false;
+    if (a->n_inp > 0x15000000) return false;  // 32-bit byte offsets into the positions
+    if (e) return true;
+    return cin > 16;
+}
+
+int cconv_z3_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {
+    const int NT = (p.cout + 15) / 16;
+    float* packed = (float*)workspace;
+    const int nchunks = cconv_cls_pack(a, packed, stream);  // the B-fragment order of cconv_cls.hip, 16 channels per chunk
+    p.Wp = packed;
+    p.NT = NT;
+    p.nchunks = nchunks;
+    const int64_t ntiles = (p.n_out + ZTM - 1) / ZTM;
+    if (ntiles > 0x7fffffff / 8) return DMCF_EUNSUPPORTED;
+    p.ntiles = (int)ntiles;
+    p.tiles_per_xcd = (int)((ntiles + 7) / 8);
+    const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    const void* fn = NT <= 1 ? (const void*)cconv_z3_kernel<1>
+                             : (NT <= 2 ? (const void*)cconv_z3_kernel<2> : (const void*)cconv_z3_kernel<4>);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZ3Lds);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    void* kargs[] = {(void*)&p};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(kZThreads), kargs, kZ3Lds, stream);
+    if (e != hipSuccess) {
+        g_last_hip_error = (int)e;
+        return DMCF_ELAUNCH;
+    }
+    return check_launch();
+}
+
+}  // namespace dmcf

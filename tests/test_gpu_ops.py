@@ -302,7 +302,7 @@ def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, m
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "direct"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "direct"])
 @pytest.mark.parametrize("window,sym", [("poly6", False), ("cubic", False), ("peak", True)])
 def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel, window, sym):
     """neighbors_value = None with a distance window: the kernels re-form d^2 from the two positions exactly as the search
@@ -329,7 +329,7 @@ def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel
         ops.cconv_forward(k, out, 2 * radius, pos, feat, bare.neighbors_index, bare.neighbors_row_splits, window="explicit")
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
 def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, cout, ks, dim):
@@ -349,7 +349,7 @@ def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, 
 
 @pytest.mark.parametrize("cin,cout,sym,radius", [(4, 8, False, 0.3), (8, 32, False, 0.45), (16, 16, False, 0.6), (24, 8, False, 0.3),
                                                  (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45)])
-@pytest.mark.parametrize("kernel", ["blk", "cls"])
+@pytest.mark.parametrize("kernel", ["blk", "cls", "z3"])
 def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, kernel, cin, cout, sym, radius):
     """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA) and cconv_cls.hip (class-sorted, four pairs per 16x16x4
     MFMA): rows from empty to several batches, every channel-chunk count, bias + accumulate, and the antisymmetric form."""
