@@ -326,8 +326,9 @@ class ShardedSimulator:
         # fluid bounding box over all ranks (pbf_model.py:330-334)
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in m.particle_radii]
         big = 3.0e38
-        lo = pos.min(dim=0).values if pos.shape[0] else torch.full((3,), big, device=dev)
-        hi = pos.max(dim=0).values if pos.shape[0] else torch.full((3,), -big, device=dev)
+        pt = pos.t().contiguous()  # [3, N]: row reductions (a strided column reduction of [N, 3] is ~0.5 ms each)
+        lo = pt.amin(dim=1) if pos.shape[0] else torch.full((3,), big, device=dev)
+        hi = pt.amax(dim=1) if pos.shape[0] else torch.full((3,), -big, device=dev)
         lo = comm.all_reduce(lo.clone(), "min") - filter_extent[-1]
         hi = comm.all_reduce(hi.clone(), "max") + filter_extent[-1]
         keep = ((box >= lo) & (box <= hi)).all(dim=1)
@@ -358,7 +359,7 @@ class ShardedSimulator:
         names = []
         center = None
         if m.centralize and any(s != 1 for s in m.strides):
-            acc64 = torch.cat([self._sets[base].double().sum(dim=0),
+            acc64 = torch.cat([self._sets[base].t().contiguous().double().sum(dim=1),
                                torch.tensor([float(self._sets[base].shape[0])], dtype=torch.float64, device=dev)])
             acc64 = self._global_sum(acc64)
             center = (acc64[:3] / acc64[3]).to(torch.float32)
