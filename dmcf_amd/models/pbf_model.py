@@ -13,10 +13,13 @@ through (run_pipeline.py:114).  Per step:
 Everything particle-sized goes through the HIP library (ContinuousConv -> dmcf_amd.ops); torch does the
 [N,3] elementwise plumbing and the Dense GEMMs.
 """
+import os
+
 import numpy as np
 import torch
 
 from .. import ops
+from ..utils import convolutions as _convs
 from ..utils.convolutions import ContinuousConv, PointSampling
 from ..utils.tools.losses import compute_density, compute_pressure, get_dilated_pos, get_window_func
 from .base_model import BaseModel, Dense
@@ -222,9 +225,13 @@ class PBFNet(BaseModel):
         self.inp_feats = fluid_feats
         self.inp_bfeats = box_feats
 
-        ans_conv = self.fluid_convs(fluid_feats * self.part_scale, pos, all_pos, filter_extent[0], None)  # :378
+        fused = self._fused_input_convs(fluid_feats, box_feats, pos, all_pos, filter_extent[0])
+        if fused is not None:
+            ans_conv, ans_obs = fused
+        else:
+            ans_conv = self.fluid_convs(fluid_feats * self.part_scale, pos, all_pos, filter_extent[0], None)  # :378
+            ans_obs = self.obs_convs(box_feats * self.part_scale, box, all_pos, filter_extent[0], None)  # :382
         ans_dense = self.fluid_dense(fluid_feats)
-        ans_obs = self.obs_convs(box_feats * self.part_scale, box, all_pos, filter_extent[0], None)  # :382
         ans_dense_obs = self.obs_dense(box_feats)
         ans_dense = torch.cat([ans_dense, ans_dense_obs], dim=0)
         if self.use_pre_adv:  # :388-399
@@ -251,12 +258,68 @@ class PBFNet(BaseModel):
         self.dilated_pos = dilated_pos
         return [dilated_pos, fluid_feats, idx, dens]
 
+    def _fused_input_convs(self, fluid_feats, box_feats, pos, all_pos, extent):
+        """The two input layers (pbf_model.py:378-383: fluid -> all, boundary -> all, same radius, same flags) as ONE
+        convolution inside a rollout step: inputs = all particles with the features [f | 0] / [0 | b], filter = the two
+        kernels stacked block-diagonally, outputs [conv_f | conv_b].  Every product with a zero block is an exact zero, so
+        each half is the sum the separate layer forms (in the order of the shared list).  It runs on the all -> all list
+        of the first HRNet layer: two searches, two grid builds and one walk over ~3e7 pairs less per step.
+        Returns None when the layers differ in anything but their weights (then they run one after the other)."""
+        a, b = self.fluid_convs, self.obs_convs
+        if (os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not pos.is_cuda
+                or fluid_feats.shape[0] == 0 or box_feats.shape[0] == 0):
+            return None
+        wa, wb = a.window_function, b.window_function
+        if a.kernel is None or b.kernel is None:
+            return None  # first call: the layers build their weights from the input widths
+        same = (isinstance(wa, _convs.WindowFunction) and isinstance(wb, _convs.WindowFunction) and wa.name == wb.name
+                and wa.fac == wb.fac and tuple(a.kernel.shape[:3]) == tuple(b.kernel.shape[:3]) and a.filters == b.filters
+                and all(getattr(a, k) == getattr(b, k) for k in (
+                    "align_corners", "coordinate_mapping", "interpolation", "normalize", "use_bias",
+                    "radius_search_ignore_query_points", "radius_search_metric", "use_dense_layer_for_center"))
+                and not (a.symmetric or b.symmetric or a.circular or b.circular or a.normalize
+                         or a.radius_search_ignore_query_points or a.use_dense_layer_for_center)
+                and a.activation is None and b.activation is None
+                and a.kernel.shape[3] == fluid_feats.shape[1] and b.kernel.shape[3] == box_feats.shape[1])
+        if not same:
+            return None
+        n, m, cf, cb, co = fluid_feats.shape[0], box_feats.shape[0], fluid_feats.shape[1], box_feats.shape[1], a.filters
+        cin = -(-(cf + cb) // 4) * 4  # the matrix-core kernels take multiples of 4 channels
+        feats = fluid_feats.new_zeros((n + m, cin))
+        feats[:n, :cf] = fluid_feats * self.part_scale
+        feats[n:, cf:cf + cb] = box_feats * self.part_scale
+        kernel = a.kernel.new_zeros(tuple(a.kernel.shape[:3]) + (cin, 2 * co))
+        kernel[..., :cf, :co] = a.kernel
+        kernel[..., cf:cf + cb, co:] = b.kernel
+        bias = torch.cat([a.bias, b.bias]) if a.use_bias else None
+        radius = float(np.float32(0.5) * np.float32(extent))
+        nns = _convs._CACHE.search(a.fixed_radius_search, all_pos, all_pos, radius, distances=False)
+        index, row_splits, raw_dist = nns.raw()
+        row_count = getattr(nns, "row_count", None)
+        out = ops.cconv_forward(kernel, all_pos, extent, all_pos, feats, index, row_splits, neighbors_value=raw_dist,
+                                window=wa.name, window_fac=wa.fac, align_corners=a.align_corners,
+                                coordinate_mapping=a.coordinate_mapping, interpolation=a.interpolation, bias=bias,
+                                n_pairs_ref=nns.total_ref, neighbors_row_count=row_count)
+        # fluid neighbours per fluid particle (postprocess, pbf_model.py:450-453), from the shared list while it is alive
+        if row_count is not None:
+            rows = index[:n * nns.stride].view(n, nns.stride)
+            cols = torch.arange(nns.stride, device=index.device, dtype=torch.int32)
+            self._fluid_counts = ((rows < n) & (cols[None, :] < row_count[:n, None])).sum(dim=1).to(torch.float32)
+        else:
+            self._fluid_counts = ops.reduce_subarrays_sum((nns.neighbors_index < n).to(torch.float32),
+                                                          nns.neighbors_row_splits)[:n]
+        a.nns = b.nns = None
+        return out[:, :co].contiguous(), out[:, co:].contiguous()
+
     def postprocess(self, prev, data, training=True, vel_corr=None, **kwargs):
         pos, vel, acc = data[:3]
         pcnt = pos.shape[0]
         # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
-        counts = ops.neighbor_counts(self.fluid_convs.nns)
-        self.num_fluid_neighbors = counts[:pcnt]
+        if self.fluid_convs.nns is None and getattr(self, "_fluid_counts", None) is not None:
+            self.num_fluid_neighbors, self._fluid_counts = self._fluid_counts, None
+        else:
+            counts = ops.neighbor_counts(self.fluid_convs.nns)
+            self.num_fluid_neighbors = counts[:pcnt]
 
         out = prev
         if out.shape[-1] == 1:  # :466-469

@@ -74,6 +74,32 @@ def test_liquid3d_real_weights_box_scene(dev):
     assert len(model._all_convs) == 18
 
 
+def test_fused_input_convs_equal_the_two_layers(dev, monkeypatch):
+    """Inside a step the two input layers run as one block-diagonal convolution on the all -> all list
+    (PBFNet._fused_input_convs): same features, same fluid-neighbour counts, same step as with DMCF_FUSE_INPUT_CONVS=0."""
+    from tools import configs, scenes
+    from dmcf_amd.utils.convolutions import neighbor_cache
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DMCF_FUSE_INPUT_CONVS", fuse)
+        model = _build(configs.LIQUID3D, w, dev)
+        data = scenes.model_inputs(scenes.box_scene(14, seed=5), device=dev)
+        with neighbor_cache():
+            d = model.transform(data)
+            x = model.preprocess(d)
+            assert (model.fluid_convs.nns is None) == (fuse == "1")
+            out = model.run_forward(x, d)
+            pos, vel = model.postprocess(out, d, training=False)
+        res[fuse] = (x[1].cpu().numpy(), model.num_fluid_neighbors.cpu().numpy(), pos.cpu().numpy())
+    feats, counts, pos = res["1"]
+    feats0, counts0, pos0 = res["0"]
+    assert np.abs(feats - feats0).max() <= 2e-6 * np.abs(feats0).max()
+    np.testing.assert_array_equal(counts, counts0)
+    assert counts.min() >= 1 and counts.max() > 20  # every particle is its own neighbour; the bulk has ~30
+    assert _rel(pos, pos0) <= 1e-6
+
+
 def test_liquid3d_momentum_conservation(dev):
     """ASCC head: sum of the network output over fluid + boundary particles vanishes (SURVEY section 4 invariant 4)."""
     from tools import configs, scenes
