@@ -63,7 +63,7 @@ __device__ __forceinline__ void xfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NTT, bool NARROW>
+template <int NTT, bool NARROW, bool SYM>
 __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
     const int64_t pt0 = (int64_t)tile * CTM;
-    const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
+    constexpr bool symmetric = SYM;  // the antisymmetric form (a template parameter: plain layers skip its 12 adds per feature round)
 
     // splat roles (A / B operands of 16x16x4): tile row m = lane & 15 = (z', y', x), pair k = lane >> 4, channel lane & 15
     const int mk = lane >> 4, mn = lane & 15;
@@ -239,11 +239,15 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         };
         // (the antisymmetric form adds the output point's own features: a padding slot then holds f_i, times weight 0)
         auto f_publish = [&](int t, const f32x4 (&f)[3]) {
-            // (a branch around the adds for layers that are not antisymmetric was measured: 2 % slower)
-            f32x4 fi4 = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (symmetric && fch_ok) fi4 = *(const f32x4*)(p.inp_feat + (pt0 + wave + (t >= nbA ? kCWaves : 0)) * cin + fch);
+            if constexpr (symmetric) {
+                f32x4 fi4 = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (fch_ok) fi4 = *(const f32x4*)(p.inp_feat + (pt0 + wave + (t >= nbA ? kCWaves : 0)) * cin + fch);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (spi * k + fr) * fstride + 4 * fc4) = f[k] + fi4;
+                for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (spi * k + fr) * fstride + 4 * fc4) = f[k] + fi4;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *(f32x4*)(Fst + (spi * k + fr) * fstride + 4 * fc4) = f[k];
+            }
         };
         // Splat of half h: the (at most 12) groups at fixed staging addresses -- no address arithmetic -- each into the tile
         // of its class.  The class of a group is wave uniform: the owner of a group's first slot left it in Cst (as the
@@ -527,13 +531,16 @@ int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    const bool sym = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
     const void* fn;
+#define CLS_PICK(NARROW, SYM)                                                                                      \
+    (NT <= 1 ? (const void*)cconv_cls_kernel<1, NARROW, SYM>                                                        \
+             : (NT <= 2 ? (const void*)cconv_cls_kernel<2, NARROW, SYM> : (const void*)cconv_cls_kernel<4, NARROW, SYM>))
     if (p.cin <= 8)
-        fn = NT <= 1 ? (const void*)cconv_cls_kernel<1, true>
-                     : (NT <= 2 ? (const void*)cconv_cls_kernel<2, true> : (const void*)cconv_cls_kernel<4, true>);
+        fn = sym ? CLS_PICK(true, true) : CLS_PICK(true, false);
     else
-        fn = NT <= 1 ? (const void*)cconv_cls_kernel<1, false>
-                     : (NT <= 2 ? (const void*)cconv_cls_kernel<2, false> : (const void*)cconv_cls_kernel<4, false>);
+        fn = sym ? CLS_PICK(false, true) : CLS_PICK(false, false);
+#undef CLS_PICK
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClsLds);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
