@@ -162,7 +162,7 @@ def main():
                        "parallelism": (f"{world} slabs along x of one {world * args.side}x{args.side}x{args.side} box, 1 process per GPU, "
                                        "per-layer ghost all-to-all-v over RCCL") if sharded else "single GPU",
                        "particles_per_gpu": n_fluid},
-            "roofline": {"bound": "hbm", "kernel": "dmcf::cconv_* (all CConv/ASCC launches of the timed steps: cconv_kernel, cconv_mfma_kernel, cconv_blk_kernel, cconv_cls_kernel, cconv_direct_kernel, lat_conv_kernel)",
+            "roofline": {"bound": "hbm", "kernel": "dmcf::cconv_* (all CConv/ASCC launches of the timed steps: cconv_kernel, cconv_mfma_kernel, cconv_blk_kernel, cconv_cls_kernel, cconv_z3_kernel, cconv_direct_kernel, lat_conv_kernel)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": len(conv), "avg_launch_ms": conv_ms / max(len(conv), 1),
                          "algorithmic_bytes_per_launch": conv_bytes / max(len(conv), 1)},

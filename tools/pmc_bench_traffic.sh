@@ -22,7 +22,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 res = dict(launches=n, fetch_kb_raw=tot["FETCH_SIZE"], write_kb_raw=tot["WRITE_SIZE"],
            hbm_bytes_per_launch=(2 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / max(n, 1),
            hbm_bytes_per_launch_uncorrected=(tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024 / max(n, 1),
-           note="sum over all dmcf::cconv* dispatches of `bench.py --steps 2 --warmup 1` (3 steps x 18 launches: 14 neighbour-list layers + 4 lattice layers), rocprofv3 --pmc, "
+           note="sum over all dmcf::cconv* dispatches of `bench.py --steps 2 --warmup 1` (3 steps x 17 launches: 13 neighbour-list layers + 4 lattice layers), rocprofv3 --pmc, "
                 "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide reads); WRITE_SIZE as reported")
 json.dump(res, open(f"{out}/cconv_hbm_traffic.json", "w"), indent=1)
 print(res)
