@@ -258,15 +258,14 @@ class PBFNet(BaseModel):
         self.dilated_pos = dilated_pos
         return [dilated_pos, fluid_feats, idx, dens]
 
-    def _fused_input_convs(self, fluid_feats, box_feats, pos, all_pos, extent):
-        """The two input layers (pbf_model.py:378-383: fluid -> all, boundary -> all, same radius, same flags) as ONE
-        convolution inside a rollout step: inputs = all particles with the features [f | 0] / [0 | b], filter = the two
-        kernels stacked block-diagonally, outputs [conv_f | conv_b].  Every product with a zero block is an exact zero, so
-        each half is the sum the separate layer forms (in the order of the shared list).  It runs on the all -> all list
-        of the first HRNet layer: two searches, two grid builds and one walk over ~3e7 pairs less per step.
-        Returns None when the layers differ in anything but their weights (then they run one after the other)."""
+    def fused_input_operands(self, fluid_feats, box_feats):
+        """Operands of the two input layers (pbf_model.py:378-383: fluid -> all, boundary -> all, same radius, same flags)
+        as ONE convolution: features [f | 0] for the fluid rows and [0 | b] for the boundary rows, the two kernels stacked
+        block-diagonally, outputs [conv_f | conv_b].  Every product with a zero block is an exact zero, so each half is the
+        sum the separate layer forms (in the order of the shared list).  None when the layers differ in anything but
+        their weights (then they run one after the other)."""
         a, b = self.fluid_convs, self.obs_convs
-        if (os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not pos.is_cuda
+        if (os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not fluid_feats.is_cuda
                 or fluid_feats.shape[0] == 0 or box_feats.shape[0] == 0):
             return None
         wa, wb = a.window_function, b.window_function
@@ -292,15 +291,35 @@ class PBFNet(BaseModel):
         kernel[..., :cf, :co] = a.kernel
         kernel[..., cf:cf + cb, co:] = b.kernel
         bias = torch.cat([a.bias, b.bias]) if a.use_bias else None
+        return feats, kernel, bias
+
+    def fused_input_conv(self, kernel, bias, feats, inp_pos, out_pos, extent):
+        """The convolution of :meth:`fused_input_operands` on the (inp_pos -> out_pos) list of the step's cache; returns
+        (output [n_out, 2 C], the list)."""
+        a = self.fluid_convs
         radius = float(np.float32(0.5) * np.float32(extent))
-        nns = _convs._CACHE.search(a.fixed_radius_search, all_pos, all_pos, radius, distances=False)
+        nns = _convs._CACHE.search(a.fixed_radius_search, inp_pos, out_pos, radius, distances=False)
         index, row_splits, raw_dist = nns.raw()
-        row_count = getattr(nns, "row_count", None)
-        out = ops.cconv_forward(kernel, all_pos, extent, all_pos, feats, index, row_splits, neighbors_value=raw_dist,
-                                window=wa.name, window_fac=wa.fac, align_corners=a.align_corners,
-                                coordinate_mapping=a.coordinate_mapping, interpolation=a.interpolation, bias=bias,
-                                n_pairs_ref=nns.total_ref, neighbors_row_count=row_count)
+        out = ops.cconv_forward(kernel, out_pos, extent, inp_pos, feats, index, row_splits, neighbors_value=raw_dist,
+                                window=a.window_function.name, window_fac=a.window_function.fac,
+                                align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
+                                interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
+                                neighbors_row_count=getattr(nns, "row_count", None))
+        a.nns = self.obs_convs.nns = None
+        return out, nns
+
+    def _fused_input_convs(self, fluid_feats, box_feats, pos, all_pos, extent):
+        """Inside a rollout step the two input layers run as one convolution on the all -> all list of the first HRNet
+        layer: two searches, two grid builds and one walk over ~3e7 pairs less per step."""
+        operands = self.fused_input_operands(fluid_feats, box_feats)
+        if operands is None:
+            return None
+        feats, kernel, bias = operands
+        out, nns = self.fused_input_conv(kernel, bias, feats, all_pos, all_pos, extent)
+        n, co = fluid_feats.shape[0], self.fluid_convs.filters
         # fluid neighbours per fluid particle (postprocess, pbf_model.py:450-453), from the shared list while it is alive
+        index = nns.raw()[0]
+        row_count = getattr(nns, "row_count", None)
         if row_count is not None:
             rows = index[:n * nns.stride].view(n, nns.stride)
             cols = torch.arange(nns.stride, device=index.device, dtype=torch.int32)
@@ -308,7 +327,6 @@ class PBFNet(BaseModel):
         else:
             self._fluid_counts = ops.reduce_subarrays_sum((nns.neighbors_index < n).to(torch.float32),
                                                           nns.neighbors_row_splits)[:n]
-        a.nns = b.nns = None
         return out[:, :co].contiguous(), out[:, co:].contiguous()
 
     def postprocess(self, prev, data, training=True, vel_corr=None, **kwargs):

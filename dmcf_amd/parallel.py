@@ -348,9 +348,19 @@ class ShardedSimulator:
         self._sets.update(pos=pos.contiguous(), box=box.contiguous(), s0=all_pos)
         n_fluid = pos.shape[0]
 
-        ans_conv = self._conv(m.fluid_convs, fluid_feats * m.part_scale, "pos", "s0", filter_extent[0])
+        operands = m.fused_input_operands(fluid_feats, box_feats)
+        if operands is not None:
+            # the two input layers as one block-diagonal convolution over all particles (models/pbf_model.py): one ghost
+            # plan and one exchange instead of two of each
+            in_feats, in_kernel, in_bias = operands
+            fused = self._conv(lambda f, pi, po, ext, _: m.fused_input_conv(in_kernel, in_bias, f, pi, po, ext)[0],
+                               in_feats, "s0", "s0", filter_extent[0])
+            co = m.fluid_convs.filters
+            ans_conv, ans_obs = fused[:, :co].contiguous(), fused[:, co:].contiguous()
+        else:
+            ans_conv = self._conv(m.fluid_convs, fluid_feats * m.part_scale, "pos", "s0", filter_extent[0])
+            ans_obs = self._conv(m.obs_convs, box_feats * m.part_scale, "box", "s0", filter_extent[0])
         ans_dense = m.fluid_dense(fluid_feats)
-        ans_obs = self._conv(m.obs_convs, box_feats * m.part_scale, "box", "s0", filter_extent[0])
         ans_dense = torch.cat([ans_dense, m.obs_dense(box_feats)], dim=0)
         feats = torch.cat([ans_conv, ans_obs, ans_dense], dim=-1)
 
