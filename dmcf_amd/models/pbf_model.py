@@ -112,6 +112,18 @@ class PBFNet(BaseModel):
     def setup(self):
         return
 
+    @property
+    def num_fluid_neighbors(self):
+        """Fluid neighbours per fluid particle of the last step (pbf_model.py:450-453)."""
+        if self._num_fluid_neighbors is None and getattr(self, "_fluid_counts", None) is not None:
+            self._num_fluid_neighbors, self._fluid_counts = self._fluid_counts(), None
+        return self._num_fluid_neighbors
+
+    @num_fluid_neighbors.setter
+    def num_fluid_neighbors(self, value):
+        self._num_fluid_neighbors = value
+        self._fluid_counts = None
+
     def get_cconv(self, name, kernel_size=None, activation=None, ignore_query_points=None, window_func=None,
                   normalize=False, **kwargs):
         """pbf_model.py:197-224: the factory fixing every CConv flag of the hot path."""
@@ -317,16 +329,23 @@ class PBFNet(BaseModel):
         feats, kernel, bias = operands
         out, nns = self.fused_input_conv(kernel, bias, feats, all_pos, all_pos, extent)
         n, co = fluid_feats.shape[0], self.fluid_convs.filters
-        # fluid neighbours per fluid particle (postprocess, pbf_model.py:450-453), from the shared list while it is alive
+        # fluid neighbours per fluid particle (pbf_model.py:450-453; only the training loss reads them): counted from the
+        # shared list when first asked for -- the closure keeps the list's index buffer alive until the next step
         index = nns.raw()[0]
         row_count = getattr(nns, "row_count", None)
         if row_count is not None:
-            rows = index[:n * nns.stride].view(n, nns.stride)
-            cols = torch.arange(nns.stride, device=index.device, dtype=torch.int32)
-            self._fluid_counts = ((rows < n) & (cols[None, :] < row_count[:n, None])).sum(dim=1).to(torch.float32)
+            stride = nns.stride
+
+            def count():
+                rows = index[:n * stride].view(n, stride)
+                cols = torch.arange(stride, device=index.device, dtype=torch.int32)
+                return ((rows < n) & (cols[None, :] < row_count[:n, None])).sum(dim=1).to(torch.float32)
         else:
-            self._fluid_counts = ops.reduce_subarrays_sum((nns.neighbors_index < n).to(torch.float32),
-                                                          nns.neighbors_row_splits)[:n]
+            idx, rs = nns.neighbors_index, nns.neighbors_row_splits
+
+            def count():
+                return ops.reduce_subarrays_sum((idx < n).to(torch.float32), rs)[:n]
+        self._fluid_counts = count
         return out[:, :co].contiguous(), out[:, co:].contiguous()
 
     def postprocess(self, prev, data, training=True, vel_corr=None, **kwargs):
@@ -334,7 +353,7 @@ class PBFNet(BaseModel):
         pcnt = pos.shape[0]
         # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
         if self.fluid_convs.nns is None and getattr(self, "_fluid_counts", None) is not None:
-            self.num_fluid_neighbors, self._fluid_counts = self._fluid_counts, None
+            self._num_fluid_neighbors = None  # formed by the property below when somebody reads it
         else:
             counts = ops.neighbor_counts(self.fluid_convs.nns)
             self.num_fluid_neighbors = counts[:pcnt]

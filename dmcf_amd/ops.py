@@ -104,7 +104,11 @@ class PaddedNeighborList(NeighborSearchResult):
 
     @property
     def total_ref(self):
-        return self.row_count.sum()
+        """0-dim device tensor holding P (no synchronisation); summed once per list, not once per consumer."""
+        t = getattr(self, "_total_ref", None)
+        if t is None:
+            t = self._total_ref = self.row_count.sum()
+        return t
 
     def release(self):
         super().release()
