@@ -348,7 +348,8 @@ def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, 
 
 
 @pytest.mark.parametrize("cin,cout,sym,radius", [(4, 8, False, 0.3), (8, 32, False, 0.45), (16, 16, False, 0.6), (24, 8, False, 0.3),
-                                                 (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45)])
+                                                 (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45),
+                                                 (20, 5, False, 0.3), (28, 40, False, 0.45)])
 @pytest.mark.parametrize("kernel", ["blk", "cls", "z3"])
 def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, kernel, cin, cout, sym, radius):
     """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA) and cconv_cls.hip (class-sorted, four pairs per 16x16x4
