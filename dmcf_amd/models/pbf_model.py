@@ -277,8 +277,9 @@ class PBFNet(BaseModel):
         sum the separate layer forms (in the order of the shared list).  None when the layers differ in anything but
         their weights (then they run one after the other)."""
         a, b = self.fluid_convs, self.obs_convs
-        if (os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not fluid_feats.is_cuda
-                or fluid_feats.shape[0] == 0 or box_feats.shape[0] == 0):
+        # (nothing here may depend on how many particles there are: in a sharded step every rank must take the same branch,
+        # the ghost plans behind the two forms are different collectives)
+        if os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not fluid_feats.is_cuda:
             return None
         wa, wb = a.window_function, b.window_function
         if a.kernel is None or b.kernel is None:

@@ -622,6 +622,15 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         out = torch.empty((n_out, cout), dtype=torch.float32, device=filters.device)
     elif out.shape != (n_out, cout) or out.dtype != torch.float32 or not out.is_contiguous():
         raise ValueError("out has the wrong shape / dtype / layout")
+    if inp_positions.shape[0] == 0 or n_out == 0:
+        # an empty input set (e.g. every boundary particle cropped away, pbf_model.py:330-336): every row is empty, the
+        # result is the bias; nothing to launch (the C ABI rejects NULL point arrays)
+        b = 0.0 if bias is None else bias.to(torch.float32)
+        if accumulate:
+            out += b
+        else:
+            out[:] = b
+        return out
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,

@@ -81,23 +81,28 @@ def test_fused_input_convs_equal_the_two_layers(dev, monkeypatch):
     from dmcf_amd.utils.convolutions import neighbor_cache
     w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
     res = {}
-    for fuse in ("1", "0"):
-        monkeypatch.setenv("DMCF_FUSE_INPUT_CONVS", fuse)
+    for fuse in ("1", "0", "1 no boundary", "0 no boundary"):
+        monkeypatch.setenv("DMCF_FUSE_INPUT_CONVS", fuse[0])
         model = _build(configs.LIQUID3D, w, dev)
-        data = scenes.model_inputs(scenes.box_scene(14, seed=5), device=dev)
+        scene = scenes.box_scene(14, seed=5)
+        if "no boundary" in fuse:  # every boundary particle is cropped away: the fused form must cope with an empty set
+            scene["box"] = scene["box"] + np.float32(100.0)
+        data = scenes.model_inputs(scene, device=dev)
         with neighbor_cache():
             d = model.transform(data)
             x = model.preprocess(d)
-            assert (model.fluid_convs.nns is None) == (fuse == "1")
+            assert (model.fluid_convs.nns is None) == (fuse[0] == "1")
             out = model.run_forward(x, d)
             pos, vel = model.postprocess(out, d, training=False)
         res[fuse] = (x[1].cpu().numpy(), model.num_fluid_neighbors.cpu().numpy(), pos.cpu().numpy())
-    feats, counts, pos = res["1"]
-    feats0, counts0, pos0 = res["0"]
-    assert np.abs(feats - feats0).max() <= 2e-6 * np.abs(feats0).max()
-    np.testing.assert_array_equal(counts, counts0)
-    assert counts.min() >= 1 and counts.max() > 20  # every particle is its own neighbour; the bulk has ~30
-    assert _rel(pos, pos0) <= 1e-6
+    for tag in ("", " no boundary"):
+        feats, counts, pos = res["1" + tag]
+        feats0, counts0, pos0 = res["0" + tag]
+        assert feats.shape == feats0.shape and (tag == "" or feats.shape[0] == 14 ** 3)
+        assert np.abs(feats - feats0).max() <= 2e-6 * np.abs(feats0).max()
+        np.testing.assert_array_equal(counts, counts0)
+        assert counts.min() >= 1 and counts.max() > 20  # every particle is its own neighbour; the bulk has ~30
+        assert _rel(pos, pos0) <= 1e-6
 
 
 def test_liquid3d_momentum_conservation(dev):
