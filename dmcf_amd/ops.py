@@ -292,12 +292,16 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         stride = max(int(row_stride), 1)
         # allocation sizes in coarse buckets (see pair_capacity): the lattice point sets change size every step
         need = m * stride
-        cap = _size_class(need)
+        # 1/8 headroom: the stride moves in steps of ~9 % (row_stride) and the lattice sets change size -- without it a
+        # list that grows a little asks for a fresh, slightly larger multi-GB block (a hipMalloc of 70-150 ms in that step)
+        cap = _size_class(need + need // 8)
         # a caller that repeats this search every step passes the capacity it got last time: while that still fits (and
         # is not grossly oversized) the request stays byte-identical, and the caching allocator answers it without a
         # hipMalloc (a fresh 2 GB block costs 20-120 ms; m * stride hovers around a bucket edge for steps on end)
         if capacity_hint is not None and need <= int(capacity_hint) <= 2 * cap:
             cap = int(capacity_hint)
+        elif capacity_hint is not None and need > int(capacity_hint):
+            cap = _size_class(need + need // 4)  # outgrown: make this reallocation the last one for a while
         index = torch.empty(cap, dtype=torch.int32, device=dev)
         dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
         counts = torch.empty(m, dtype=torch.int32, device=dev)
