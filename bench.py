@@ -7,18 +7,31 @@ of the Liquid3d SymNet with the reference's trained weights + integration) over 
 
 Workload (BASELINE.json: metric quoted on "1M particles"; config 5 "synthetic 3-D box"): per GPU a cube of
 ``side``^3 = 1,000,000 fluid particles, spacing h = 0.05, jitter U(-0.1h, 0.1h) seed 0, velocities N(0, 0.1^2)
-seed 1, closed 2-layer boundary shell (124,864 particles).  N > 1: one process per GPU, each with its own
-box of the same size (weak scaling), no data-path collective in this round.
+seed 1, closed 2-layer boundary shell (124,864 particles at N = 1).
+
+``--gpus N`` with N > 1 and no RANK in the environment: bench.py launches its own N ranks (it re-executes itself
+under ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1``); started BY such a
+launcher (RANK / WORLD_SIZE set) it is one rank: one process per GPU, RCCL (backend "nccl") world size asserted = N.
+The ranks shard ONE box of N * side^3 particles into axis-aligned blocks (dmcf_amd/parallel.py: 2 = 2x1x1, 4 = 2x2x1,
+8 = 2x2x2; other N: slabs) -- weak scaling, side^3 particles per GPU -- and every CConv layer refreshes its ghost
+features with one all-to-all-v over RCCL.
 
 Extra objects on the JSON line:
-  roofline      the CConv kernel (dmcf::cconv_kernel): algorithmic bytes (SURVEY.md section 8d formula) of all its
-                launches in the timed steps / their summed duration measured with HIP events on the launch stream
-  cpu_baseline  the CPU oracle (numpy + C restatement, OpenMP on all host cores) timed on a bounded sample of the
-                same workload (a smaller box of the same density and network), rank 0, N = 1 only
+  roofline          the DOMINANT CConv kernel of the timed steps (the template instantiation with the largest summed
+                    duration): algorithmic bytes of its launches / their summed duration, HIP
+                    events on the launch stream.  ``traffic`` cites the PMC measurement committed under profiles/ for
+                    that kernel (``traffic_source``), it is not re-measured in this run.
+  roofline_groups   the same fraction for (a) all neighbour-list kernels together, (b) the lattice-form launches --
+                    charged the bytes THEY move (input volume + per-offset matrices + table + outputs), not the pair
+                    bytes of a list they never read --, and per kernel instantiation
+  cpu_baseline      the CPU oracle (numpy + C restatement, OpenMP on all host cores) timed on a bounded sample of the
+                    same workload (a smaller box from the same generator, ~config 4's 100k particles), rank 0, N = 1
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,13 +44,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 
 
 def cconv_algorithmic_bytes(m):
-    """P*(4 idx + 4 dist + 12 xyz + 4*Cin feats) + n_out*(8 + 12 + 4*Cout) + 4*K*Cin*Cout."""
-    return (m["pairs"] * (4 + 4 + 12 + 4 * m["cin"]) + m["n_out"] * (8 + 12 + 4 * m["cout"])
-            + 4 * m["K"] * m["cin"] * m["cout"])
+    """SURVEY.md section 8d, no cache credit.  Neighbour-list launch: P * (4 index + 12 neighbour xyz + 4 * Cin features
+    [+ 4 importance / d^2 only when the list carries that array]) + n_out * (8 row split + 12 xyz + 4 * Cout) +
+    4 * K * Cin * Cout.  Lattice launch (no list): the input volume, the per-offset matrices, the cell table, the outputs."""
+    if m.get("lattice"):
+        return (m["volume_bytes"] + m["table_bytes"] + 4 * m["n_offsets"] * m["cin"] * m["cout"]
+                + m["n_out"] * 4 * m["cout"] + 4 * m["K"] * m["cin"] * m["cout"])
+    per_pair = 4 + 12 + 4 * m["cin"] + (4 if m.get("pair_values", True) else 0)
+    return m["pairs"] * per_pair + m["n_out"] * (8 + 12 + 4 * m["cout"]) + 4 * m["K"] * m["cin"] * m["cout"]
+
+
+def frs_algorithmic_bytes(m):
+    """12 (n_in + n_out) + 12 n_in + P * (4 [+ 4 distances]) + 8 n_out."""
+    return (12 * (m["n_points"] + m["n_queries"]) + 12 * m["n_points"] + m.get("pairs", 0) * (8 if m.get("distances") else 4)
+            + 8 * m["n_queries"])
 
 
 def cpu_baseline(side, weights, cfg):
-    """Time ONE step of the CPU oracle (the restated reference path) on a side^3 box of the same density."""
+    """Time ONE step of the CPU oracle (the restated reference path) on a side^3 box from the bench's scene generator."""
     import oracle  # noqa: F401  (builds the C library if needed)
     from oracle.model_ref import ModelRef
     from tools import scenes
@@ -49,19 +73,100 @@ def cpu_baseline(side, weights, cfg):
     dt = time.time() - t0
     n = scene["pos"].shape[0]
     return dict(value=n / dt, unit="particle-steps/s", cores=len(os.sched_getaffinity(0)), kind="port",
-                sample=f"1 step of the CPU oracle (oracle/model_ref.py, OpenMP) on a {side}^3 = {n}-particle box of the "
-                       f"same density and network; {dt:.1f} s, {ref.pairs} neighbour pairs")
+                sample=f"1 step of the CPU oracle (oracle/model_ref.py: numpy + OpenMP C restatement of the Open3D CPU "
+                       f"algorithms; not TensorFlow/Open3D) on a {side}^3 = {n}-particle box (+ {scene['box'].shape[0]} "
+                       f"boundary) from the bench's own scene generator, same density and network; {dt:.1f} s, "
+                       f"{ref.pairs} neighbour pairs")
 
 
-def main():
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launcher_command(argv, gpus, port=None):
+    """The command ``python bench.py --gpus N`` re-executes itself with (one rank per GPU)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)  # the caching allocator reaches its steady state after ~3 steps
-    ap.add_argument("--side", type=int, default=100, help="fluid cube edge in particles (100 -> 1M particles)")
-    ap.add_argument("--cpu-side", type=int, default=40, help="edge of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--side", type=int, default=100, help="fluid cube edge in particles per GPU (100 -> 1M particles)")
+    ap.add_argument("--cpu-side", type=int, default=46, help="edge of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--layers-json", default=None, help="write the per-launch table here")
-    args = ap.parse_args()
+    ap.add_argument("--decomp", default="blocks", choices=["blocks", "slabs"])
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reduction logic only, on the gloo backend without a GPU (CPU test)")
+    return ap.parse_args(argv)
+
+
+def block_grid(world):
+    """Ranks per axis (x, y, z) of the block decomposition: SURVEY.md section 8e (8 = 2x2x2, 4 = 2x2x1, 2 = 2x1x1)."""
+    grid = [1, 1, 1]
+    k, w = 0, world
+    while w % 2 == 0 and w > 1:
+        grid[k % 3] *= 2
+        w //= 2
+        k += 1
+    grid[0] *= w  # an odd factor: slabs along x
+    return grid
+
+
+def summarise(recs, steps):
+    """Per-kernel roofline table from the (kind, meta, ms) launch records of the timed steps."""
+    groups = {}
+    for kind, m, ms in recs:
+        if kind != "cconv":
+            continue
+        g = groups.setdefault(m.get("kernel", "cconv"), dict(launches=0, ms=0.0, bytes=0, lattice=bool(m.get("lattice"))))
+        g["launches"] += 1
+        g["ms"] += ms
+        g["bytes"] += cconv_algorithmic_bytes(m)
+
+    def frac(gs):
+        ms = sum(g["ms"] for g in gs)
+        by = sum(g["bytes"] for g in gs)
+        n = sum(g["launches"] for g in gs)
+        gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        return dict(launches=n, ms_per_step=ms / steps, avg_launch_ms=ms / max(n, 1), algorithmic_bytes_per_launch=by / max(n, 1),
+                    achieved=gbs, frac=gbs / HBM_PEAK_GBS)
+    nl = [g for g in groups.values() if not g["lattice"]]
+    lat = [g for g in groups.values() if g["lattice"]]
+    table = dict(neighbour_list=frac(nl), lattice=frac(lat), by_kernel={k: frac([g]) for k, g in sorted(groups.items())})
+    dominant = max(groups, key=lambda k: groups[k]["ms"]) if groups else None
+    return table, dominant
+
+
+def cited_traffic(kernel):
+    """HBM bytes per launch of ``kernel`` from the newest PMC summary committed under profiles/ (FETCH_SIZE / WRITE_SIZE
+    passes of the bench command, corrected as MI355X_MICROARCH.md prescribes); (None, None) if there is none."""
+    best = (None, None)
+    pdir = os.path.join(ROOT, "profiles")
+    for f in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if not f.endswith("hbm_traffic.json"):
+            continue
+        try:
+            d = json.load(open(os.path.join(pdir, f)))
+        except ValueError:
+            continue
+        per = d.get("by_kernel", {})
+        for name, v in per.items():
+            if kernel and (name == kernel or name.endswith("::" + kernel) or kernel in name):
+                best = (v.get("hbm_bytes_per_launch"), f"profiles/{f} [{name}]")
+    return best
+
+
+def main():
+    args = parse_args()
+    in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not in_launcher:
+        # the driver's contract: plain `python bench.py --gpus N` -- start the N ranks ourselves
+        raise SystemExit(subprocess.call(launcher_command(sys.argv[1:], args.gpus)))
 
     import torch
     import torch.distributed as dist
@@ -69,15 +174,39 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    # DMCF_BENCH_SHARDED=1 under torch.distributed.run with ONE process: the sharded driver + RCCL collectives at world
-    # size 1 (the only way to exercise that path on a 1-GPU box; its ghost sets are empty)
-    sharded = world > 1 or (os.environ.get("DMCF_BENCH_SHARDED") == "1" and "RANK" in os.environ)
+    if in_launcher and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    # DMCF_BENCH_SHARDED=1 under a launcher with ONE process: the sharded driver + RCCL collectives at world size 1 (the
+    # only way to exercise that path on a 1-GPU box; its ghost sets are empty)
+    sharded = world > 1 or (os.environ.get("DMCF_BENCH_SHARDED") == "1" and in_launcher)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+    if args.dry_run:
+        # everything around the step: rendezvous, world-size check, barrier, max-over-ranks timing, one line from rank 0
+        if sharded:
+            dist.init_process_group("gloo")
+            assert dist.get_world_size() == args.gpus and dist.get_rank() == rank
+        t0 = time.perf_counter()
+        time.sleep(0.01 * (rank + 1))
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if sharded:
+            dist.barrier()
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "rollout_particle_steps_per_sec", "dry_run": True, "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "block_grid": block_grid(world), "max_rank_seconds": float(el.item())}), flush=True)
+        if sharded:
+            dist.destroy_process_group()
+        return
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DMCF hot path has no CPU fallback); --dry-run tests the launch logic")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    elif args.gpus != 1:
-        raise SystemExit("for --gpus N > 1 launch with torch.distributed.run (one process per GPU)")
+        assert dist.get_world_size() == world == args.gpus, "RCCL world size != --gpus"
     dev = torch.device("cuda", local_rank)
 
     from dmcf_amd import models, ops
@@ -89,24 +218,32 @@ def main():
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, weights, device=dev)
+    extra = {}
     if not sharded:
         sim = Simulator(model, device=f"cuda:{local_rank}")
         scene = scenes.box_scene(args.side)
         n_fluid = scene["pos"].shape[0]
+        n_total = n_fluid
         state = scenes.model_inputs(scene, device=dev)
         step = lambda st: sim.step([st])[0]  # noqa: E731
+        par = "single GPU"
     else:
-        # weak scaling: a (side*N) x side x side box, rank r owns the r-th cube (slab along x); every layer
-        # refreshes its ghost features with one all-to-all-v over RCCL (dmcf_amd/parallel.py)
+        # weak scaling: ONE box of grid * side particles, rank r owns one block of side^3; every layer refreshes its ghost
+        # features with one all-to-all-v over RCCL (dmcf_amd/parallel.py)
         from dmcf_amd import parallel
         comm = parallel.TorchDistComm()
-        decomp = parallel.SlabDecomposition.uniform(0, 0.0, world * args.side * 0.05, world)
+        grid = block_grid(world) if args.decomp == "blocks" else [world, 1, 1]
+        h = 0.05
+        decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * args.side * h for g in grid], grid)
         ssim = parallel.ShardedSimulator(model, comm, decomp)
-        scene = scenes.box_slab_scene(args.side, world, rank)
+        scene = scenes.box_block_scene(args.side, grid, rank)
         n_fluid = scene["pos"].shape[0]
-        state = parallel.shard_scene(scene, decomp, rank, dev)
+        state = parallel.shard_scene(scene, decomp, rank, dev, presharded=True)
         state["gid"] = state["gid"] + rank * n_fluid
+        n_total = world * n_fluid
         step = ssim.step
+        par = (f"{grid[0]}x{grid[1]}x{grid[2]} blocks of one {grid[0] * args.side}x{grid[1] * args.side}x{grid[2] * args.side} box, "
+               "1 process per GPU, per-layer ghost all-to-all-v over RCCL")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -138,36 +275,42 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # particles actually stepped: the sum over the ranks of what they own now (migration moves particles, none are lost)
+        cnt = torch.tensor([state["pos"].shape[0]], dtype=torch.int64, device=dev)
+        dist.all_reduce(cnt)
+        assert int(cnt.item()) == n_total, f"particles lost in migration: {int(cnt.item())} != {n_total}"
+        extra["ghost_rows_per_step_rank0"] = int(ssim.exchanged_rows / max(args.steps + args.warmup, 1))
 
     if rank == 0:
         recs = timer.results()
-        conv = [(m, ms) for k, m, ms in recs if k == "cconv"]
-        conv_ms = sum(ms for _, ms in conv)
-        conv_bytes = sum(cconv_algorithmic_bytes(m) for m, _ in conv)
-        achieved = conv_bytes / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_cconv_hbm_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        table, dominant = summarise(recs, args.steps)
+        dom = table["by_kernel"].get(dominant, dict(achieved=0.0, frac=0.0, launches=0, avg_launch_ms=0.0, algorithmic_bytes_per_launch=0.0))
+        traffic, traffic_source = cited_traffic(dominant)
         other = {}
         for k, m, ms in recs:
             other[k] = other.get(k, 0.0) + ms
+        frs = [(m, ms) for k, m, ms in recs if k in ("frs_search_padded", "frs_write", "frs_count")]
+        frs_ms = sum(ms for _, ms in frs)
+        frs_bytes = sum(frs_algorithmic_bytes(m) for m, _ in frs if "pairs" in m)
         line = {
-            "metric": "rollout_particle_steps_per_sec", "value": world * n_fluid * args.steps / elapsed,
+            "metric": "rollout_particle_steps_per_sec", "value": n_total * args.steps / elapsed,
             "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"synthetic 3-D box, {n_fluid} fluid + {scene['box'].shape[0]} boundary particles per GPU, "
-                                   f"Liquid3d SymNet (18 CConv/ASCC layers, reference checkpoint weights), one rollout step",
-                       "parallelism": (f"{world} slabs along x of one {world * args.side}x{args.side}x{args.side} box, 1 process per GPU, "
-                                       "per-layer ghost all-to-all-v over RCCL") if sharded else "single GPU",
-                       "particles_per_gpu": n_fluid},
-            "roofline": {"bound": "hbm", "kernel": "dmcf::cconv_* (all CConv/ASCC launches of the timed steps: cconv_kernel, cconv_mfma_kernel, cconv_blk_kernel, cconv_cls_kernel, cconv_z3_kernel, cconv_direct_kernel, lat_conv_kernel)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": len(conv), "avg_launch_ms": conv_ms / max(len(conv), 1),
-                         "algorithmic_bytes_per_launch": conv_bytes / max(len(conv), 1)},
+            "config": {"workload": f"synthetic 3-D box (BASELINE.json config 5), {n_fluid} fluid particles per GPU + closed 2-layer "
+                                   f"boundary shell ({scene['box'].shape[0]} boundary particles on rank 0), Liquid3d SymNet (18 CConv/ASCC "
+                                   "layers, reference checkpoint weights), one rollout step",
+                       "parallelism": par, "particles_per_gpu": n_fluid},
+            "roofline": {"bound": "hbm", "kernel": f"dmcf::{dominant}", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
+                         "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"]},
+            "roofline_groups": table,
+            "search": {"ms_per_step": frs_ms / args.steps, "achieved": frs_bytes / (frs_ms * 1e-3) / 1e9 if frs_ms > 0 else 0.0,
+                       "unit": "GB/s", "launches": len(frs)},
             "kernel_ms_per_step": {k: v / args.steps for k, v in other.items()},
         }
+        line.update(extra)
         if world == 1 and args.cpu_side > 0:
             line["cpu_baseline"] = cpu_baseline(args.cpu_side, weights, cfg)
         if args.layers_json:

@@ -81,7 +81,7 @@ class LatticeConvArgs(ctypes.Structure):
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
-    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
+    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_kernel_name", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
     "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
     "dmcf_lattice_conv_batch_workspace_bytes", "dmcf_lattice_conv_forward_batch",
     "dmcf_reduce_subarrays_sum",
@@ -134,6 +134,8 @@ def lib():
     L.dmcf_cconv_workspace_bytes.argtypes = [c.POINTER(CconvArgs)]
     L.dmcf_cconv_forward.restype = c.c_int
     L.dmcf_cconv_forward.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_cconv_kernel_name.restype = c.c_int
+    L.dmcf_cconv_kernel_name.argtypes = [c.POINTER(CconvArgs), c.c_char_p, c.c_size_t]
     L.dmcf_lattice_conv_workspace_bytes.restype = c.c_size_t
     L.dmcf_lattice_conv_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs)]
     L.dmcf_lattice_conv_forward.restype = c.c_int

@@ -31,6 +31,8 @@
 
 #include <type_traits>
 
+#include <stdio.h>
+
 #include "cconv_common.h"
 
 namespace dmcf {
@@ -575,17 +577,6 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.cout = a->filter_dims[4];
     p.sx = dx; p.sy = dy; p.sz = dz;
     p.K = dx * dy * dz;
-    const LaunchCfg cfg = make_cfg(dx, dy, dz, p.cin, p.cout);
-    if (cfg.lds > 160 * 1024) return DMCF_EUNSUPPORTED;
-    {
-        float* packed = (float*)workspace;
-        const int64_t total = (int64_t)cfg.packed_floats;
-        const unsigned g = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
-                           p.cin, p.cout, cfg.CC, cfg.PS, cfg.nchunks, cfg.nblocks, cfg.NT,
-                           (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
-        p.Wp = packed;
-    }
     p.out_pos = a->out_positions;
     p.inp_pos = a->inp_positions;
     p.inp_feat = a->inp_features;
@@ -613,6 +604,19 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     if (cconv_cls_eligible(a, dz, dy, dx)) return cconv_cls_launch(p, a, workspace, stream);
     if (cconv_blk_eligible(a, dz, dy, dx)) return cconv_blk_launch(p, a, workspace, stream);
     if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
+    // the generic LDS-splat kernel: its own filter packing and LDS budget (every specialised kernel above packs its own
+    // layout into the same workspace and has its own limits)
+    const LaunchCfg cfg = make_cfg(dx, dy, dz, p.cin, p.cout);
+    if (cfg.lds > 160 * 1024) return DMCF_EUNSUPPORTED;
+    {
+        float* packed = (float*)workspace;
+        const int64_t total = (int64_t)cfg.packed_floats;
+        const unsigned g = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
+                           p.cin, p.cout, cfg.CC, cfg.PS, cfg.nchunks, cfg.nblocks, cfg.NT,
+                           (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
+        p.Wp = packed;
+    }
     p.KCp = cfg.KCp;
     p.PS = cfg.PS;
     p.zgroup = cfg.zgroup;
@@ -648,6 +652,30 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     e = hipLaunchKernel(fn, dim3(grid), dim3(kThreads), kargs, cfg.lds, stream);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
     return check_launch();
+}
+
+int dmcf_cconv_kernel_name(const dmcf_cconv_args* a, char* name, size_t name_bytes) {
+    if (!name || name_bytes < 2) return DMCF_EINVAL;
+    int rc = validate(a, false);
+    if (rc != DMCF_OK) return rc;
+    int dz, dy, dx;
+    full_dims(a, dz, dy, dx);
+    const int cin = a->filter_dims[3], cout = a->filter_dims[4], NT = (cout + 15) / 16;
+    const int ntt = NT <= 1 ? 1 : (NT <= 2 ? 2 : 4);
+    const bool sym = (a->flags & DMCF_FLAG_SYMMETRIC) != 0;
+    if (cconv_direct_eligible(a, dz, dy, dx))
+        snprintf(name, name_bytes, "cconv_direct_kernel<%d, %s>", cout, specialised(a) ? "false" : "true");
+    else if (cconv_z3_eligible(a, dz, dy, dx))
+        snprintf(name, name_bytes, "cconv_z3_kernel<%d>", ntt);
+    else if (cconv_cls_eligible(a, dz, dy, dx))
+        snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false");
+    else if (cconv_blk_eligible(a, dz, dy, dx))
+        snprintf(name, name_bytes, "cconv_blk_kernel<%d>", ntt);
+    else if (!a->geometry && cconv_mfma_eligible(dz * dy * dx, cin, cout))
+        snprintf(name, name_bytes, "cconv_mfma_kernel");
+    else
+        snprintf(name, name_bytes, "cconv_kernel<%d>", make_cfg(dx, dy, dz, cin, cout).CC);
+    return DMCF_OK;
 }
 
 size_t dmcf_cconv_geometry_bytes(int64_t n_pairs) {

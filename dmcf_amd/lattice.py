@@ -16,6 +16,15 @@ import torch
 _TLS = threading.local()  # per thread: the virtual ranks of dmcf_amd.parallel are threads, each with its own lattices
 _KEEP = 16
 
+# Parity guard.  The reference (and the neighbour-list kernels) subtract two ROUNDED float32 positions,
+# fl(fl(n_j v) + c) - fl(fl(n_i v) + c); the lattice form uses the nominal d * v.  The two differ by the rounding of the
+# positions, ~ulp(|x|), i.e. ~6e-8 |x| / extent of the filter extent, and the ball -> cube map and the x3 filter scale turn
+# that into a relative deviation of the layer output of about 0.6e-6 * |x| / extent (measured on the 1M-particle bench
+# scene: 8.5e-6 at |x| / extent = 15.5).  Above this ratio the layer keeps the neighbour-list form,
+# whose arithmetic is the reference's own: the deviation of a layer stays below 2e-5 of its output, which is below 1e-7
+# of the positions after the out_scale of every shipped model.  DMCF_LATTICE_MAX_RATIO overrides it.
+MAX_X_OVER_EXTENT = float(os.environ.get("DMCF_LATTICE_MAX_RATIO", "32"))
+
 
 def _registry():
     """(data_ptr, n) -> LatticeInfo; the newest few lattices of this thread only."""
@@ -32,8 +41,14 @@ def clear():
 
 
 class LatticeInfo:
-    def __init__(self, gpos, center, voxel, family, minp, dims, keep=None):
+    def __init__(self, gpos, center, voxel, family, minp, dims, keep=None, center_host=None):
         self.gpos = gpos            # keeps the storage alive, so the registry key stays unique
+        # largest |coordinate| any point of the box can have (host arithmetic; None: the centre is not known on the host
+        # and the guard of pair() then keeps the neighbour-list form)
+        self.max_abs = None
+        if center_host is not None:
+            self.max_abs = max(abs(float(center_host[k])) + max(abs(int(minp[k])), abs(int(minp[k]) + int(dims[k]))) * float(voxel[k])
+                               for k in range(3))
         self.keep = keep            # ... and whatever the family key points at (the source positions / the centre)
         self.version = gpos._version
         self.center = center        # float32 [3] on the device
@@ -62,6 +77,11 @@ class LatticeInfo:
         dx, dy, dz = dims
         c = self.cells().long()
         lin = ((c[:, 2] - minp[2]) * dy + (c[:, 1] - minp[1])) * dx + (c[:, 0] - minp[0])
+        if os.environ.get("DMCF_LATTICE_CHECK") == "1":  # a point outside the box would scatter out of bounds below
+            lo = torch.tensor(list(minp), device=c.device)
+            hi = lo + torch.tensor(list(dims), device=c.device)
+            if not bool(((c >= lo) & (c < hi)).all()):
+                raise RuntimeError("lattice points outside the registered box of cells")
         if own:
             self._lin = lin
         return lin
@@ -88,16 +108,16 @@ class LatticeInfo:
         return v.view(dz, dy, dx, features.shape[1])
 
 
-def register(gpos, center, voxel, family, minp, dims, keep=None):
+def register(gpos, center, voxel, family, minp, dims, keep=None, center_host=None):
     if gpos.shape[0] == 0 or any(not (float(v) > 1e-5) for v in voxel):
         return  # empty, or a collapsed axis (2-D scenes): the neighbour-list form handles those
     reg = _registry()
-    reg[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims, keep)
+    reg[(gpos.data_ptr(), gpos.shape[0])] = LatticeInfo(gpos, center, voxel, family, minp, dims, keep, center_host)
     while len(reg) > _KEEP:
         reg.popitem(last=False)
 
 
-def register_points(pos, center, voxel, family, box=None, keep=None):
+def register_points(pos, center, voxel, family, box=None, keep=None, center_host=None):
     """Register ANY float32 [n, 3] tensor of points of the lattice ``center + cell * voxel`` (a filtered grid_pos result,
     owned + ghost points of a sharded step).  ``box`` = (minp, dims) of a box of cells known to hold them all; without it
     the bounding box of the cells is found on the device (one small host round trip)."""
@@ -109,7 +129,7 @@ def register_points(pos, center, voxel, family, box=None, keep=None):
         lo, hi = cells.amin(dim=0), cells.amax(dim=0)
         b = torch.cat([lo, hi - lo + 1]).tolist()
         box = (b[0:3], b[3:6])
-    info = LatticeInfo(pos, center, voxel, family, box[0], box[1], keep if keep is not None else center)
+    info = LatticeInfo(pos, center, voxel, family, box[0], box[1], keep if keep is not None else center, center_host)
     reg = _registry()
     reg[(pos.data_ptr(), pos.shape[0])] = info
     while len(reg) > _KEEP:
@@ -170,14 +190,19 @@ class LatticePair:
                                 parts=parts, fill=fill, **kw)
 
 
-def pair(inp_positions, out_positions):
+def pair(inp_positions, out_positions, extent=None):
     """LatticePair if both tensors are registered lattices of one family and the spacings are in the ratio 1, 2, 3, ...
-    (outputs as fine or coarser) or 1/2 (outputs twice as fine); None otherwise (then the neighbour-list form runs)."""
+    (outputs as fine or coarser) or 1/2 (outputs twice as fine); None otherwise (then the neighbour-list form runs).
+    ``extent``: the filter extent of the layer, for the parity guard (MAX_X_OVER_EXTENT): None if the scene reaches too far
+    from the origin for this extent."""
     if not enabled():
         return None
     a, b = lookup(inp_positions), lookup(out_positions)
     if a is None or b is None or a.family != b.family:
         return None
+    if extent is not None:
+        if a.max_abs is None or b.max_abs is None or max(a.max_abs, b.max_abs) > MAX_X_OVER_EXTENT * float(extent):
+            return None
     if all(a.voxel[k] == 2.0 * b.voxel[k] for k in range(3)):
         return LatticePair(a, b, 0.5)
     step = round(b.voxel[0] / a.voxel[0])

@@ -39,7 +39,7 @@ class CConv(PBFNet):
         ans_convs = [feats]
         for conv, dense in zip(self.convs, self.denses):  # cconv.py:59-67
             feats = torch.relu(ans_convs[-1])
-            ans_conv = conv(feats, pos, pos, filter_extent, None)
+            ans_conv = self.apply_conv(conv, feats, pos, pos, filter_extent)
             ans_dense = dense(feats)
             if ans_dense.shape[-1] == ans_convs[-1].shape[-1]:
                 ans = ans_conv + ans_dense + ans_convs[-1]

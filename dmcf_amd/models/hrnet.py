@@ -73,7 +73,10 @@ class HRNet(PBFNet):
                         feats = torch.cat([feats, feats / dens[inp_scale] ** 2], dim=-1)
                     ext = filter_extent[max(inp_scale, scale)]
                     conv_in = feats if importance == 1.0 else feats * importance
-                    ans_conv = self.convs[layer][scale][0][inp_scale](conv_in, pos[inp_scale], pos[scale], ext, None)
+                    # (the same relu(x_{inp_scale}) feeds every output scale: its widest extent is a hint for the hook)
+                    widest = max(filter_extent[max(inp_scale, s)] for s in range(len(self.convs[layer])))
+                    ans_conv = self.apply_conv(self.convs[layer][scale][0][inp_scale], conv_in, pos[inp_scale], pos[scale], ext,
+                                               widest if conv_in is feats else None)
                     if layer < len(self.denses):
                         if scale == inp_scale:  # :93-99
                             ans_conv = ans_conv + self.denses[layer][scale][0][inp_scale](feats)
@@ -98,7 +101,7 @@ class HRNet(PBFNet):
                 else:
                     ans.append(torch.cat(inp, dim=-1))
                 for i in range(1, len(self.convs[layer][scale])):  # :120-131 (k > 0 sub-layers)
-                    ans_conv = self.convs[layer][scale][i][0](ans[-1] * importance, pos[scale], pos[scale], ext, None)
+                    ans_conv = self.apply_conv(self.convs[layer][scale][i][0], ans[-1] * importance, pos[scale], pos[scale], ext)
                     ans_conv = ans_conv + self.denses[layer][scale][i][0](ans[-1])
                     if len(ans_convs[-1]) > scale and ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:
                         ans_conv = ans_conv + ans_convs[-1][scale]

@@ -139,6 +139,17 @@ class PBFNet(BaseModel):
         self._all_convs.append((name, conv))
         return conv
 
+    conv_hook = None
+
+    def apply_conv(self, conv, feats, inp_pos, out_pos, extent, widest_extent=None):
+        """Every ContinuousConv call of the forward pass goes through here: ``conv(feats, inp_pos, out_pos, extent, None)``
+        (hrnet.py:90-92, sym_net.py:66, cconv.py) unless a ``conv_hook`` is installed -- the sharded driver
+        (dmcf_amd/parallel.py) installs one that extends the input rows by the ghost particles within extent / 2.
+        ``widest_extent``: the largest extent of the calls that read the same ``feats`` (a hint for that hook)."""
+        if self.conv_hook is not None:
+            return self.conv_hook(conv, feats, inp_pos, out_pos, extent, widest_extent)
+        return conv(feats, inp_pos, out_pos, extent, None)
+
     def integrate_pos_vel(self, pos1, vel1, acc1=None):
         """Semi-implicit Euler (pbf_model.py:234-240)."""
         dt = self.timestep

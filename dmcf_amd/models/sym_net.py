@@ -40,5 +40,5 @@ class SymNet(HRNet):
         for conv in self.sym_convs:  # sym_net.py:63-67
             ans = torch.relu(ans)
             conv_in = ans if self.part_scale == 1.0 else ans * self.part_scale
-            ans = conv(conv_in, self.all_pos, self.all_pos, ext, None)
+            ans = self.apply_conv(conv, conv_in, self.all_pos, self.all_pos, ext)
         return self.act(ans)

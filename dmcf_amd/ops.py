@@ -314,8 +314,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
                                  lambda: fixed_radius_search(points, queries, radius, ignore_query_point, return_distances,
                                                              hash_table))
         if timer is not None:
-            timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
-            timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
+            timer.end("frs_search_padded", dict(n_points=n, n_queries=m, pairs=res.total_ref, distances=bool(return_distances)), t0)
         return res
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
@@ -342,8 +341,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         keep = (points, queries, ws)  # noqa: F841  (the closure keeps the operands alive for a possible redo)
         res = NeighborSearchResult(index, row_splits, dist, total=None, redo=write)
     if timer is not None:
-        timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=res.total_ref), t1)
-        timer.end("frs_query", dict(n_points=n, n_queries=m, pairs=res.total_ref), t0)
+        timer.end("frs_write", dict(n_points=n, n_queries=m, pairs=res.total_ref, distances=bool(return_distances)), t1)
     return res
 
 
@@ -601,12 +599,15 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
     else:
         _lib.check(L.dmcf_lattice_conv_forward_batch(arr, len(parts), _ptr(ws), nbytes, _stream()), "dmcf_lattice_conv_forward_batch")
     if timer is not None:
-        # bench accounting (SURVEY 8d is per neighbour pair): the pairs the neighbour-list form would have had, estimated as
-        # outputs x stencil offsets x the fraction of occupied cells in the input lattice's box (``fill``; a slight
-        # under-estimate: the interior is denser than the box average); the parts of a batch split the outputs evenly
+        # bench accounting: this form reads no neighbour list, so it is charged what it does read and write -- the input
+        # volume once, the per-offset matrices, the cell -> point table and the output rows (``pairs_equiv`` = the pairs the
+        # neighbour-list form would have had, for information only: outputs x stencil offsets x the fraction of occupied
+        # cells of the input lattice's box)
         no = int(n_out if n_out_launch is None else n_out_launch)
-        timer.end("cconv", dict(pairs=int(no * (n_off / len(parts)) * float(fill)), n_out=no, cin=int(cin), cout=int(cout),
-                                K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False, lattice=True), t0)
+        timer.end("cconv", dict(pairs=0, pairs_equiv=int(no * (n_off / len(parts)) * float(fill)), n_out=no, cin=int(cin),
+                                cout=int(cout), K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False,
+                                lattice=True, kernel="lat_conv_kernel", n_offsets=int(n_off),
+                                volume_bytes=int(inp_volume.numel()) * 4, table_bytes=int(out_table.numel()) * 4), t0)
     return out
 
 
@@ -647,8 +648,11 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         kdims = [int(d) for d in filters.shape[:3]]
         if symmetric:
             kdims[int(sym_axis)] *= 2
+        name = ctypes.create_string_buffer(96)
+        L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96)
         timer.end("cconv", dict(pairs=n_pairs_ref if n_pairs_ref is not None else int(a.n_pairs), n_out=n_out, cin=int(filters.shape[3]), cout=cout,
-                                K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric)), t0)
+                                K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric), kernel=name.value.decode(),
+                                pair_values=bool(a.neighbors_value)), t0)
     return out
 
 
@@ -712,17 +716,10 @@ class GridTooSparse(RuntimeError):
     the caller uses the sort-based device formulation instead."""
 
 
-_GRID_TLS = threading.local()
-
-
-def grid_pos_last_box():
-    """(minp, dims) of the integer box of cells of this thread's last :func:`grid_pos` call."""
-    return _GRID_TLS.last_box
-
-
-def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, return_box=False):
     """Lattice points of ``grid_pos`` (utils/tools/losses.py:136-181) via dmcf_grid_pos_bounds/_count/_write.
-    ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean)."""
+    ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean).
+    ``return_box``: -> (points, (minp, dims) | None): the integer box of cells of THIS call (None for an empty result)."""
     import numpy as np
     L = _lib.lib()
     pos = _dev_f32(pos, "pos", 3)
@@ -736,7 +733,8 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     common = (1 if centralize else 0,)
     _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, common[0], _ptr(cen) if cen is not None else None, int(pad),
                                       float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
-    hdr = ws[0:32].cpu()  # header.minp, dims, cells (host round trip 1 of 2)
+    hdr = ws[0:64].cpu()  # header.minp, dims, cells, (total,) centre (host round trip 1 of 2)
+    center_host = hdr[40:52].view(torch.float32).tolist()
     minp, dims = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
     cells = int(hdr[24:32].view(torch.int64).item())
     if cells < 0:
@@ -751,15 +749,16 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     if total:
         _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
                                          _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
-        _GRID_TLS.last_box = (minp, dims)  # integer box of cells holding every lattice point of this call (per thread:
-        # the virtual ranks of dmcf_amd.parallel are threads)
         if centralize and center is None:
             # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
             # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
             from . import lattice
             # (the entry keeps ``pos`` alive: its address + version identify the family for as long as the entry exists)
             lattice.register(out, ws[40:52].view(torch.float32).clone(), [float(v) for v in vs],
-                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims, keep=pos)
+                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims, keep=pos,
+                             center_host=center_host)
+    if return_box:
+        return out, ((minp, dims) if total else None)
     return out
 
 

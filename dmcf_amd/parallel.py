@@ -63,7 +63,9 @@ class Comm:
 
 
 class TorchDistComm(Comm):
-    """torch.distributed communicator: counts then payload, each one all_to_all_single."""
+    """torch.distributed communicator: counts then payload, each one all_to_all_single.  Backend "nccl" (= RCCL over xGMI)
+    is the production path; with "gloo" (CPU tests, and the two-processes-on-one-GPU test) device tensors are staged
+    through the host, because gloo's all-to-all takes CPU tensors only."""
 
     def __init__(self, group=None):
         import torch.distributed as dist
@@ -71,9 +73,15 @@ class TorchDistComm(Comm):
         self.group = group
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
+        self.stage = dist.get_backend(group) == "gloo"
 
     def all_reduce(self, t, op="sum"):
         ops = {"sum": self.dist.ReduceOp.SUM, "min": self.dist.ReduceOp.MIN, "max": self.dist.ReduceOp.MAX}
+        if self.stage and t.is_cuda:
+            h = t.cpu()
+            self.dist.all_reduce(h, op=ops[op], group=self.group)
+            t.copy_(h)
+            return t
         self.dist.all_reduce(t, op=ops[op], group=self.group)
         return t
 
@@ -85,17 +93,18 @@ class TorchDistComm(Comm):
         trailing = tuple(send[0].shape[1:])
         width = int(np.prod(trailing)) if trailing else 1
         sc = [int(s.shape[0]) for s in send]
+        xdev = torch.device("cpu") if self.stage else dev
         if recv_counts is None:
-            send_counts = torch.tensor(sc, dtype=torch.int64, device=dev)
+            send_counts = torch.tensor(sc, dtype=torch.int64, device=xdev)
             rc_t = torch.empty_like(send_counts)
             dist.all_to_all_single(rc_t, send_counts, group=self.group)
             rc = rc_t.tolist()
         else:
             rc = [int(c) for c in recv_counts]
-        inp = torch.cat([s.reshape(s.shape[0], width) for s in send], dim=0).contiguous()
-        out = torch.empty((sum(rc), width), dtype=inp.dtype, device=dev)
+        inp = torch.cat([s.reshape(s.shape[0], width) for s in send], dim=0).contiguous().to(xdev)
+        out = torch.empty((sum(rc), width), dtype=inp.dtype, device=xdev)
         dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
-        parts = torch.split(out, rc, dim=0)
+        parts = torch.split(out.to(dev), rc, dim=0)
         return [p.reshape((p.shape[0],) + trailing) for p in parts]
 
 
@@ -162,84 +171,212 @@ def run_local_ranks(world, fn):
 # --------------------------------------------------------------------------------------------------
 # decomposition and ghost plans
 # --------------------------------------------------------------------------------------------------
-class SlabDecomposition:
-    """Region of rank r = { x : cuts[r] <= x[axis] < cuts[r+1] }, cuts[0] = -inf, cuts[world] = +inf."""
+class BlockDecomposition:
+    """Axis-aligned blocks (8 ranks = 2x2x2, 4 = 2x2x1, 2 = 2x1x1): ``cuts[k]`` = the increasing
+    inner cut planes along axis k, rank = (ix * ny + iy) * nz + iz.  Region of a rank = the product of its per-axis
+    intervals [cut[i-1], cut[i]) with -inf / +inf at the ends: ownership is a pure function of the position, per axis, so
+    every point -- particle or lattice point -- has exactly one owner."""
+
+    def __init__(self, cuts):
+        self.cuts = [[float(c) for c in ax] for ax in cuts]
+        assert len(self.cuts) == 3
+        for ax in self.cuts:
+            assert all(a < b for a, b in zip(ax, ax[1:])), "cuts must increase"
+        self.grid = [len(ax) + 1 for ax in self.cuts]
+        self.world = self.grid[0] * self.grid[1] * self.grid[2]
+
+    @staticmethod
+    def uniform(lo, hi, grid):
+        return BlockDecomposition([[lo[k] + (hi[k] - lo[k]) * i / grid[k] for i in range(1, grid[k])] for k in range(3)])
+
+    @staticmethod
+    def medians(pos, grid):
+        """Cut planes at particle-count quantiles of a (host) position array, axis by axis (load balance)."""
+        cuts = []
+        for k in range(3):
+            q = [i / grid[k] for i in range(1, grid[k])]
+            cuts.append([float(v) for v in np.quantile(np.asarray(pos)[:, k], q)] if q else [])
+        return BlockDecomposition(cuts)
+
+    def coords(self, r):
+        nx, ny, nz = self.grid
+        return (r // (ny * nz), (r // nz) % ny, r % nz)
+
+    def bounds(self, r):
+        """[(lo, hi)] per axis of rank r's block."""
+        out = []
+        for k, i in enumerate(self.coords(r)):
+            ax = self.cuts[k]
+            out.append((-float("inf") if i == 0 else ax[i - 1], float("inf") if i == len(ax) else ax[i]))
+        return out
+
+    def owner(self, pos):
+        own = torch.zeros(pos.shape[0], dtype=torch.int64, device=pos.device)
+        for k in range(3):
+            if self.grid[k] > 1:
+                b = torch.tensor(self.cuts[k], dtype=pos.dtype, device=pos.device)
+                i = torch.bucketize(pos[:, k].contiguous(), b, right=True)
+            else:
+                i = 0
+            own = own * self.grid[k] + i
+        return own
+
+    def gap2(self, pos, r):
+        """Squared distance of each point to the block of rank r (0 inside)."""
+        d2 = torch.zeros(pos.shape[0], dtype=pos.dtype, device=pos.device)
+        for k, (lo, hi) in enumerate(self.bounds(r)):
+            if lo == -float("inf") and hi == float("inf"):
+                continue
+            x = pos[:, k]
+            g = torch.clamp(torch.maximum(lo - x, x - hi), min=0.0)
+            d2 = d2 + g * g
+        return d2
+
+    def within(self, pos, r, width):
+        """mask of points whose distance to the block of rank r is <= width (points on the upper faces count as outside
+        the half-open block, distance 0: they are within any width)."""
+        return self.gap2(pos, r) <= float(width) * float(width)
+
+    def neighbours(self, r, width):
+        """Ranks whose block is within ``width`` of rank r's block (the only possible ghost peers)."""
+        out = []
+        mine = self.bounds(r)
+        for q in range(self.world):
+            if q == r:
+                continue
+            d2 = 0.0
+            for (alo, ahi), (blo, bhi) in zip(mine, self.bounds(q)):
+                g = max(blo - ahi, alo - bhi, 0.0)
+                d2 += g * g
+            if d2 <= width * width:
+                out.append(q)
+        return out
+
+
+class SlabDecomposition(BlockDecomposition):
+    """Slabs along one axis: the one-axis special case of :class:`BlockDecomposition` (cuts[0] = -inf, cuts[world] = +inf)."""
 
     def __init__(self, axis, inner_cuts):
         self.axis = int(axis)
         self.inner = [float(c) for c in inner_cuts]
-        assert all(a < b for a, b in zip(self.inner, self.inner[1:])), "cuts must increase"
-        self.world = len(self.inner) + 1
+        cuts = [[], [], []]
+        cuts[self.axis] = self.inner
+        super().__init__(cuts)
 
     @staticmethod
     def uniform(axis, lo, hi, world):
         return SlabDecomposition(axis, [lo + (hi - lo) * r / world for r in range(1, world)])
 
-    def bounds(self, r):
-        lo = -float("inf") if r == 0 else self.inner[r - 1]
-        hi = float("inf") if r == self.world - 1 else self.inner[r]
-        return lo, hi
 
-    def owner(self, pos):
-        if self.world == 1:
-            return torch.zeros(pos.shape[0], dtype=torch.int64, device=pos.device)
-        b = torch.tensor(self.inner, dtype=pos.dtype, device=pos.device)
-        return torch.bucketize(pos[:, self.axis].contiguous(), b, right=True)
+def _bounds_tensor(decomp, ranks, device):
+    """float32 [len(ranks), 3, 2]: (lo, hi) per axis of the blocks of ``ranks``."""
+    return torch.tensor([[[lo, hi] for lo, hi in decomp.bounds(r)] for r in ranks], dtype=torch.float32, device=device)
 
-    def within(self, pos, r, width):
-        """mask of points whose distance to the region of rank r is <= width"""
-        lo, hi = self.bounds(r)
-        x = pos[:, self.axis]
-        return (x >= lo - width) & (x < hi + width)
+
+def _gap2(pos, bounds_rows):
+    """Squared distance of pos[i] to the block whose bounds are bounds_rows[i] ([m, 3, 2]); same arithmetic per point as
+    BlockDecomposition.gap2 (sender and receiver must decide identically on bit-identical copies of a position)."""
+    g = torch.clamp(torch.maximum(bounds_rows[:, :, 0] - pos, pos - bounds_rows[:, :, 1]), min=0.0)
+    g = g * g
+    return (g[:, 0] + g[:, 1]) + g[:, 2]
 
 
 class GhostPlan:
-    """Ghost copies of one owned point set for one halo width: built once, reused by every layer."""
+    """Ghost copies of one owned point set for one halo width: built once per step, reused by every layer.
 
-    def __init__(self, comm, decomp, pos_owned, width):
-        self.comm = comm
-        self.decomp = decomp
-        width = float(width) * (1.0 + 1e-5) + 1e-6  # superset slack; the search re-tests distances exactly
-        self.width = width
-        self._in_wide = {}
-        empty = torch.zeros(0, dtype=torch.int64, device=pos_owned.device)
-        self.send_idx = [empty if r == comm.rank else torch.nonzero(decomp.within(pos_owned, r, width)).reshape(-1)
-                         for r in range(comm.world)]
-        recv = comm.all_to_all([pos_owned[i] for i in self.send_idx])
-        self.recv_counts = [int(r.shape[0]) for r in recv]  # the same rows travel for every layer of the step
+    A WIDE plan (``parent`` None) selects, for every rank whose block is within ``width`` of this rank's, the owned points
+    within ``width`` of that block (squared distance to the box), and exchanges their positions once: two host round trips
+    (the selection sizes, the receive counts).  A NARROW plan derives from a wide one of the same point set WITHOUT
+    communication: the sender keeps the rows of the wide send lists that pass the narrower test, the receiver runs the same
+    test on the bit-identical received positions and gets the same rows in the same order."""
+
+    def __init__(self, comm, decomp, pos_owned, width, parent=None):
+        self.comm, self.decomp = comm, decomp
+        self.width = float(width) * (1.0 + 1e-5) + 1e-6  # superset slack; the search re-tests distances exactly
         self.n_owned = pos_owned.shape[0]
-        self.ghost_pos = torch.cat(recv, dim=0) if comm.world > 1 else pos_owned[:0]
-        self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous()
+        dev = pos_owned.device
+        world, rank = comm.world, comm.rank
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        self.send_idx = [empty] * world
+        self.recv_counts = [0] * world
+        self.in_parent = None
+        w2 = self.width * self.width
+        if world == 1:
+            self.ghost_pos = pos_owned[:0]
+        elif parent is None:
+            peers = decomp.neighbours(rank, self.width)
+            if peers and self.n_owned:
+                # candidates: owned points within ``width`` of one of the block's own finite faces
+                near = torch.zeros(self.n_owned, dtype=torch.bool, device=dev)
+                for k, (lo, hi) in enumerate(decomp.bounds(rank)):
+                    x = pos_owned[:, k]
+                    if lo != -float("inf"):
+                        near |= (x - lo) <= self.width
+                    if hi != float("inf"):
+                        near |= (hi - x) <= self.width
+                cand = torch.nonzero(near).reshape(-1)
+                cpos = pos_owned[cand]
+                b = _bounds_tensor(decomp, peers, dev)                      # [P, 3, 2]
+                flags = torch.stack([_gap2(cpos, b[i:i + 1].expand(cpos.shape[0], 3, 2)) <= w2 for i in range(len(peers))])
+                hit = torch.nonzero(flags)                                  # rows ordered by peer, then by point
+                counts = torch.bincount(hit[:, 0], minlength=len(peers)).tolist()
+                rows = cand[hit[:, 1]]
+                off = 0
+                for i, r in enumerate(peers):
+                    self.send_idx[r] = rows[off:off + counts[i]]
+                    off += counts[i]
+            recv = comm.all_to_all([pos_owned[i] for i in self.send_idx])
+            self.recv_counts = [int(r.shape[0]) for r in recv]
+            self.ghost_pos = torch.cat(recv, dim=0)
+        else:
+            assert parent.n_owned == self.n_owned and self.width <= parent.width
+            self.parent = parent
+            # sender side: the rows of the wide lists that are within the narrower width of the peer's block
+            peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
+            if peers:
+                rows = torch.cat([parent.send_idx[r] for r in peers])
+                seg = torch.repeat_interleave(torch.arange(len(peers), device=dev),
+                                              torch.tensor([parent.send_idx[r].shape[0] for r in peers], device=dev))
+                keep = _gap2(pos_owned[rows], _bounds_tensor(decomp, peers, dev)[seg]) <= w2
+                counts = torch.bincount(seg[keep], minlength=len(peers)).tolist()
+                rows = rows[keep]
+                off = 0
+                for i, r in enumerate(peers):
+                    self.send_idx[r] = rows[off:off + counts[i]]
+                    off += counts[i]
+            # receiver side: the same test on the received copies
+            g = parent.ghost_pos
+            if g.shape[0]:
+                src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
+                mine = _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2)
+                keep = _gap2(g, mine) <= w2
+                self.in_parent = torch.nonzero(keep).reshape(-1)
+                self.recv_counts = torch.bincount(src[keep], minlength=world).tolist()
+                self.ghost_pos = g[self.in_parent]
+            else:
+                self.in_parent = empty
+                self.ghost_pos = g
+        self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous() if world > 1 else pos_owned
 
     def extend(self, feats_owned):
-        """[n_owned, C] -> [n_owned + n_ghost, C] (owned rows first, ghosts in the order of ``pos_ext``)."""
+        """[n_owned, C] -> [n_owned + n_ghost, C] (owned rows first, ghosts in the order of ``pos_ext``): one all-to-all-v,
+        no host round trip (the counts are the plan's)."""
         if self.comm.world == 1:
             return feats_owned
         recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx], recv_counts=self.recv_counts)
         return torch.cat([feats_owned] + recv, dim=0).contiguous()
 
-    def index_in(self, wide):
-        """Rows of ``wide``'s ghosts (a plan of the same point set with a larger width) that are this plan's ghosts, in this
-        plan's order: the senders picked their rows with ``decomp.within(pos, this rank, width)`` in ascending row order, and
-        the same test on the same received positions picks the same rows here -- no communication."""
-        idx = self._in_wide.get(id(wide))
-        if idx is None:
-            parts, off = [], 0
-            for cnt in wide.recv_counts:
-                g = wide.ghost_pos[off:off + cnt]
-                parts.append(torch.nonzero(self.decomp.within(g, self.comm.rank, self.width)).reshape(-1) + off)
-                off += cnt
-            idx = torch.cat(parts) if parts else torch.zeros(0, dtype=torch.int64, device=wide.ghost_pos.device)
-            if idx.shape[0] != self.ghost_pos.shape[0] or (os.environ.get("DMCF_SHARD_CHECK") == "1"
-                                                           and not torch.equal(wide.ghost_pos[idx], self.ghost_pos)):
-                raise RuntimeError("ghost plans of one point set are not nested")
-            self._in_wide[id(wide)] = idx
-            self._wide_keep = wide  # id() stays unique while the plan lives
-        return idx
-
     def extend_from(self, wide, wide_ext):
-        """``extend`` without communication, from the same features already extended by the wider plan."""
-        return torch.cat([wide_ext[:self.n_owned], wide_ext[self.n_owned:][self.index_in(wide)]], dim=0)
+        """``extend`` without communication, from the same features already extended by the wider plan this one derives
+        from (directly or through intermediate plans)."""
+        chain, p = [], self
+        while p is not wide:
+            chain.append(p)
+            p = p.parent
+        ghosts = wide_ext[self.n_owned:]
+        for p in reversed(chain):
+            ghosts = ghosts[p.in_parent]
+        return torch.cat([wide_ext[:self.n_owned], ghosts], dim=0)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -249,8 +386,9 @@ class ShardedSimulator:
     """``step(state) -> state`` on the particles this rank owns.
 
     state = dict(pos, vel, acc|None, box, box_normals, gid): owned fluid particles (``gid`` = global particle
-    id, int64, carried through migration), owned boundary particles (static).  The arithmetic per layer is the
-    model's own layers (same weights, same HIP kernels); only *which rows* a rank holds differs."""
+    id, int64, carried through migration), owned boundary particles (static).  The network is the model's OWN
+    ``forward`` (models/hrnet.py, sym_net.py, cconv.py): this class only installs ``model.conv_hook``, through which
+    every ContinuousConv call of the forward pass gets its input rows extended by the ghosts within the layer's radius."""
 
     def __init__(self, model, comm, decomp):
         self.model = model
@@ -258,38 +396,79 @@ class ShardedSimulator:
         self.decomp = decomp
         assert decomp.world == comm.world
         self.exchanged_rows = 0
+        self.host_syncs = 0
+        m = model
+        for key in ("translate", "scale", "grav_eqvar"):
+            if key in m.transformation:
+                # ownership / ghost tests run on transformed positions with cuts given in scene coordinates
+                raise NotImplementedError(f"transformation {key!r} is not wired into the sharded path (the 2-D scenes that "
+                                          "use it do not amortise a halo: SURVEY.md section 8e, last row)")
+        if m.dens_feats or m.pres_feats or m.dens_norm or m.use_pre_adv or m.use_feats:
+            raise NotImplementedError("dens_feats / pres_feats / dens_norm / use_pre_adv / use_feats in the sharded path")
+        if m.voxel_size is None and any(s != 1 for s in m.strides):
+            raise NotImplementedError("FPS based multi-scale (voxel_size None) in the sharded path: farthest point sampling "
+                                      "is sequential over the whole point set")
 
     # -- helpers -----------------------------------------------------------------------------------
     def _plan(self, name, width):
+        """The ghost plan of point set ``name`` for ``width``: derived without communication from the set's widest plan
+        (built when the set is registered, at the largest radius of the network)."""
         key = (name, round(float(width), 9))
         plan = self._plans.get(key)
         if plan is None:
-            plan = GhostPlan(self.comm, self.decomp, self._sets[name], width)
+            wide = self._wide[name]
+            if float(width) * (1.0 + 1e-5) + 1e-6 > wide.width:
+                raise RuntimeError(f"ghost plan of {name!r} asked for width {width} > the step's widest {wide.width}")
+            # derive from the narrowest existing plan that is still wide enough (fewer rows to test)
+            parent = min((p for (n, _), p in self._plans.items() if n == name and p.width >= float(width) * (1.0 + 1e-5) + 1e-6),
+                         key=lambda p: p.width)
+            plan = GhostPlan(self.comm, self.decomp, self._sets[name], width, parent=parent)
+            if os.environ.get("DMCF_SHARD_CHECK") == "1" and self.comm.world > 1:
+                direct = GhostPlan(self.comm, self.decomp, self._sets[name], width)
+                if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
+                        not torch.equal(a, b) for a, b in zip(direct.send_idx, plan.send_idx)):
+                    raise RuntimeError("a derived ghost plan differs from the directly built one")
             self._plans[key] = plan
-            lat = self._lattices.get(name)
-            if lat is not None:
-                box = lat[2]  # the union of all ranks' boxes: owned + ghost points
-                lattice.register_points(plan.pos_ext, lat[0], lat[1], ("sharded", lat[0].data_ptr()), box)
+            self._register_lattice(name, plan)
         return plan
 
-    def _conv(self, layer, feats_owned, inp, out, extent, share=None):
-        """layer(feats, pos[inp] -> pos[out]) with inputs extended by the ghosts within extent/2.
-        ``share`` = dict(width=...) common to all the layers that read the SAME features: the ghost rows travel once, at the
-        largest width any of them needs, and the narrower sets are subsets of those rows (GhostPlan.index_in)."""
-        plan = self._plan(inp, 0.5 * float(extent))
-        if share is None or self.comm.world == 1:
-            feats_ext = plan.extend(feats_owned)
-            self.exchanged_rows += feats_ext.shape[0] - feats_owned.shape[0]
-        else:
-            wide = self._plan(inp, share["width"])
-            if "ext" not in share:
-                share["ext"] = wide.extend(feats_owned)
-                self.exchanged_rows += share["ext"].shape[0] - feats_owned.shape[0]
-            feats_ext = share["ext"] if plan is wide else plan.extend_from(wide, share["ext"])
-        return layer(feats_ext, plan.pos_ext, self._sets[out], extent, None)
+    def _add_set(self, name, pos, width):
+        """Register an owned point set and build its widest ghost plan (the only one that communicates)."""
+        self._sets[name] = pos
+        self._name_of[id(pos)] = name
+        wide = GhostPlan(self.comm, self.decomp, pos, width)
+        self._wide[name] = wide
+        self._plans[(name, round(float(width), 9))] = wide
+        return wide
 
-    def _global_sum(self, t64):
-        return self.comm.all_reduce(t64, "sum")
+    def _register_lattice(self, name, plan):
+        lat = self._lattices.get(name)
+        if lat is not None:
+            lattice.register_points(plan.pos_ext, lat[0], lat[1], ("sharded", lat[0].data_ptr()), lat[2], center_host=lat[3])
+
+    def _conv_hook(self, conv, feats, inp_pos, out_pos, extent, widest_extent=None):
+        """model.conv_hook: conv(feats, inp_pos -> out_pos) with the input rows extended by the ghosts within extent / 2.
+        ``widest_extent``: the largest extent any layer reading the SAME ``feats`` uses -- the ghost rows then travel once,
+        at that width, and the narrower sets are subsets of those rows (GhostPlan.extend_from)."""
+        inp = self._name_of[id(inp_pos)]
+        plan = self._plan(inp, 0.5 * float(extent))
+        n_own = feats.shape[0]
+        if self.comm.world == 1:
+            ext = feats
+        elif widest_extent is None or float(widest_extent) <= float(extent):
+            ext = plan.extend(feats)
+            self.exchanged_rows += ext.shape[0] - n_own
+        else:
+            wide = self._plan(inp, 0.5 * float(widest_extent))
+            hit = self._shared.get(id(feats))
+            if hit is None or hit[0] is not feats or hit[1] is not wide:
+                hit = (feats, wide, wide.extend(feats))
+                self.exchanged_rows += hit[2].shape[0] - n_own
+                if len(self._shared) >= 4:
+                    self._shared.pop(next(iter(self._shared)))
+                self._shared[id(feats)] = hit
+            ext = plan.extend_from(wide, hit[2])
+        return conv(ext, plan.pos_ext, out_pos, extent, None)
 
     # -- one step ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -314,12 +493,9 @@ class ShardedSimulator:
     def _step(self, state):
         m, comm = self.model, self.comm
         dev = state["pos"].device
-        self._plans, self._sets, self._lattices = {}, {}, {}
+        self._plans, self._sets, self._lattices, self._wide, self._name_of, self._shared = {}, {}, {}, {}, {}, {}
         pos0, vel0, acc = state["pos"], state["vel"], state.get("acc")
         box_all, bfeats_all = state["box"], state["box_normals"]
-        if "grav_eqvar" in m.transformation:
-            raise NotImplementedError("grav_eqvar (WBC-SPH) is not wired into the sharded path; 2-D scenes of a few "
-                                      "thousand particles do not amortise a halo (SURVEY.md section 8e, last row)")
         d = m.transform([pos0, vel0, acc, None, box_all, bfeats_all])
         _pos, _vel, acc_t, _, box, bfeats = d
         pos, vel = m.integrate_pos_vel(_pos, _vel, acc_t)
@@ -327,10 +503,10 @@ class ShardedSimulator:
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in m.particle_radii]
         big = 3.0e38
         pt = pos.t().contiguous()  # [3, N]: row reductions (a strided column reduction of [N, 3] is ~0.5 ms each)
-        lo = pt.amin(dim=1) if pos.shape[0] else torch.full((3,), big, device=dev)
-        hi = pt.amax(dim=1) if pos.shape[0] else torch.full((3,), -big, device=dev)
-        lo = comm.all_reduce(lo.clone(), "min") - filter_extent[-1]
-        hi = comm.all_reduce(hi.clone(), "max") + filter_extent[-1]
+        lohi = torch.cat([-(pt.amin(dim=1) if pos.shape[0] else torch.full((3,), big, device=dev)),
+                          pt.amax(dim=1) if pos.shape[0] else torch.full((3,), -big, device=dev)])
+        lohi = comm.all_reduce(lohi, "max")  # one collective for both ends: max(-lo), max(hi)
+        lo, hi = -lohi[:3] - filter_extent[-1], lohi[3:] + filter_extent[-1]
         keep = ((box >= lo) & (box <= hi)).all(dim=1)
         box, bfeats = box[keep], bfeats[keep]
 
@@ -345,64 +521,89 @@ class ShardedSimulator:
         fluid_feats = torch.cat(fluid_feats, dim=-1)
         box_feats = torch.cat(box_feats, dim=-1)
         all_pos = torch.cat([pos, box], dim=0).contiguous()
-        self._sets.update(pos=pos.contiguous(), box=box.contiguous(), s0=all_pos)
+        pos, box = pos.contiguous(), box.contiguous()
         n_fluid = pos.shape[0]
+        m.all_pos = all_pos  # the ASCC head convolves all_pos -> all_pos (models/sym_net.py)
+        m.conv_hook = self._conv_hook
+        try:
+            r_max = 0.5 * filter_extent[-1]
+            multi = any(s != 1 for s in m.strides)
+            margin = 0.0
+            if multi:
+                margin = max(float(np.max(np.asarray(m.voxel_size, dtype=np.float32) * np.float32(s))) for s in m.strides) \
+                    * (1.0 + m.sample_hyst + m.sample_pad + 0.05)
+            wide_w = max(r_max, margin)  # the widest ghost set any layer (or the lattice construction) of the step needs
+            self._add_set("s0", all_pos, wide_w)
+            operands = m.fused_input_operands(fluid_feats, box_feats)
+            if operands is not None:
+                # the two input layers as one block-diagonal convolution over all particles (models/pbf_model.py): one
+                # exchange instead of two
+                in_feats, in_kernel, in_bias = operands
+                fused = self._conv_hook(lambda f, pi, po, ext, _: m.fused_input_conv(in_kernel, in_bias, f, pi, po, ext)[0],
+                                        in_feats, all_pos, all_pos, filter_extent[0])
+                co = m.fluid_convs.filters
+                ans_conv, ans_obs = fused[:, :co].contiguous(), fused[:, co:].contiguous()
+            else:
+                self._add_set("pos", pos, wide_w)
+                self._add_set("box", box, wide_w)
+                ans_conv = self._conv_hook(m.fluid_convs, fluid_feats * m.part_scale, pos, all_pos, filter_extent[0])
+                ans_obs = self._conv_hook(m.obs_convs, box_feats * m.part_scale, box, all_pos, filter_extent[0])
+            ans_dense = m.fluid_dense(fluid_feats)
+            ans_dense = torch.cat([ans_dense, m.obs_dense(box_feats)], dim=0)
+            feats = torch.cat([ans_conv, ans_obs, ans_dense], dim=-1)
 
-        operands = m.fused_input_operands(fluid_feats, box_feats)
-        if operands is not None:
-            # the two input layers as one block-diagonal convolution over all particles (models/pbf_model.py): one ghost
-            # plan and one exchange instead of two of each
-            in_feats, in_kernel, in_bias = operands
-            fused = self._conv(lambda f, pi, po, ext, _: m.fused_input_conv(in_kernel, in_bias, f, pi, po, ext)[0],
-                               in_feats, "s0", "s0", filter_extent[0])
-            co = m.fluid_convs.filters
-            ans_conv, ans_obs = fused[:, :co].contiguous(), fused[:, co:].contiguous()
-        else:
-            ans_conv = self._conv(m.fluid_convs, fluid_feats * m.part_scale, "pos", "s0", filter_extent[0])
-            ans_obs = self._conv(m.obs_convs, box_feats * m.part_scale, "box", "s0", filter_extent[0])
-        ans_dense = m.fluid_dense(fluid_feats)
-        ans_dense = torch.cat([ans_dense, m.obs_dense(box_feats)], dim=0)
-        feats = torch.cat([ans_conv, ans_obs, ans_dense], dim=-1)
+            # multi-scale point sets: the same lattice on every rank (global origin), each rank keeps its region
+            base_name = "s0" if m.use_bnds else "pos"
+            if base_name not in self._sets:
+                self._add_set("pos", pos, wide_w)
+            base = self._sets[base_name]
+            sets = []
+            center = None
+            if m.centralize and multi:
+                acc64 = torch.cat([base.t().contiguous().double().sum(dim=1),
+                                   torch.tensor([float(base.shape[0])], dtype=torch.float64, device=dev)])
+                acc64 = comm.all_reduce(acc64, "sum")
+                center = (acc64[:3] / acc64[3]).to(torch.float32)
+                center_host = center.tolist()
+            for si, stride in enumerate(m.strides):
+                if stride == 1:
+                    sets.append(base)
+                    continue
+                vs = np.asarray(m.voxel_size, dtype=np.float32) * np.float32(stride)
+                cand = self._plan(base_name, float(vs.max()) * (1.0 + m.sample_hyst + m.sample_pad + 0.05)).pos_ext
+                g, gbox = grid_pos(cand, vs, centralize=m.centralize, pad=m.sample_pad, hyst=m.sample_hyst, center=center,
+                                   return_box=True)
+                g = g[self.decomp.owner(g) == comm.rank].contiguous()
+                name = f"s{si}"
+                if center is not None and g.is_cuda:
+                    # all lattices of the step share the agreed centre: the layers between them (and their owned + ghost
+                    # inputs, see _register_lattice) can take the lattice form of ContinuousConv (dmcf_amd/lattice.py).  The
+                    # ghost copies a layer adds to this set come from other ranks' lattices: the union of all ranks' boxes
+                    # (one tiny all-reduce) holds owned and ghost points alike.  Only the INPUT volumes are that large
+                    # (zero-filled, 4 B x Cin per cell); the kernel walks the output box.  A rank without candidates
+                    # contributes nothing to the union.
+                    big_i = 1 << 40
+                    if gbox is not None:
+                        blo, bdims = list(gbox[0]), list(gbox[1])
+                        ext = [v for k in range(3) for v in (-blo[k], blo[k] + bdims[k] - 1)]
+                    else:
+                        ext = [-big_i] * 6
+                    ext = comm.all_reduce(torch.tensor(ext, dtype=torch.int64, device=dev), "max").tolist()
+                    if ext[0] > -big_i:
+                        ulo = [-ext[2 * k] for k in range(3)]
+                        udims = [ext[2 * k + 1] + ext[2 * k] + 1 for k in range(3)]
+                        self._lattices[name] = (center, [float(v) for v in vs], (ulo, udims), center_host)
+                        lattice.register_points(g, center, vs, ("sharded", center.data_ptr()), (ulo, udims),
+                                                center_host=center_host)
+                self._add_set(name, g, wide_w)
+                self._register_lattice(name, self._wide[name])
+                sets.append(g)
 
-        # multi-scale point sets: the same lattice on every rank (global origin), each rank keeps its region
-        base = "s0" if m.use_bnds else "pos"
-        names = []
-        center = None
-        if m.centralize and any(s != 1 for s in m.strides):
-            acc64 = torch.cat([self._sets[base].t().contiguous().double().sum(dim=1),
-                               torch.tensor([float(self._sets[base].shape[0])], dtype=torch.float64, device=dev)])
-            acc64 = self._global_sum(acc64)
-            center = (acc64[:3] / acc64[3]).to(torch.float32)
-        for si, stride in enumerate(m.strides):
-            if stride == 1:
-                names.append(base)
-                continue
-            if m.voxel_size is None:
-                raise NotImplementedError("FPS based multi-scale (voxel_size None) is out of scope")
-            vs = np.asarray(m.voxel_size, dtype=np.float32) * np.float32(stride)
-            margin = float(vs.max()) * (1.0 + m.sample_hyst + m.sample_pad + 0.05)
-            cand = self._plan(base, margin).pos_ext
-            g = grid_pos(cand, vs, centralize=m.centralize, pad=m.sample_pad, hyst=m.sample_hyst, center=center)
-            g = g[self.decomp.owner(g) == comm.rank].contiguous()
-            name = f"s{si}"
-            self._sets[name] = g
-            names.append(name)
-            if center is not None and g.is_cuda:
-                # all lattices of the step share the agreed centre: the layers between them (and their owned + ghost
-                # inputs, see _plan) can take the lattice form of ContinuousConv (dmcf_amd/lattice.py)
-                box = ops.grid_pos_last_box()  # of the candidates' lattice: holds the owned points
-                # the ghost copies a layer adds to this set come from other ranks' lattices: the union of all ranks' boxes
-                # (one tiny all-reduce, here where the queue is empty anyway) holds owned and ghost points alike.  Only the
-                # INPUT volumes are that large (zero-filled, 4 B x Cin per cell); the kernel walks the output box.
-                lo, dims = list(box[0]), list(box[1])
-                ext = torch.tensor([v for k in range(3) for v in (-lo[k], lo[k] + dims[k] - 1)], dtype=torch.int64, device=dev)
-                ext = comm.all_reduce(ext, "max").tolist()
-                for k in range(3):
-                    lo[k], dims[k] = -ext[2 * k], ext[2 * k + 1] + ext[2 * k] + 1
-                self._lattices[name] = (center, [float(v) for v in vs], (lo, dims))
-                lattice.register_points(g, center, vs, ("sharded", center.data_ptr()), (lo, dims))
-
-        out = self._forward(names, feats, filter_extent, n_fluid)
+            if not m.use_bnds and type(m).__name__ == "SymNet":
+                raise NotImplementedError("use_bnds=False with the ASCC head in the sharded path")
+            out = m.run_forward([sets, feats, None, None], None, training=False)
+        finally:
+            m.conv_hook = None
 
         # postprocess (pbf_model.py:440-489) on the owned fluid particles
         if out.shape[-1] == 1:
@@ -416,92 +617,36 @@ class ShardedSimulator:
         new_pos, new_vel = m.compute_new_pos_vel(_pos, _vel, pos2, vel2, pos_correction)
         new_pos, new_vel = m.inv_transform([new_pos, new_vel], None)
 
-        # migration: every particle goes to the owner of its new position
+        # migration: every particle goes to the owner of its new position: one stable sort by owner, one host round trip
+        # (the send counts), two all-to-all-v (payload; global ids with the receive counts the first one produced)
         own = self.decomp.owner(new_pos)
         gid = state["gid"]
         payload = torch.cat([new_pos, new_vel] + ([acc] if acc is not None else []), dim=1)
-        send_idx = [torch.nonzero(own == r).reshape(-1) for r in range(comm.world)]
-        recv = comm.all_to_all([payload[i] for i in send_idx])
-        recv_gid = comm.all_to_all([gid[i] for i in send_idx])
-        payload = torch.cat(recv, dim=0)
+        if comm.world > 1:
+            order = torch.argsort(own, stable=True)
+            counts = torch.bincount(own, minlength=comm.world).tolist()
+            recv = comm.all_to_all(list(torch.split(payload[order], counts, dim=0)))
+            rc = [int(r.shape[0]) for r in recv]
+            payload = torch.cat(recv, dim=0)
+            gid = torch.cat(comm.all_to_all(list(torch.split(gid[order], counts, dim=0)), recv_counts=rc), dim=0)
         new_state = dict(pos=payload[:, 0:3].contiguous(), vel=payload[:, 3:6].contiguous(),
                          acc=payload[:, 6:9].contiguous() if acc is not None else None,
-                         box=box_all, box_normals=bfeats_all, gid=torch.cat(recv_gid, dim=0))
+                         box=box_all, box_normals=bfeats_all, gid=gid)
         return new_state
 
-    def _forward(self, names, feats, filter_extent, n_fluid):
-        m = self.model
-        kind = type(m).__name__
-        if kind in ("SymNet", "HRNet"):
-            if not m.use_bnds:
-                feats = feats[:n_fluid]
-            ans_convs = [[feats]]
-            for layer in range(len(m.convs)):
-                ans = []
-                relu_in = [torch.relu(t) for t in ans_convs[-1]]  # once per layer (see models/hrnet.py)
-                # every output scale reads the same relu(x_{inp_scale}): one ghost exchange per input scale and layer, at
-                # the largest radius of the layer, instead of one per (scale, inp_scale)
-                n_scales = len(m.convs[layer])
-                shares = [dict(width=0.5 * float(max(filter_extent[max(i, s)] for s in range(n_scales))))
-                          for i in range(len(relu_in))]
-                for scale in range(n_scales):
-                    if len(m.convs[layer][scale]) != 1:
-                        raise NotImplementedError("k > 0 sub-layers (hrnet.py:120-131) are unused by shipped configs")
-                    importance = m.part_scale if scale == 0 else 1.0
-                    inp = []
-                    for inp_scale in range(len(ans_convs[-1])):
-                        f = relu_in[inp_scale]
-                        ext = filter_extent[max(inp_scale, scale)]
-                        conv_in = f if importance == 1.0 else f * importance
-                        ans_conv = self._conv(m.convs[layer][scale][0][inp_scale], conv_in, names[inp_scale],
-                                              names[scale], ext, share=shares[inp_scale] if conv_in is f else None)
-                        if scale == inp_scale:
-                            ans_conv = ans_conv + m.denses[layer][scale][0][inp_scale](f)
-                            if ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:
-                                ans_conv = ans_conv + ans_convs[-1][scale]
-                        inp.append(ans_conv)
-                    if m.add_merge:
-                        merged = inp[0]
-                        for t in inp[1:]:
-                            merged = merged + t
-                        ans.append(merged)
-                    else:
-                        ans.append(torch.cat(inp, dim=-1))
-                ans_convs.append(ans)
-            out = m.out_activation(ans_convs[-1][0])
-            if kind == "SymNet":
-                if not m.use_bnds:
-                    raise NotImplementedError("use_bnds=False with the ASCC head in the sharded path")
-                ext = float(np.float32(m.particle_radii[0]) * np.float32(2))
-                for conv in m.sym_convs:
-                    out = torch.relu(out)
-                    conv_in = out if m.part_scale == 1.0 else out * m.part_scale
-                    out = self._conv(conv, conv_in, "s0", "s0", ext)
-                out = m.act(out)
-            return out
-        if kind == "CConv":
-            feats = feats[:n_fluid]
-            ext = float(np.float32(m.particle_radii[0]) * np.float32(2))
-            ans_convs = [feats]
-            for conv, dense in zip(m.convs, m.denses):
-                f = torch.relu(ans_convs[-1])
-                ans_conv = self._conv(conv, f, "pos", "pos", ext)
-                ans_dense = dense(f)
-                ans = ans_conv + ans_dense
-                if ans_dense.shape[-1] == ans_convs[-1].shape[-1]:
-                    ans = ans + ans_convs[-1]
-                ans_convs.append(ans)
-            return m.out_activation(ans_convs[-1])
-        raise NotImplementedError(kind)
 
-
-def shard_scene(scene, decomp, rank, device):
-    """Owned part of a scene dict(pos, vel, box, box_normals[, acc]) for ``rank`` (numpy in, tensors out)."""
+def shard_scene(scene, decomp, rank, device, presharded=False):
+    """Owned part of a scene dict(pos, vel, box, box_normals[, acc]) for ``rank`` (numpy in, tensors out).
+    ``presharded``: the arrays already are this rank's part (each rank generated only its own block); ownership is still
+    checked against the decomposition -- a particle the generator put on the wrong side of a cut would otherwise be
+    silently duplicated or lost."""
     def t(a):
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device)
     pos, box = t(scene["pos"]), t(scene["box"])
     own_p = decomp.owner(pos) == rank
     own_b = decomp.owner(box) == rank
+    if presharded and not (bool(own_p.all()) and bool(own_b.all())):
+        raise ValueError(f"rank {rank}: pre-sharded scene holds points outside its block")
     state = dict(pos=pos[own_p].contiguous(), vel=t(scene["vel"])[own_p].contiguous(),
                  acc=t(scene["acc"])[own_p].contiguous() if scene.get("acc") is not None else None,
                  box=box[own_b].contiguous(), box_normals=t(scene["box_normals"])[own_b].contiguous(),

@@ -376,7 +376,7 @@ class ContinuousConv(torch.nn.Module):
                 window, neighbors_value = "explicit", user_neighbors_importance
         else:
             lat = self._lattice_form(inp_features, inp_positions, out_positions, inp_importance,
-                                     fixed_radius_search_hash_table)
+                                     fixed_radius_search_hash_table, extent)
             if lat is not None:
                 # both point sets are grid_pos lattices of this step: no search, no per-pair geometry
                 # (dmcf_lattice_conv_forward; DMCF_LATTICE_CONV=0 keeps the neighbour-list form)
@@ -476,7 +476,7 @@ class ContinuousConv(torch.nn.Module):
             out_features = self.activation(out_features)
         return out_features
 
-    def _lattice_form(self, inp_features, inp_positions, out_positions, inp_importance, hash_table):
+    def _lattice_form(self, inp_features, inp_positions, out_positions, inp_importance, hash_table, extent):
         """The LatticePair for this call if dmcf_lattice_conv_forward applies: both position tensors registered grid_pos
         lattices of one family (dmcf_amd/lattice.py), a named window, none of the options that form needs a pair list for."""
         from .. import lattice
@@ -485,7 +485,9 @@ class ContinuousConv(torch.nn.Module):
                 or self.radius_search_metric != "L2" or not inp_features.is_cuda
                 or self.in_channels not in (4, 8) or self.filters > 32):
             return None
-        return lattice.pair(inp_positions, out_positions)
+        # (None too when the scene reaches so far from the origin that the nominal offsets d * voxel of this form and the
+        # reference's differences of rounded positions part by more than the parity bar allows: lattice.MAX_X_OVER_EXTENT)
+        return lattice.pair(inp_positions, out_positions, extent)
 
     call = forward
 

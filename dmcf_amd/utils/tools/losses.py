@@ -68,11 +68,13 @@ def _unique_first_occurrence(idx):
     return uniq[torch.argsort(first)]
 
 
-def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, return_box=False):
     """losses.py:136-181: lattice corners of the voxels (edge ``voxel_size``) that contain a particle,
     with +-``hyst`` hysteresis; axes with voxel_size < 1e-5 collapse (2-D / 1-D scenes).
     ``center`` (extension used by the sharded path): the lattice origin to use instead of this call's own
-    mean when ``centralize`` -- every rank passes the global mean so all ranks build the same lattice."""
+    mean when ``centralize`` -- every rank passes the global mean so all ranks build the same lattice.
+    ``return_box``: -> (points, (minp, dims) | None), the integer box of cells (x, y, z) that holds every returned point;
+    None when it is not known on the host (empty result, or the sort-based fallback ran)."""
     # voxel_size is kept on the host (list / numpy float32) so that the axis collapse test does not
     # force a device round trip; values are float32 like the reference's tf.constant
     vs_host = np.asarray(voxel_size.detach().cpu() if isinstance(voxel_size, torch.Tensor) else voxel_size,
@@ -80,7 +82,8 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     if pos.is_cuda:  # product path: the HIP kernels (csrc/grid.hip); below is the host-side form of the same
         from ... import ops
         try:
-            return ops.grid_pos(pos, vs_host, centralize=centralize, pad=pad, hyst=hyst, center=center)
+            out, box = ops.grid_pos(pos, vs_host, centralize=centralize, pad=pad, hyst=hyst, center=center, return_box=True)
+            return (out, box) if return_box else out
         except ops.GridTooSparse:
             pass  # bounding box too large for a dense cell table: sort-based form, still on the device
     voxel_size = torch.from_numpy(vs_host.copy()).to(pos.device)
@@ -112,8 +115,10 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None):
     gpos = torch.stack([idx % maxp64[0], idx // maxp64[0] % maxp64[1], idx // (maxp64[0] * maxp64[1])], dim=-1) \
         + minp.to(torch.int64)  # :172-174
     if centralize:
-        return gpos.to(torch.float32) * voxel_size + center  # :177
-    return gpos.to(torch.float32) * voxel_size + voxel_size / 2  # :179
+        out = gpos.to(torch.float32) * voxel_size + center  # :177
+    else:
+        out = gpos.to(torch.float32) * voxel_size + voxel_size / 2  # :179
+    return (out, None) if return_box else out
 
 
 def get_dilated_pos(pos, strides, voxel_size=None, centralize=False, pad=0, hyst=0.1):

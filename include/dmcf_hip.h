@@ -193,6 +193,10 @@ size_t dmcf_cconv_geometry_bytes(int64_t n_pairs);
 int dmcf_cconv_geometry(const dmcf_cconv_args* args, void* geometry, size_t geometry_bytes, dmcf_stream_t stream);
 int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t workspace_bytes,
                        dmcf_stream_t stream);
+/* Diagnostics: the name of the device kernel dmcf_cconv_forward dispatches these arguments to (the dispatch looks at the
+ * layer -- filter shape, channel counts, flags -- never at the neighbour list), as rocprofv3 prints it without the
+ * namespace, e.g. "cconv_z3_kernel<1>".  bench.py groups its per-launch HIP-event timings by it. */
+int dmcf_cconv_kernel_name(const dmcf_cconv_args* args, char* name, size_t name_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * ml3d.ops.continuous_conv (utils/convolutions.py:414-431) between two point sets on ALIGNED REGULAR LATTICES -- the

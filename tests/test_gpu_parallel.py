@@ -42,20 +42,8 @@ def _assemble(parts, n):
     return pos, vel
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_virtual_ranks_match_single_rank_on_gpu(world, monkeypatch):
-    from dmcf_amd import parallel
-    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")  # narrow ghost sets must be the expected rows of the widest one
-    from tools import scenes
-    assert torch.cuda.is_available()
-    dev = torch.device("cuda:0")
-    parts = [scenes.box_slab_scene(10, 4, r, seed=7) for r in range(4)]  # 40 x 10 x 10 box, 4000 fluid particles
-    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
-    n = scene["pos"].shape[0]
-    ref = parallel.run_local_ranks(1, lambda c: _run_rank(c, parallel.SlabDecomposition(0, []), scene, 3, dev))
+def _check(res, ref, n):
     pos1, vel1 = _assemble(ref, n)
-    decomp = parallel.SlabDecomposition.uniform(0, 0.0, 40 * 0.05, world)
-    res = parallel.run_local_ranks(world, lambda c: _run_rank(c, decomp, scene, 3, dev))
     assert all(p["exchanged"] > 0 for p in res)
     pos, vel = _assemble(res, n)
     assert np.abs(pos - pos1).max() <= 1e-5 * np.abs(pos1).max()
@@ -64,3 +52,94 @@ def test_virtual_ranks_match_single_rank_on_gpu(world, monkeypatch):
     total = sum(p["out_sum"] for p in res)
     scale = sum(p["out_abs"] for p in res)
     assert np.all(np.abs(total) <= 2e-5 * scale)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_virtual_ranks_match_single_rank_on_gpu(world, monkeypatch):
+    from dmcf_amd import parallel
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")  # every derived ghost plan is compared with a directly built one
+    from tools import scenes
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    parts = [scenes.box_slab_scene(10, 4, r, seed=7) for r in range(4)]  # 40 x 10 x 10 box, 4000 fluid particles
+    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    n = scene["pos"].shape[0]
+    ref = parallel.run_local_ranks(1, lambda c: _run_rank(c, parallel.SlabDecomposition(0, []), scene, 3, dev))
+    decomp = parallel.SlabDecomposition.uniform(0, 0.0, 40 * 0.05, world)
+    res = parallel.run_local_ranks(world, lambda c: _run_rank(c, decomp, scene, 3, dev))
+    _check(res, ref, n)
+
+
+@pytest.mark.parametrize("grid", [[2, 2, 1], [2, 2, 2]])
+def test_virtual_block_ranks_match_single_rank_on_gpu(grid, monkeypatch):
+    """SURVEY.md section 8e's partitioning: 2x2x1 and 2x2x2 blocks of one 24^3 box (the pieces bench.py --gpus 4 / 8 gives
+    its ranks, at side 12), real kernels, against one rank; face, edge and corner ghost peers; ASCC sum over ranks = 0."""
+    from dmcf_amd import parallel
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")
+    from tools import scenes
+    dev = torch.device("cuda:0")
+    world = grid[0] * grid[1] * grid[2]
+    side = 12
+    parts = [scenes.box_block_scene(side, grid, r, seed=3) for r in range(world)]
+    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    n = scene["pos"].shape[0]
+    ref = parallel.run_local_ranks(1, lambda c: _run_rank(c, parallel.SlabDecomposition(0, []), scene, 3, dev))
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * side * 0.05 for g in grid], grid)
+    # every rank's generated piece lies inside its block (what bench.py relies on with presharded=True)
+    for r in range(world):
+        parallel.shard_scene(parts[r], decomp, r, dev, presharded=True)
+    res = parallel.run_local_ranks(world, lambda c: _run_rank(c, decomp, scene, 3, dev))
+    _check(res, ref, n)
+    ghosts = sum(p["exchanged"] for p in res)
+    print(f"grid {grid}: {ghosts} ghost feature rows exchanged in 3 steps for {n} particles")
+
+
+def _proc_worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from dmcf_amd import parallel
+    from tools import scenes
+    dev = torch.device("cuda:0")  # both processes share the one GPU of the box; the collectives run over gloo
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        grid = [2, 1, 1]
+        scene = scenes.box_block_scene(12, grid, rank, seed=3)
+        decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * 12 * 0.05 for g in grid], grid)
+        comm = parallel.TorchDistComm()
+        from dmcf_amd import models
+        from dmcf_amd.utils import tf_checkpoint as tc
+        from tools import configs
+        cfg = configs.LIQUID3D
+        model = getattr(models, cfg["name"])(**cfg)
+        tc.load_into_model(model, dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz"))), device=dev)
+        sim = parallel.ShardedSimulator(model, comm, decomp)
+        state = parallel.shard_scene(scene, decomp, rank, dev, presharded=True)
+        state["gid"] = state["gid"] + rank * scene["pos"].shape[0]
+        for _ in range(3):
+            state = sim.step(state)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), gid=state["gid"].cpu().numpy(), pos=state["pos"].cpu().numpy(),
+                 vel=state["vel"].cpu().numpy(), exchanged=sim.exchanged_rows)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_one_gpu_match_single_rank(tmp_path):
+    """Two REAL processes (torch.distributed, TorchDistComm, the bench's pre-sharded scene pieces) with the real kernels:
+    they share the box's single GPU and talk over gloo -- everything of the N > 1 bench path except RCCL itself."""
+    import torch.multiprocessing as mp
+    from dmcf_amd import parallel
+    from tools import scenes
+    dev = torch.device("cuda:0")
+    port = 29500 + os.getpid() % 2000
+    mp.spawn(_proc_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [dict(np.load(os.path.join(tmp_path, f"rank{r}.npz"))) for r in range(2)]
+    parts = [scenes.box_block_scene(12, [2, 1, 1], r, seed=3) for r in range(2)]
+    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    n = scene["pos"].shape[0]
+    ref = parallel.run_local_ranks(1, lambda c: _run_rank(c, parallel.SlabDecomposition(0, []), scene, 3, dev))
+    pos1, vel1 = _assemble(ref, n)
+    assert all(int(p["exchanged"]) > 0 for p in res)
+    pos, vel = _assemble(res, n)
+    assert np.abs(pos - pos1).max() <= 1e-5 * np.abs(pos1).max()
+    assert np.abs(vel - vel1).max() <= 2e-4 * np.abs(vel1).max()

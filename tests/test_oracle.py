@@ -251,3 +251,27 @@ def test_against_open3d_golden(oracle):
             ref = g[f"cconv_{name}_{mapping}"]
             assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(oracle.reduce_subarrays_sum(g["rss_values"], g["rss_row_splits"]), g["rss_out"], rtol=1e-6)
+
+
+def test_column_fixture_from_the_reference_generator(oracle):
+    """tests/golden/column_test.npz holds the two test scenes of configs/column/hrnet.yml as the REFERENCE's own generator
+    (datasets/column_gen.py, seed 44) produces them: their structure, and three oracle steps of the config's HRNet on them."""
+    import os
+    from oracle.model_ref import ModelRef
+    from tools import configs, scenes
+    fix = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "column_test.npz"))
+    assert fix["s0_pos"].shape == (200, 1, 3) and fix["s1_pos"].shape == (200, 5, 3) and fix["s1_box"].shape == (2, 3)
+    for s in (0, 1):
+        pos, vel, grav = fix[f"s{s}_pos"], fix[f"s{s}_vel"], fix[f"s{s}_grav"]
+        assert np.all(pos[..., 0] == 0) and np.all(pos[..., 2] == 0)          # a 1-D column along y
+        assert np.allclose(grav, [0.0, -10.0, 0.0])                            # gravity / res * res
+        assert pos[0, :, 1].min() > fix[f"s{s}_box"][:, 1].max()               # released above the two boundary points
+        assert pos[50, :, 1].mean() < pos[0, :, 1].mean()                      # ... and falling
+        cfg = dict(configs.COLUMN_HRNET)
+        ref = ModelRef(cfg, scenes.random_weights(cfg, seed=2))
+        state = [pos[0], vel[0], np.broadcast_to(grav[0], pos[0].shape).astype(np.float32).copy(), None,
+                 fix[f"s{s}_box"], fix[f"s{s}_box_normals"]]
+        for _ in range(3):
+            p, v = ref.step(state)
+            assert np.isfinite(p).all() and p.shape == pos[0].shape
+            state = [p, v] + state[2:]

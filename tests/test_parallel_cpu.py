@@ -73,6 +73,62 @@ def test_slab_ownership_and_halo():
     assert d.within(pos, 1, 0.6).tolist() == [False, True, True, True, True, False, False]
 
 
+def test_block_ownership_halo_and_neighbours():
+    from dmcf_amd.parallel import BlockDecomposition
+    d = BlockDecomposition.uniform([0.0, 0.0, 0.0], [2.0, 2.0, 2.0], [2, 2, 2])
+    assert d.world == 8 and d.coords(5) == (1, 0, 1)
+    pos = torch.tensor([[0.5, 0.5, 0.5], [1.5, 0.5, 0.5], [0.5, 1.5, 0.5], [0.5, 0.5, 1.5], [1.5, 1.5, 1.5], [-9.0, 9.0, 1.0]])
+    assert d.owner(pos).tolist() == [0, 4, 2, 1, 7, 3]  # every point has exactly one owner, the outer blocks are unbounded
+    # distance to block 7 = [1, inf)^3 is the Euclidean distance to the box: the corner point needs sqrt(3) * 0.5
+    assert d.within(pos[:1], 7, 0.86).tolist() == [False] and d.within(pos[:1], 7, 0.87).tolist() == [True]
+    assert d.within(pos[1:2], 7, 0.70).tolist() == [False] and d.within(pos[1:2], 7, 0.71).tolist() == [True]
+    assert sorted(d.neighbours(0, 0.1)) == [1, 2, 3, 4, 5, 6, 7]
+    s = BlockDecomposition.uniform([0.0, 0.0, 0.0], [4.0, 1.0, 1.0], [4, 1, 1])
+    assert s.neighbours(0, 0.5) == [1] and s.neighbours(1, 0.99) == [0, 2] and s.neighbours(1, 1.0) == [0, 2, 3]
+    m = BlockDecomposition.medians(np.random.default_rng(0).uniform(0, 1, size=(1000, 3)), [2, 2, 1])
+    own = m.owner(torch.from_numpy(np.random.default_rng(0).uniform(0, 1, size=(1000, 3)).astype(np.float32)))
+    assert torch.bincount(own, minlength=4).min() >= 200
+
+
+@pytest.mark.parametrize("grid", [[2, 2, 1], [2, 2, 2]])
+def test_virtual_block_ranks_equal_single_rank(monkeypatch, grid):
+    """2x2x1 and 2x2x2 blocks (virtual ranks) against 1 rank: face, edge and corner peers, derived narrow ghost plans."""
+    import shims
+    from dmcf_amd import parallel
+    shims.install(monkeypatch)
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")  # every derived ghost plan is compared with a directly built one
+    scene = _scene()
+    n = scene["pos"].shape[0]
+    ref = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2))
+    pos1, vel1 = _assemble(ref, n)
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [0.6, 0.3, 0.3], grid)
+    parts = parallel.run_local_ranks(decomp.world, lambda comm: _run_rank(comm, decomp, scene, 2))
+    assert all(p["exchanged"] > 0 for p in parts)
+    pos, vel = _assemble(parts, n)
+    _close(pos, pos1)
+    _close(vel, vel1, 2e-4)
+
+
+def test_bench_self_launch_dry_run():
+    """`python bench.py --gpus 2` (no external launcher) starts two ranks and prints ONE line; gloo, no GPU."""
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--dry-run"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry_run"] is True and rec["block_grid"] == [2, 1, 1]
+    import bench
+    assert bench.block_grid(8) == [2, 2, 2] and bench.block_grid(4) == [2, 2, 1] and bench.block_grid(1) == [1, 1, 1]
+    cmd = bench.launcher_command(["--gpus", "4"], 4, port=1234)
+    assert "--nproc-per-node=4" in cmd and "127.0.0.1" in cmd and cmd[-2:] == ["--gpus", "4"]
+
+
 def test_virtual_ranks_equal_single_rank(monkeypatch):
     """2 and 3 virtual ranks (threads, LocalComm) against 1 rank, two steps, oracle backend."""
     import shims

@@ -121,24 +121,27 @@ def random_weights(model_cfg, seed=0, lo=-0.05, hi=0.05, fluid_channels=None):
     return w
 
 
-def box_slab_scene(side, world, rank, h=0.05, jitter=0.1, vel_std=0.1, shell_layers=2, seed=0):
-    """The part of a (side*world) x side x side box (cubes stacked along x, closed 2-layer shell around the
-    whole box) that lies in the slab of ``rank``: x index in [side*rank, side*(rank+1)), plus the end caps for
-    the first / last rank.  Used by ``bench.py --gpus N`` (weak scaling: side^3 fluid particles per GPU);
-    each rank generates only its own part."""
+def box_block_scene(side, grid, rank, h=0.05, jitter=0.1, vel_std=0.1, shell_layers=2, seed=0):
+    """The part of ONE (grid[0]*side) x (grid[1]*side) x (grid[2]*side) box (closed 2-layer shell around the whole box)
+    that lies in the block of ``rank`` = (ix * grid[1] + iy) * grid[2] + iz (the rank order of
+    dmcf_amd.parallel.BlockDecomposition): side^3 fluid particles with lattice indices [side*i, side*(i+1)) per axis,
+    plus the pieces of the shell outside the block's outer faces.  Used by ``bench.py --gpus N`` (weak scaling: side^3
+    fluid particles per GPU); each rank generates only its own part."""
     L = shell_layers
+    grid = [int(g) for g in grid]
+    c = (rank // (grid[1] * grid[2]), (rank // grid[2]) % grid[1], rank % grid[2])
     rng = np.random.default_rng(seed + 2 * rank)
-    ix = np.arange(side * rank, side * (rank + 1))
-    ax = (np.arange(side, dtype=np.float64) + 0.5) * h
-    pos = np.stack(np.meshgrid((ix + 0.5) * h, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    axes = [(np.arange(side * c[k], side * (c[k] + 1)) + 0.5) * h for k in range(3)]
+    pos = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
     pos = pos + rng.uniform(-jitter * h, jitter * h, size=pos.shape)
     vel = np.random.default_rng(seed + 2 * rank + 1).normal(0.0, vel_std, size=pos.shape)
-    lo = side * rank - (L if rank == 0 else 0)
-    hi = side * (rank + 1) + (L if rank == world - 1 else 0)
-    gx = np.arange(lo, hi)
-    gyz = np.arange(-L, side + L)
-    gi = np.stack(np.meshgrid(gx, gyz, gyz, indexing="ij"), -1).reshape(-1, 3)
-    total = np.array([side * world, side, side])
+    g = []
+    for k in range(3):
+        lo = side * c[k] - (L if c[k] == 0 else 0)
+        hi = side * (c[k] + 1) + (L if c[k] == grid[k] - 1 else 0)
+        g.append(np.arange(lo, hi))
+    gi = np.stack(np.meshgrid(*g, indexing="ij"), -1).reshape(-1, 3)
+    total = np.array([side * grid[0], side * grid[1], side * grid[2]])
     outside_lo = gi < 0
     outside_hi = gi >= total
     is_shell = (outside_lo | outside_hi).any(axis=1)
@@ -147,3 +150,8 @@ def box_slab_scene(side, world, rank, h=0.05, jitter=0.1, vel_std=0.1, shell_lay
     normals /= np.linalg.norm(normals, axis=1, keepdims=True)
     return dict(pos=pos.astype(np.float32), vel=vel.astype(np.float32), box=box.astype(np.float32),
                 box_normals=normals.astype(np.float32))
+
+
+def box_slab_scene(side, world, rank, **kw):
+    """:func:`box_block_scene` for cubes stacked along x."""
+    return box_block_scene(side, [world, 1, 1], rank, **kw)
