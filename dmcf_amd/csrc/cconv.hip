@@ -588,6 +588,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.geo4 = nullptr;
     p.geob = nullptr;
     p.n_out = a->n_out;
+    p.n_inp = a->n_inp;
     p.pair_cap = a->n_pairs;
     p.inv_extent = 1.0f / a->extent;
     const float radius = 0.5f * a->extent;

@@ -31,7 +31,7 @@ constexpr int ZTM = kZWaves;      // output points per workgroup = rows of the B
 constexpr int kZRow = 1024;       // floats per B row: k' = (z * 4 + y) * 64 + channel * 4 + x (16 channels)
 constexpr int kZPairs = 61;       // pairs per batch
 constexpr int kZSlots = 64;       // + padding to even class sizes
-constexpr int kZRec = 12;         // floats per slot record: X, -, -, -, wy[z'][y] (8)
+constexpr int kZRec = 12;         // floats per slot record: hat(X - x) (4), w[z'] * hat(Y - y) (8)
 constexpr int kZWaveF = kZSlots * kZRec + kZSlots;  // per wave outside the B tile: records + indices
 constexpr int kZMaxNT = 4;
 constexpr int kZNoPair = 3;
@@ -46,6 +46,18 @@ __device__ __forceinline__ void zfence() {
 }
 
 __device__ __forceinline__ float zhat(float d) { return __builtin_amdgcn_fmed3f(1.0f - fabsf(d), 0.0f, 1.0f); }
+
+typedef uint32_t u32x4z __attribute__((ext_vector_type(4)));
+constexpr uint32_t kZOob = 0xffffffffu;  // a byte offset no buffer holds: the load returns zeros
+
+// 32-bit LDS byte address of a pointer into the dynamic shared array
+__device__ __forceinline__ uint32_t zlds(const void* q) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)q;
+}
+// ds_read_b32 at an IMMEDIATE offset from a lane address: the splat loop then has no address arithmetic (the compiler's
+// form of the same loop advanced six pointers per four matrix instructions: 21 VALU operations, 12 of them useful)
+// ("memory": the compiler must not move the staging stores of the batch around these reads)
+#define ZREAD(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:" #off : "=v"(dst) : "v"(addr) : "memory")
 
 template <int NTT>
 __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParams p) {
@@ -63,14 +75,16 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
 
     // splat roles (A / B operands of 32x32x2): row m = lane & 31 = (z', y, x), pair k = lane >> 5, channel lane & 31
     const int hk = lane >> 5, jn = lane & 31;
-    const float xm = (float)(lane & 3);
     const int zc = (lane >> 4) & 1;
     // feature load roles: lane -> (slot lane >> 3 of a group of 8, channels 4 (lane & 7) ..)
     const int fr = lane >> 3, fc4 = lane & 7;
     const bool fch_ok = 4 * fc4 < cin;
-    const float* zero4 = p.Wp + (size_t)p.nchunks * 64 * (4 * p.NT * 16 * 4);
-    const char* featB = (const char*)(p.inp_feat + (fch_ok ? 4 * fc4 : 0));
+    // feature rows through a buffer resource: the address of a row is ONE 24-bit multiply (the slot's byte offset is formed
+    // when its index is published), and a padding slot / a channel block past cin is an out-of-range offset that the
+    // hardware answers with zeros -- no 64-bit address arithmetic, no selects, no block of zeros to point at
     const uint32_t rowB = (uint32_t)cin * 4u;
+    const uint32_t cbyte = fch_ok ? 16u * (uint32_t)fc4 : kZOob;
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)p.inp_feat, 0, (int)((uint32_t)p.n_inp * rowB), 0x00020000);
     // contraction roles
     const int mi = lane & 15, mg = lane >> 4;
 
@@ -96,55 +110,44 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     oy = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oy)));
     oz = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oz)));
     const int NB = (nt + kZPairs - 1) / kZPairs;
-    const int32_t* idx_row = p.idx + rb;
-    const float* nval_row = p.nval ? p.nval + rb : nullptr;
+    // the row as a buffer of nt entries: entries past its end (and the lanes past a batch's 61 pairs) read as index 0
+    const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)(p.idx + rb), 0, nt * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.nval ? p.nval + rb : p.inp_pos), 0,
+                                                                         p.nval ? nt * 4 : 0, 0x00020000);
 
     f32x16 t0, t1, t2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) t0[r] = t1[r] = t2[r] = 0.0f;
 
-    auto where = [&](int t, int& o) -> bool {
-        o = kZPairs * t + lane;
-        return t < NB && lane < kZPairs && o < nt;
-    };
+    auto valid = [&](int t) -> bool { return lane < kZPairs && kZPairs * t + lane < nt; };
     auto ld_idx = [&](int t, int& j, float& nv) {
-        int o;
-        j = 0;
-        nv = 0.0f;
-        if (where(t, o)) {
-            j = idx_row[(uint32_t)o];
-            if (nval_row) nv = nval_row[(uint32_t)o];
-        }
+        const uint32_t off = lane < kZPairs ? (uint32_t)(kZPairs * t + lane) * 4u : kZOob;
+        j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, off, 0, 0);
+        nv = p.nval ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rV, off, 0, 0)) : 0.0f;
     };
-    auto ld_pos = [&](int t, int j, float& x, float& y, float& z) {
-        int o;
-        x = y = z = 0.0f;
-        if (where(t, o)) {
-            const float* q = (const float*)((const char*)p.inp_pos + (size_t)((uint32_t)j * 12u));  // n_inp * 12 < 2^32: launch check
-            x = q[0];
-            y = q[1];
-            z = q[2];
-        }
+    // (lanes without a pair hold index 0: a valid row, unused.  A scalar base + 32-bit lane offset; the 96-bit buffer load
+    // builtin of this compiler loses two of its three components here)
+    auto ld_pos = [&](int j, float& x, float& y, float& z) {
+        const float* q = (const float*)((const char*)p.inp_pos + (size_t)__umul24((uint32_t)j, 12u));
+        x = q[0];
+        y = q[1];
+        z = q[2];
     };
     auto geom = [&](int t, int j, float nv, float x, float y, float z, int& cls) -> f32x4 {
-        f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
-        cls = kZNoPair;
-        int o;
-        if (where(t, o)) {
-            x -= ox;
-            y -= oy;
-            z -= oz;
-            float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-            if (p.inp_imp) a *= p.inp_imp[j];
-            filter_coords<false>(x, y, z, p);
-            c.x = fminf(3.0f, fmaxf(0.0f, x));
-            c.y = fminf(3.0f, fmaxf(0.0f, y));
-            z = fminf(3.0f, fmaxf(0.0f, z));
-            const float zf = fminf(floorf(z), 2.0f), fz = z - zf;
-            cls = (int)zf;
-            c.z = a * (1.0f - fz);
-            c.w = a * fz;
-        }
+        f32x4 c;
+        x -= ox;
+        y -= oy;
+        z -= oz;
+        float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+        if (p.inp_imp) a *= p.inp_imp[j];
+        filter_coords<false>(x, y, z, p);
+        c.x = fminf(3.0f, fmaxf(0.0f, x));
+        c.y = fminf(3.0f, fmaxf(0.0f, y));
+        z = fminf(3.0f, fmaxf(0.0f, z));
+        const float zf = fminf(floorf(z), 2.0f), fz = z - zf;
+        cls = valid(t) ? (int)zf : kZNoPair;
+        c.z = a * (1.0f - fz);
+        c.w = a * fz;
         return c;
     };
     // Ordered batch: plane class c occupies slots [cb[c], cb[c + 1]), an even number; the lanes of a class keep their order.
@@ -167,79 +170,94 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         o.cb[3] = base;
         return o;
     };
+    uint32_t* Jof = (uint32_t*)Jst;  // byte offset of the slot's feature row, kZOob: padding
     auto push_index = [&](int j, int cls, int pos) {
-        Jst[lane] = -1;
+        Jof[lane] = kZOob;
         zfence();
-        if (cls != kZNoPair) Jst[pos] = j;
+        if (cls != kZNoPair) Jof[pos] = __umul24((uint32_t)j, rowB);
     };
-    // record of a slot: X and the eight products w[z'] * hat(Y - y) -- formed here once per pair (lane = pair), so that the
-    // splat's A operand is one subtract, one clamp and one multiply per instruction
+    // record of a slot: the four hat(X - x) and the eight products w[z'] * hat(Y - y) -- formed here once per pair (lane =
+    // pair), so that the splat's A operand is ONE multiply per matrix instruction
     auto push_rec = [&](const f32x4& c, int cls, int pos) {
         float* r = Rec + kZRec * lane;
-        r[0] = 0.0f;
-        *(f32x4*)(r + 4) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0
+        *(f32x4*)(r) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0
+        *(f32x4*)(r + 4) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         *(f32x4*)(r + 8) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         zfence();
         if (cls != kZNoPair) {
+            const f32x4 hx = {zhat(c.x), zhat(c.x - 1.0f), zhat(c.x - 2.0f), zhat(c.x - 3.0f)};
             const f32x4 hy = {zhat(c.y), zhat(c.y - 1.0f), zhat(c.y - 2.0f), zhat(c.y - 3.0f)};
             r = Rec + kZRec * pos;
-            r[0] = c.x;
+            *(f32x4*)(r) = hx;
             *(f32x4*)(r + 4) = c.z * hy;
             *(f32x4*)(r + 8) = c.w * hy;
         }
     };
-    // feature rows of half h of the ordered batch: four groups of 8 slots, lane = (slot, 4 channels); padding slots and
-    // channels past cin read a block of zeros behind the packed filter (unconditional loads)
+    // feature rows of half h of the ordered batch: four groups of 8 slots, lane = (slot, 4 channels)
     auto f_issue = [&](int h, f32x4 (&f)[4]) {
-        int jj[4];
+        uint32_t jo[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) jj[k] = Jst[32 * h + 8 * k + fr];
+        for (int k = 0; k < 4; ++k) jo[k] = Jof[32 * h + 8 * k + fr];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const char* src = featB + (uint64_t)(uint32_t)jj[k] * rowB;
-            f[k] = *(const f32x4*)((jj[k] >= 0 && fch_ok) ? src : (const char*)zero4);
-        }
+        for (int k = 0; k < 4; ++k)
+            f[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rF, __builtin_elementwise_add_sat(jo[k], cbyte), 0, 0));
     };
     auto f_publish = [&](const f32x4 (&f)[4]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) *(f32x4*)(Fst + (8 * k + fr) * 32 + 4 * fc4) = f[k];
     };
-    // groups [g0, g1) of half h, all of one plane class, into that class's tile
-    const float* prx = Rec + kZRec * hk;
-    const float* prw = Rec + kZRec * hk + 4 + 4 * zc + ((lane >> 2) & 3);
-    const float* prf = Fst + 32 * hk + jn;
+    // groups [g0, g1) of half h, all of one plane class, into that class's tile.  LDS byte addresses of this lane's operands
+    // of group 0: hat(X - x) of slot hk, the product w[z'] hat(Y - y) of its row, the feature of channel jn
+    const uint32_t a_hx = zlds(Rec + kZRec * hk + (lane & 3));
+    const uint32_t a_wy = zlds(Rec + kZRec * hk + 4 + 4 * zc + ((lane >> 2) & 3));
+    const uint32_t a_f = zlds(Fst + 32 * hk + jn);
     auto run = [&](f32x16& tl, int g0, int g1, int h) {
-        const float* qx = prx + 2 * kZRec * g0;
-        const float* qw = prw + 2 * kZRec * g0;
-        const float* qf = prf - 32 * 32 * h + 64 * g0;
         int n = g1 - g0;
-        // four groups at a time: twelve reads at immediate offsets, then three VALU operations per matrix instruction
+        if (n <= 0) return;
+        uint32_t qx = a_hx + (uint32_t)(8 * kZRec) * (uint32_t)g0;   // 2 slots x kZRec floats x 4 bytes per group
+        uint32_t qw = a_wy + (uint32_t)(8 * kZRec) * (uint32_t)g0;
+        uint32_t qf = a_f + 256u * (uint32_t)(g0 - 16 * h);
+        // four groups at a time: twelve reads at immediate offsets, one multiply per matrix instruction
         for (; n >= 4; n -= 4) {
-            float x[4], w[4], b[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                x[u] = qx[2 * kZRec * u];
-                w[u] = qw[2 * kZRec * u];
-                b[u] = qf[64 * u];
-            }
-            float a[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) a[u] = w[u] * zhat(x[u] - xm);
+            float x0, x1, x2, x3, w0, w1, w2, w3, b0, b1, b2, b3;
+            ZREAD(x0, qx, 0);
+            ZREAD(w0, qw, 0);
+            ZREAD(b0, qf, 0);
+            ZREAD(x1, qx, 96);
+            ZREAD(w1, qw, 96);
+            ZREAD(b1, qf, 256);
+            ZREAD(x2, qx, 192);
+            ZREAD(w2, qw, 192);
+            ZREAD(b2, qf, 512);
+            ZREAD(x3, qx, 288);
+            ZREAD(w3, qw, 288);
+            ZREAD(b3, qf, 768);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(b0), "+v"(b1),
+                           "+v"(b2), "+v"(b3));
+            const float a0 = w0 * x0, a1 = w1 * x1, a2 = w2 * x2, a3 = w3 * x3;
             // the four dependent matrix instructions back to back: an instruction of this wave between two of them costs
             // ~40 clocks of the matrix pipe (MI355X_MICROARCH.md)
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u], tl, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, tl, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, tl, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, tl, 0, 0, 0);
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, tl, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            qx += 8 * kZRec;
-            qw += 8 * kZRec;
-            qf += 256;
+            qx += 4u * 8u * kZRec;
+            qw += 4u * 8u * kZRec;
+            qf += 1024u;
         }
         for (; n > 0; --n) {
-            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(qw[0] * zhat(qx[0] - xm), qf[0], tl, 0, 0, 0);
-            qx += 2 * kZRec;
-            qw += 2 * kZRec;
-            qf += 64;
+            float x0, w0, b0;
+            ZREAD(x0, qx, 0);
+            ZREAD(w0, qw, 0);
+            ZREAD(b0, qf, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(w0), "+v"(b0));
+            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(w0 * x0, b0, tl, 0, 0, 0);
+            qx += 8u * kZRec;
+            qw += 8u * kZRec;
+            qf += 256u;
         }
     };
     auto splat = [&](int h, const Order& o) {
@@ -256,7 +274,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         float nvA, nvB, px, py, pz;
         ld_idx(0, jA, nvA);
         ld_idx(1, jB, nvB);
-        ld_pos(0, jA, px, py, pz);
+        ld_pos(jA, px, py, pz);
         const f32x4 first = geom(0, jA, nvA, px, py, pz, cl);
         Order oc = order(cl);
         f32x4 ff[4];
@@ -266,7 +284,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         f_issue(0, ff);
         jA = jB;
         nvA = nvB;
-        ld_pos(1, jA, px, py, pz);
+        ld_pos(jA, px, py, pz);
         for (int t = 0; t < NB; ++t) {
             // here: (jA, nvA, px, py, pz) = batch t + 1, ff = the features of half 0 of batch t
             const bool two = oc.cb[3] > 32;
@@ -284,7 +302,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
             if (two) f_publish(ff);
             jA = jB;
             nvA = nvB;
-            ld_pos(t + 2, jA, px, py, pz);
+            ld_pos(jA, px, py, pz);
             if (t + 1 < NB) f_issue(0, ff);
             if (two) {
                 zfence();
@@ -384,7 +402,8 @@ bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
     if ((cin & 3) || cin > 32 || cout > 16 * kZMaxNT) return false;
     if ((uintptr_t)a->inp_features & 15) return false;
-    if (a->n_inp > 0x15000000) return false;  // 32-bit byte offsets into the positions
+    // 24-bit multiplies form the byte offsets of feature and position rows; the buffers must stay below 2 GB
+    if (a->n_inp >= (1 << 24) || a->n_inp * (int64_t)cin * 4 >= ((int64_t)1 << 31)) return false;
     if (e) return true;
     return cin > 16;
 }

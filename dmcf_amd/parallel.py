@@ -446,6 +446,14 @@ class ShardedSimulator:
         if lat is not None:
             lattice.register_points(plan.pos_ext, lat[0], lat[1], ("sharded", lat[0].data_ptr()), lat[2], center_host=lat[3])
 
+    def _lattice_margin(self, stride):
+        """Halo of particles a rank needs to build every lattice point of ``grid_pos`` (losses.py:136-181) it owns: a point
+        is a corner (+- pad) of a voxel holding a particle, with +- hyst hysteresis, i.e. within (1 + hyst + pad) voxels of
+        the particle PER AXIS -- the ghost test measures the Euclidean distance to the block, hence the sqrt(3)."""
+        m = self.model
+        vs = np.asarray(m.voxel_size, dtype=np.float32) * np.float32(stride)
+        return float(vs.max()) * (1.0 + m.sample_hyst + m.sample_pad + 0.05) * 3.0 ** 0.5
+
     def _conv_hook(self, conv, feats, inp_pos, out_pos, extent, widest_extent=None):
         """model.conv_hook: conv(feats, inp_pos -> out_pos) with the input rows extended by the ghosts within extent / 2.
         ``widest_extent``: the largest extent any layer reading the SAME ``feats`` uses -- the ghost rows then travel once,
@@ -530,8 +538,7 @@ class ShardedSimulator:
             multi = any(s != 1 for s in m.strides)
             margin = 0.0
             if multi:
-                margin = max(float(np.max(np.asarray(m.voxel_size, dtype=np.float32) * np.float32(s))) for s in m.strides) \
-                    * (1.0 + m.sample_hyst + m.sample_pad + 0.05)
+                margin = max(self._lattice_margin(s) for s in m.strides)
             wide_w = max(r_max, margin)  # the widest ghost set any layer (or the lattice construction) of the step needs
             self._add_set("s0", all_pos, wide_w)
             operands = m.fused_input_operands(fluid_feats, box_feats)
@@ -570,7 +577,7 @@ class ShardedSimulator:
                     sets.append(base)
                     continue
                 vs = np.asarray(m.voxel_size, dtype=np.float32) * np.float32(stride)
-                cand = self._plan(base_name, float(vs.max()) * (1.0 + m.sample_hyst + m.sample_pad + 0.05)).pos_ext
+                cand = self._plan(base_name, self._lattice_margin(stride)).pos_ext
                 g, gbox = grid_pos(cand, vs, centralize=m.centralize, pad=m.sample_pad, hyst=m.sample_hyst, center=center,
                                    return_box=True)
                 g = g[self.decomp.owner(g) == comm.rank].contiguous()

@@ -171,8 +171,8 @@ def continuous_conv(filters, out_positions, extents, inp_positions, inp_features
     dims = np.asarray(filters.shape, dtype=np.int32)
     out_positions = _f32(out_positions).reshape(-1, 3)
     inp_positions = _f32(inp_positions).reshape(-1, 3)
-    inp_features = _f32(inp_features).reshape(inp_positions.shape[0], -1)
-    assert inp_features.shape[1] == dims[3]
+    inp_features = _f32(inp_features).reshape(inp_positions.shape[0], int(dims[3]))  # (an empty input set is legal: every
+    # boundary particle cropped away, pbf_model.py:330-336 -- all rows are empty and the result is zero)
     extent = float(np.float32(np.asarray(extents).reshape(-1)[0]))
     idx = np.ascontiguousarray(neighbors_index, dtype=np.int32)
     rs = np.ascontiguousarray(neighbors_row_splits, dtype=np.int64)

@@ -25,13 +25,16 @@ def main():
     g = torch.Generator(device=dev).manual_seed(0)
     cases = [("L3  24->8  s0->s1 R0.2", s0, s1, 0.2, 24, 8, (4, 4, 4), "poly6", False),
              ("L14 32->32 s0->s0 R0.1", s0, s0, 0.1, 32, 32, (4, 4, 4), "poly6", False),
+             ("L2  24->16 s0->s0 R0.1", s0, s0, 0.1, 24, 16, (4, 4, 4), "poly6", False),
+             ("L5  16->32 s0->s0 R0.1", s0, s0, 0.1, 16, 32, (4, 4, 4), "poly6", False),
+             ("IN   8->16 s0->s0 R0.1", s0, s0, 0.1, 8, 16, (4, 4, 4), "poly6", False),
              ("L8  16->16 s0->s1 R0.2", s0, s1, 0.2, 16, 16, (4, 4, 4), "poly6", False),
              ("L6   8->32 s1->s0 R0.2", s1, s0, 0.2, 8, 32, (4, 4, 4), "poly6", False),
              ("L7   4->32 s1->s0 R0.2", s1, s0, 0.2, 4, 32, (4, 4, 4), "poly6", False),
              ("L4  24->4  s0->s2 R0.4", s0, grid_pos(s0, np.float32([0.1] * 3), centralize=True), 0.4, 24, 4, (4, 4, 4), "poly6", False),
              ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
     for name, inp, out, R, cin, cout, ks, win, sym in cases:
-        if os.environ.get('ONLY') and not name.startswith(os.environ['ONLY']): continue
+        if os.environ.get('ONLY') and not any(name.startswith(o) for o in os.environ['ONLY'].split(',')): continue
         nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=True)
         feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
         W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5

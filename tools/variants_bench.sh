@@ -1,7 +1,7 @@
 #!/bin/bash
-# Diagnostic: time the L8 micro-benchmark case with each library variant under variants/ (built by hand).
+# Diagnostic: time micro-benchmark cases with each library variant under variants/ (built by hand); the last one stays installed.
 for f in variants/*.so; do
   cp $f dmcf_amd/libdmcf_hip.so
   echo "== $f"
-  DMCF_CCONV_KERNEL=${KERNEL:-blk} timeout 300 python tools/microbench.py 2>&1 | grep "^L8\|^L6\|rror"
+  timeout 600 python tools/microbench.py 2>&1 | grep "^L\|^ASCC\|^IN\|rror"
 done
