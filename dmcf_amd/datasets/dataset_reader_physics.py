@@ -121,6 +121,37 @@ class Dataset:
         return self.data[idx] if self.data is not None else read_scene(self.files[idx])
 
 
+class DatasetGroup:
+    """datasets/dataset_reader_physics.py:85-142, the part the test split needs: ``dataset_path`` holds the scene files
+    (``*.msgpack.zst``) of the split, in ``<path>/test`` if that directory exists, else in ``<path>`` itself.  ``data``:
+    scenes already in memory (a list of per-scene frame lists, e.g. a committed fixture).  The training-side generators
+    (``type: column | free_fall`` without a dataset_path: the reference's own 1-D SPH solver, column_gen.py) are host code
+    outside the per-step hot path and are not rebuilt here: pass ``data`` or a ``dataset_path``."""
+
+    def __init__(self, train=None, valid=None, test=None, split="train", regen=False, data=None, **dataset_cfg):
+        self.name = dataset_cfg.pop("name", "dataset")
+        self.train = self.valid = self.test = None
+        if data is not None:
+            self.test = self.valid = Dataset(data=data)
+            return
+        if "dataset_path" not in dataset_cfg or dataset_cfg["dataset_path"] is None:
+            raise NotImplementedError(
+                f"dataset type {dataset_cfg.get('type', 'tank')!r} is generated by the reference's training-side solver "
+                "(datasets/column_gen.py / free_fall_gen.py), which is outside the hot path: pass --dataset_path with "
+                "scene files, or DatasetGroup(data=...)")
+        path = dataset_cfg.pop("dataset_path")
+        if split == "train":
+            raise NotImplementedError("training is out of scope of the MI355X hot path (SURVEY.md section 2 row 16)")
+        if split != "valid":  # :132-142
+            sub = os.path.join(path, "test")
+            self.test = Dataset(dataset_path=sub if os.path.exists(sub) else path)
+            if split == "test":
+                self.valid = self.test
+        else:
+            sub = os.path.join(path, "valid")
+            self.valid = Dataset(dataset_path=sub if os.path.exists(sub) else path)
+
+
 def align_vector(v0, v1):
     """Rotation taking v1 to v0 (:35-49), float32 like the reference's numpy code."""
     v0 = np.asarray(v0, dtype=np.float32)

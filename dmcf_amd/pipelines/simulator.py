@@ -9,6 +9,7 @@ Training / validation / HDF5 writing are out of scope of the hot path.  The numb
 between steps (run_sample.py:173-177 adds inflow), so nothing here assumes a fixed N.
 """
 import logging
+import os
 import time
 
 import numpy as np
@@ -34,6 +35,12 @@ class Simulator:
         if self.device.type != "cuda":
             raise RuntimeError("the DMCF hot path runs on the GPU only (no CPU fallback)")
         self.timing = []
+        self.repeated_steps = 0  # steps repeated with exact buffer sizes after a NeighborCapacityExceeded
+        # base_pipeline.py:46-63: <main_log_dir | output_dir>/<Model>_<dataset>_<version>
+        tag = "_".join([type(model).__name__, dataset.name if dataset is not None and hasattr(dataset, "name") else "",
+                        str(kwargs.get("version", ""))])
+        self.cfg.logs_dir = os.path.join(main_log_dir, tag)
+        self.cfg.out_dir = os.path.join(kwargs.get("output_dir", "./output"), tag)
 
     def _to_device(self, x):
         if x is None:
@@ -52,6 +59,7 @@ class Simulator:
                     pos, vel = self.model(inputs[bi], training=False)
             except ops.NeighborCapacityExceeded:
                 # a neighbour list grew by more than the slack since the previous step: repeat with exact sizes
+                self.repeated_steps += 1
                 with neighbor_cache(estimate=False):
                     pos, vel = self.model(inputs[bi], training=False)
             results.append([pos, vel] + list(inputs[bi][2:]))
@@ -87,3 +95,60 @@ class Simulator:
         if timing:
             log.info("Average runtime: %.05f" % (np.mean(timing) / len(inputs)))
         return results
+
+    def load_ckpt(self, ckpt_path):
+        """base_pipeline.py:155-187 for inference: read a TensorFlow tensor-bundle checkpoint (``<dir>/ckpt`` prefix, or
+        the newest ``ckpt-<n>`` in a directory) into the model; returns the epoch (0 without a checkpoint: the model then
+        runs on its initialisers, as the reference does)."""
+        from ..utils import tf_checkpoint as tc
+        if not ckpt_path:
+            log.info("No checkpoint")
+            return 0
+        prefix = ckpt_path
+        if os.path.isdir(ckpt_path):
+            import glob
+            import re
+            idx = sorted(glob.glob(os.path.join(ckpt_path, "*.index")),
+                         key=lambda f: [int(x) for x in re.findall(r"\d+", os.path.basename(f))] or [0])
+            if not idx:
+                log.info("No checkpoint")
+                return 0
+            prefix = idx[-1][:-len(".index")]
+        log.info("Loading checkpoint %s", prefix)
+        tc.load_into_model(self.model, tc.load_checkpoint(prefix), device=self.device)
+        m = __import__("re").findall(r"(\d+)$", os.path.basename(prefix))
+        return int(m[0]) if m else 0
+
+    def run_test(self, epoch=None):
+        """simulator.py:111-165: roll out every scene of the test split over its full length and write
+        ``<out_dir>/visual/<scene>/<epoch>.hdf5`` with the datasets pred / gt / bnd (``.npz`` with the same content when
+        h5py is not installed).  Returns the list of output paths."""
+        from ..datasets import get_rollout, write_results, write_results_npz
+        cfg = self.cfg
+        gen = dict(cfg.get("data_generator") or {})
+        test_kw = dict(gen.pop("test", None) or {})
+        for k in ("train", "valid"):
+            gen.pop(k, None)
+        test_data = get_rollout(self.dataset.test, **gen, **test_kw)
+        if epoch is None:
+            epoch = self.load_ckpt(self.model.cfg.get("ckpt_path"))
+        log.info("Started testing")
+        results = self.run_rollout(test_data, test_data[0]["pos"].shape[0])
+        paths = []
+        for i in range(len(results)):
+            data = test_data[i]
+            pos = np.stack([r[0].cpu().numpy() for r in results[i]])
+            out_dir = os.path.join(cfg.out_dir, "visual", "%04d" % i)
+            os.makedirs(out_dir, exist_ok=True)
+            output = [(pos, {"name": "pred", "type": "PARTICLE"}), (data["pos"], {"name": "gt", "type": "PARTICLE"}),
+                      (data["box"][0], {"name": "bnd", "type": "PARTICLE"})]
+            path = os.path.join(out_dir, "%04d.hdf5" % epoch)
+            try:
+                write_results(path, self.model.name, output)
+            except ImportError:
+                path = path[:-5] + ".npz"
+                write_results_npz(path, self.model.name, output)
+            paths.append(path)
+        if cfg.get("test_compute_metric", False):
+            raise NotImplementedError("test_compute_metric (run_valid: Chamfer / EMD metrics) is out of scope of the hot path")
+        return paths

@@ -378,6 +378,50 @@ def test_canyon_sample_with_inflow(dev):
                     None, data[4], data[5]]
 
 
+def test_run_pipeline_test_split_on_canyon_frames(dev, tmp_path):
+    """run_pipeline.py --split test (run_pipeline.py:80-154 -> Simulator.run_test, simulator.py:111-165): YAML -> model ->
+    checkpoint -> get_rollout -> run_rollout -> write_results, on the frames of the reference's canyon scene."""
+    import yaml
+    from dmcf_amd import run_pipeline
+    from dmcf_amd.datasets import read_scene
+    from dmcf_amd.pipelines import Simulator
+    from tools import configs
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    cfg = dict(dataset=dict(name="CConvData3D"),
+               model=dict(configs.LIQUID3D, ckpt_path=None),
+               pipeline=dict(name="Simulator", version="v0", main_log_dir=str(tmp_path / "logs"), output_dir=str(tmp_path / "out"),
+                             data_generator=dict(scale=[1.0, 1.0, 1.0], train=dict(stride=1), valid=dict(stride=1),
+                                                 test=dict(stride=1, time_start=0, time_end=50))))
+    yml = tmp_path / "liquid3d.yml"
+    yml.write_text(yaml.safe_dump(cfg))
+    args, extra = run_pipeline.parse_args(["-c", str(yml), "--split", "test", "--dataset_path", GOLDEN, "--pipeline.version", "v7"])
+    pipe = run_pipeline.build(args, extra)
+    assert isinstance(pipe, Simulator) and pipe.cfg.out_dir.endswith("SymNet_CConvData3D_v7")
+    from dmcf_amd.utils import tf_checkpoint as tc
+    tc.load_into_model(pipe.model, w, device=dev)  # (the checkpoint blob itself is not shipped to the GPU box)
+    paths = pipe.run_test(epoch=3)
+    assert len(paths) == 1 and os.path.basename(paths[0]).startswith("0003.")
+    frames = read_scene(os.path.join(GOLDEN, "canyon_crop.msgpack.zst"))
+    if paths[0].endswith(".npz"):
+        out = np.load(paths[0])
+        pred, gt, bnd = out["SymNet/pred"], out["SymNet/gt"], out["SymNet/bnd"]
+        assert str(out["SymNet/pred.type"]) == "PARTICLE"
+    else:
+        import h5py
+        with h5py.File(paths[0]) as f:
+            pred, gt, bnd = f["SymNet/pred"][:], f["SymNet/gt"][:], f["SymNet/bnd"][:]
+    assert pred.shape == (3, frames[0]["pos"].shape[0], 3) and gt.shape == pred.shape and bnd.shape == frames[0]["box"].shape
+    np.testing.assert_array_equal(pred[0], frames[0]["pos"])
+    np.testing.assert_array_equal(gt[2], frames[2]["pos"])
+    # the rollout is the Simulator's: step 1 equals one run_inference on frame 0
+    sim = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+    grav = t(np.broadcast_to(frames[0]["grav"], frames[0]["pos"].shape)) if frames[0].get("grav") is not None else None
+    one = sim.step([[t(frames[0]["pos"]), t(frames[0]["vel"]), grav, None, t(frames[0]["box"]), t(frames[0]["box_normals"])]])[0]
+    np.testing.assert_array_equal(pred[1], one[0].cpu().numpy())
+    assert np.isfinite(pred).all()
+
+
 def test_fps_multiscale_2d(dev):
     """voxel_size: None: farthest-point-sampled scales (losses.py:274-282) and HRNet's cross-scale Dense branch
     (hrnet.py:100-113) on the WaterRamps architecture."""

@@ -184,3 +184,31 @@ def test_fps_multiscale_host_logic(oracle, monkeypatch):
     assert np.abs(pos.numpy() - pos_ref).max() <= 1e-6 * np.abs(pos_ref).max()
     assert np.abs(model.pos_correction.numpy() - ref.pos_correction).max() <= 1e-4 * np.abs(ref.pos_correction).max()
     assert [len(i) for i in ref.fps_idx[1:]] == [len(model.all_pos) // 2, len(model.all_pos) // 4]
+
+
+def test_run_pipeline_arguments_and_dataset_group(tmp_path):
+    """run_pipeline.py:12-52 (flags + --section.key overrides) and DatasetGroup (dataset_reader_physics.py:85-142) without
+    a GPU: the test split resolves <path>/test or <path>; generators and the train split raise."""
+    import yaml
+    from dmcf_amd import run_pipeline
+    from dmcf_amd.datasets import DatasetGroup, read_scene
+    from dmcf_amd.utils.config import Config
+    from tools import configs
+    cfg = dict(dataset=dict(name="D"), model=dict(configs.LIQUID3D), pipeline=dict(name="Simulator", version="v0"))
+    yml = tmp_path / "c.yml"
+    yml.write_text(yaml.safe_dump(cfg))
+    args, extra = run_pipeline.parse_args(["-c", str(yml), "--split", "test", "--dataset_path", GOLDEN, "--model.timestep", "0.01",
+                                           "--ckpt_path", "/x/ckpt"])
+    assert extra == {"model.timestep": "0.01"} and args.split == "test"
+    d, p, m = Config.merge_cfg_file(Config.load_from_file(str(yml)), args, extra)
+    assert m["timestep"] == 0.01 and m["ckpt_path"] == "/x/ckpt" and d["dataset_path"] == GOLDEN and p["split"] == "test"
+    g = DatasetGroup(**d, split="test")
+    assert len(g.test) == 1 and g.valid is g.test and len(g.test[0]) == 3  # the canyon crop: one scene file, three frames
+    g2 = DatasetGroup(name="x", data=[read_scene(os.path.join(GOLDEN, "canyon_crop.msgpack.zst"))])
+    assert len(g2.test) == 1
+    with pytest.raises(NotImplementedError):
+        DatasetGroup(name="x", type="column", split="test")
+    with pytest.raises(NotImplementedError):
+        DatasetGroup(name="x", dataset_path=GOLDEN, split="train")
+    with pytest.raises(NotImplementedError):
+        run_pipeline.main(["-c", str(yml), "--split", "train"])

@@ -41,6 +41,29 @@ def box_scene(side, h=0.05, jitter=0.1, vel_std=0.1, shell_layers=2, seed=0, dim
                 box_normals=normals.astype(np.float32))
 
 
+def dam_break_scene(block=(50, 40, 50), tank=(100, 60, 50), h=0.05, jitter=0.1, shell_layers=2, seed=0):
+    """BASELINE.json config 4 ("Liquid3d 3-D, ~100k particles"): a dam-break block of 50 x 40 x 50 = 100,000 fluid particles
+    (lattice spacing h, jitter U(-jitter h, jitter h), default_rng(seed), at rest) standing in one corner of an OPEN tank of
+    ``tank`` lattice cells -- floor and four walls of ``shell_layers`` boundary layers with inward normals, no lid; y is up
+    (gravity (0, -9.81, 0) comes from the model).  Returns dict(pos, vel, box, box_normals) float32."""
+    rng = np.random.default_rng(seed)
+    axes = [(np.arange(n, dtype=np.float64) + 0.5) * h for n in block]
+    pos = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
+    pos = pos + rng.uniform(-jitter * h, jitter * h, size=pos.shape)
+    L = shell_layers
+    g = [np.arange(-L, tank[0] + L), np.arange(-L, tank[1]), np.arange(-L, tank[2] + L)]  # no cells above the rim
+    gi = np.stack(np.meshgrid(*g, indexing="ij"), -1).reshape(-1, 3)
+    lo = gi < 0
+    hi = gi >= np.asarray(tank)
+    hi[:, 1] = False
+    shell = (lo | hi).any(axis=1)
+    box = (gi[shell] + 0.5) * h
+    normals = lo[shell].astype(np.float64) - hi[shell].astype(np.float64)
+    normals /= np.linalg.norm(normals, axis=1, keepdims=True)
+    return dict(pos=pos.astype(np.float32), vel=np.zeros_like(pos, dtype=np.float32), box=box.astype(np.float32),
+                box_normals=normals.astype(np.float32))
+
+
 def model_inputs(scene, device=None, grav=None):
     """[pos, vel, acc|None, feats|None, box, box_normals] as the Simulator feeds the model
     (pipelines/simulator.py:83-90).  numpy arrays, or torch tensors on ``device``."""
