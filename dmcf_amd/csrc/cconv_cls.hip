@@ -87,7 +87,11 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
     // contraction roles
     const int mi = lane & 15, mg = lane >> 4;
     const uint32_t gs_lds = cls_lds_addr(Gs), fst_lds = cls_lds_addr(Fst);
-    const float* zero4 = p.Wp + (size_t)p.nchunks * 64 * (4 * p.NT * 16 * 4);
+    // feature rows through a buffer resource (as in cconv_z3.hip): a slot's byte offset is one 24-bit multiply, formed when
+    // its index is published; padding slots and channel blocks past cin are out-of-range offsets, answered with zeros
+    constexpr uint32_t kOob = 0xffffffffu;
+    const uint32_t rowB = (uint32_t)cin * 4u;
+    const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)p.inp_feat, 0, (int)((uint32_t)p.n_inp * rowB), 0x00020000);
 
     f32x4 acc[NTT];
 #pragma unroll
@@ -133,54 +137,56 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
 #pragma unroll
         for (int c = 0; c < 9; ++c) tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-        // batch t of the stream -> is this lane's pair valid, and where is it
-        auto where = [&](int t, int& pp, int64_t& at) -> bool {
-            pp = t >= nbA ? 1 : 0;
-            const int o = 64 * (t - (pp ? nbA : 0)) + lane;
-            at = (pp ? rbs[1] : rbs[0]) + o;
-            return t < NB && o < (pp ? nts[1] : nts[0]);
+        // ONE buffer over both rows of the wave (they are 8 rows apart in the list): offsets past a row's end are replaced by
+        // an out-of-range one and read as index 0 (a valid point, unused)
+        const int nt0 = __builtin_amdgcn_readfirstlane(nts[0]), nt1 = __builtin_amdgcn_readfirstlane(nts[1]);
+        const int64_t rb0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rbs[0] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rbs[0]);
+        const int64_t rb1 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rbs[1] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rbs[1]);
+        const int64_t gapB = nt1 > 0 ? rb1 - rb0 : 0;  // entries from row A's start to row B's (rows of a list are stored in order)
+        const bool near = gapB >= 0 && gapB + nt1 < ((int64_t)1 << 29) && nt0 < (1 << 29);
+        const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.idx + rb0), 0, near ? (int)(max((int64_t)nt0, gapB + nt1) * 4) : 0, 0x00020000);
+        const uint32_t offB = (uint32_t)gapB * 4u;
+        // batch t of the stream -> is this lane's pair valid
+        auto valid = [&](int t) -> bool {
+            const bool pp = t >= nbA;
+            return t < NB && 64 * (t - (pp ? nbA : 0)) + lane < (pp ? nt1 : nt0);
         };
         auto ld_idx = [&](int t, int& j, float& nv) {
-            int pp;
-            int64_t at;
+            const bool pp = t >= nbA, ok = valid(t);
+            const int o = 64 * (t - (pp ? nbA : 0)) + lane;
             j = 0;
             nv = 0.0f;
-            if (where(t, pp, at)) {
-                j = p.idx[at];
-                if (p.nval) nv = p.nval[at];
+            if (near) {
+                j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, ok ? (uint32_t)o * 4u + (pp ? offB : 0u) : kOob, 0, 0);
+            } else if (ok) {
+                j = p.idx[(pp ? rb1 : rb0) + o];
             }
+            if (p.nval && ok) nv = p.nval[(pp ? rb1 : rb0) + o];
         };
-        auto ld_pos = [&](int t, int j, float& x, float& y, float& z) {
-            int pp;
-            int64_t at;
-            x = y = z = 0.0f;
-            if (where(t, pp, at)) {
-                x = p.inp_pos[3 * (int64_t)j];
-                y = p.inp_pos[3 * (int64_t)j + 1];
-                z = p.inp_pos[3 * (int64_t)j + 2];
-            }
+        auto ld_pos = [&](int j, float& x, float& y, float& z) {  // a scalar base + one 24-bit multiply
+            const float* q = (const float*)((const char*)p.inp_pos + (size_t)__umul24((uint32_t)j, 12u));
+            x = q[0];
+            y = q[1];
+            z = q[2];
         };
         auto geom = [&](int t, int j, float nv, float x, float y, float z, int& cls) -> ClsRec {
-            ClsRec c = {0.0f, {0.0f, 0.0f, 0.0f, 0.0f}};
-            cls = kNoPair;
-            int pp;
-            int64_t at;
-            if (where(t, pp, at)) {
-                x -= pp ? oxs[1] : oxs[0];
-                y -= pp ? oys[1] : oys[0];
-                z -= pp ? ozs[1] : ozs[0];
-                float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-                if (p.inp_imp) a *= p.inp_imp[j];
-                filter_coords<false>(x, y, z, p);
-                c.x = fminf(3.0f, fmaxf(0.0f, x));
-                y = fminf(3.0f, fmaxf(0.0f, y));
-                z = fminf(3.0f, fmaxf(0.0f, z));
-                const float yf = fminf(floorf(y), 2.0f), zf = fminf(floorf(z), 2.0f);
-                const float fy = y - yf, fz = z - zf;
-                cls = 3 * (int)zf + (int)yf;
-                const float a0 = a * (1.0f - fz), a1 = a * fz;
-                c.w = (f32x4){a0 * (1.0f - fy), a0 * fy, a1 * (1.0f - fy), a1 * fy};
-            }
+            ClsRec c;
+            const bool pp = t >= nbA;
+            x -= pp ? oxs[1] : oxs[0];
+            y -= pp ? oys[1] : oys[0];
+            z -= pp ? ozs[1] : ozs[0];
+            float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+            if (p.inp_imp) a *= p.inp_imp[j];
+            filter_coords<false>(x, y, z, p);
+            c.x = fminf(3.0f, fmaxf(0.0f, x));
+            y = fminf(3.0f, fmaxf(0.0f, y));
+            z = fminf(3.0f, fmaxf(0.0f, z));
+            const float yf = fminf(floorf(y), 2.0f), zf = fminf(floorf(z), 2.0f);
+            const float fy = y - yf, fz = z - zf;
+            cls = valid(t) ? 3 * (int)zf + (int)yf : kNoPair;
+            const float a0 = a * (1.0f - fz), a1 = a * fz;
+            c.w = (f32x4){a0 * (1.0f - fy), a0 * fy, a1 * (1.0f - fy), a1 * fy};
             return c;
         };
         // Ordered batch: class c occupies slots [cb[c], cb[c + 1]), a multiple of 4 long; the lanes of a class keep
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             Jst[lane] = -1;
             if (lane < kSlots - 64) Jst[64 + lane] = -1;
             xfence();
-            if (cls != kNoPair) Jst[pos] = j;
+            if (cls != kNoPair) Jst[pos] = (int)__umul24((uint32_t)j, rowB);  // the byte offset of the slot's feature row
         };
         auto push_rec = [&](const ClsRec& c, int cls, int pos) {
             *(f32x4*)(Gs + 4 * lane) = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};  // padding slots: weight 0, X 0
@@ -223,19 +229,16 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         };
         // 16-byte feature loads of half h of the ordered batch (narrow chunks: h = 0, the whole batch): three groups of 16
         // (32) slots, lane = (slot, 4 channels).
-        // Padding slots (index -1), slots past the batch and channels past cin read a block of zeros behind the packed
-        // filter: unconditional loads, nothing for the compiler to wait on before it issues them.
-        const char* featB = (const char*)(p.inp_feat + fch);
-        const uint32_t rowB = (uint32_t)cin * 4u;
+        // Padding slots (offset -1), slots past the batch and channels past cin are out of the buffer's range: the loads are
+        // unconditional and return zeros there.
+        const uint32_t cbyte = fch_ok ? 4u * (uint32_t)fch : kOob;
         auto f_issue = [&](int h, f32x4 (&f)[3]) {
-            int jj[3];
+            uint32_t jo[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) jj[k] = Jst[kHalfSlots * h + spi * k + fr];  // -1: padding slot or past the batch
+            for (int k = 0; k < 3; ++k) jo[k] = (uint32_t)Jst[kHalfSlots * h + spi * k + fr];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const char* src = featB + (uint64_t)(uint32_t)jj[k] * rowB;  // one 32 x 32 -> 64 bit multiply-add
-                f[k] = *(const f32x4*)((jj[k] >= 0 && fch_ok) ? src : (const char*)zero4);
-            }
+            for (int k = 0; k < 3; ++k)
+                f[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rF, __builtin_elementwise_add_sat(jo[k], cbyte), 0, 0));
         };
         // (the antisymmetric form adds the output point's own features: a padding slot then holds f_i, times weight 0)
         auto f_publish = [&](int t, const f32x4 (&f)[3]) {
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             float nvA, nvB, px, py, pz;
             ld_idx(0, jA, nvA);
             ld_idx(1, jB, nvB);
-            ld_pos(0, jA, px, py, pz);
+            ld_pos(jA, px, py, pz);
             const ClsRec first = geom(0, jA, nvA, px, py, pz, cl);
             Order oc = order(cl);
             f32x4 ff[3];
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             f_issue(0, ff);
             jA = jB;
             nvA = nvB;
-            ld_pos(1, jA, px, py, pz);
+            ld_pos(jA, px, py, pz);
             if constexpr (narrow) {
                 for (int t = 0; t < NB; ++t) {
                     // here: (jA, nvA, px, py, pz) = batch t + 1.  One feature round per batch: the loads of batch t + 1 are
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                     push_index(jA, cl, on.pos);
                     jA = jB;
                     nvA = nvB;
-                    ld_pos(t + 2, jA, px, py, pz);
+                    ld_pos(jA, px, py, pz);
                     xfence();
                     if (t + 1 < NB) f_issue(0, ff);
                     splat8(nslots);
@@ -385,7 +388,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                     if (two) f_publish(t, ff);
                     jA = jB;
                     nvA = nvB;
-                    ld_pos(t + 2, jA, px, py, pz);
+                    ld_pos(jA, px, py, pz);
                     if (t + 1 < NB) f_issue(0, ff);
                     if (two) {
                         xfence();
@@ -505,6 +508,8 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
     if ((cin & 3) || cout > 16 * kCMaxNT) return false;
     if ((uintptr_t)a->inp_features & 15) return false;
+    // 24-bit multiplies form the byte offsets of feature and position rows; the feature buffer must stay below 2 GB
+    if (a->n_inp >= (1 << 24) || a->n_inp * (int64_t)cin * 4 >= ((int64_t)1 << 31)) return false;
     if (e) return true;
     return cin >= 8;
 }

@@ -24,6 +24,12 @@ _KEEP = 16
 # whose arithmetic is the reference's own: the deviation of a layer stays below 2e-5 of its output, which is below 1e-7
 # of the positions after the out_scale of every shipped model.  DMCF_LATTICE_MAX_RATIO overrides it.
 MAX_X_OVER_EXTENT = float(os.environ.get("DMCF_LATTICE_MAX_RATIO", "32"))
+# The dense input volume of a launch: at most this many floats (cells x channels; the kernel addresses it with 32-bit byte
+# offsets, DMCF_EUNSUPPORTED above 2^29).  A few particles far from the rest -- a splash -- blow the lattices' bounding box up:
+# the layer then keeps the neighbour-list form, which does not care.
+MAX_VOLUME_FLOATS = 1 << 28
+# ... and sparser than one point per MAX_CELLS_PER_POINT cells the zero-filled volume costs more than the list it replaces
+MAX_CELLS_PER_POINT = 32
 
 
 def _registry():
@@ -154,39 +160,60 @@ class LatticePair:
     def __init__(self, inp, out, ratio):
         self.inp, self.out, self.ratio = inp, out, ratio
 
-    def conv(self, ops, kernel, inp_features, n_out, extent, **kw):
-        """The launch of dmcf_lattice_conv_forward for this pair (outputs on the finer lattice: the eight parity classes
-        of the output cells, each with its own stencil, as one dmcf_lattice_conv_forward_batch grid)."""
+    def plan(self, ops, extent, dev):
+        """(volume min, volume dims, parts | None) of the launch for this extent: the box of input cells the kernel can touch
+        (outputs on the finer lattice: the eight parity classes of the output cells, each with its own stencil, one volume
+        that serves them all)."""
+        key = (float(extent), str(dev))
+        hit = getattr(self, "_plan", None)
+        if hit is not None and hit[0] == key:
+            return hit[1]
         a, b = self.inp, self.out
-        radius, dev = 0.5 * float(extent), inp_features.device
-        fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
+        radius = 0.5 * float(extent)
         if self.ratio >= 1:
             step = int(self.ratio)
             vmin, vdim = ops.lattice_volume_box(b.minp, b.dims, step, ops.lattice_reach(a.voxel, radius, dev), a.minp, a.dims)
-            return ops.lattice_conv(kernel, a.volume(inp_features, vmin, vdim), vmin, b.table(), b.minp, n_out, a.voxel, extent,
-                                    inp_step=step, fill=fill, **kw)
-        lo = [b.minp[k] for k in range(3)]
-        hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
-        launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
-        for pz in (0, 1):
-            for py in (0, 1):
-                for px in (0, 1):
-                    ph = (px, py, pz)
-                    # base vectors a with lo <= 2 a + phase <= hi
-                    bmin = [-((ph[k] - lo[k]) // 2) for k in range(3)]
-                    bmax = [(hi[k] - ph[k]) // 2 for k in range(3)]
-                    bdim = [bmax[k] - bmin[k] + 1 for k in range(3)]
-                    if min(bdim) <= 0:
-                        continue
-                    shift = [ph[k] * b.voxel[k] for k in range(3)]
-                    m, d = ops.lattice_volume_box(bmin, bdim, 1, ops.lattice_reach(a.voxel, radius, dev, shift))
-                    vlo = [min(vlo[k], m[k]) for k in range(3)]
-                    vhi = [max(vhi[k], m[k] + d[k] - 1) for k in range(3)]
-                    launches.append((ph, bmin, bdim, shift))
-        vdim = [vhi[k] - vlo[k] + 1 for k in range(3)]
-        vol = a.volume(inp_features, vlo, vdim)  # one volume that serves all eight launches
-        parts = [dict(out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim) for ph, bmin, bdim, shift in launches]
-        return ops.lattice_conv(kernel, vol, vlo, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
+            res = (vmin, vdim, None)
+        else:
+            lo = [b.minp[k] for k in range(3)]
+            hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
+            launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
+            for pz in (0, 1):
+                for py in (0, 1):
+                    for px in (0, 1):
+                        ph = (px, py, pz)
+                        # base vectors a with lo <= 2 a + phase <= hi
+                        bmin = [-((ph[k] - lo[k]) // 2) for k in range(3)]
+                        bmax = [(hi[k] - ph[k]) // 2 for k in range(3)]
+                        bdim = [bmax[k] - bmin[k] + 1 for k in range(3)]
+                        if min(bdim) <= 0:
+                            continue
+                        shift = [ph[k] * b.voxel[k] for k in range(3)]
+                        m, d = ops.lattice_volume_box(bmin, bdim, 1, ops.lattice_reach(a.voxel, radius, dev, shift))
+                        vlo = [min(vlo[k], m[k]) for k in range(3)]
+                        vhi = [max(vhi[k], m[k] + d[k] - 1) for k in range(3)]
+                        launches.append((ph, bmin, bdim, shift))
+            vdim = [vhi[k] - vlo[k] + 1 for k in range(3)]
+            parts = [dict(out_phase=ph, rel_shift=shift, base_min=bmin, base_dims=bdim) for ph, bmin, bdim, shift in launches]
+            res = (vlo, vdim, parts)
+        self._plan = (key, res)
+        return res
+
+    def volume_cells(self, ops, extent, dev):
+        vdim = self.plan(ops, extent, dev)[1]
+        return int(vdim[0]) * int(vdim[1]) * int(vdim[2])
+
+    def conv(self, ops, kernel, inp_features, n_out, extent, **kw):
+        """The launch of dmcf_lattice_conv_forward for this pair (outputs on the finer lattice: one
+        dmcf_lattice_conv_forward_batch grid of the eight parity classes)."""
+        a, b = self.inp, self.out
+        fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
+        vmin, vdim, parts = self.plan(ops, extent, inp_features.device)
+        vol = a.volume(inp_features, vmin, vdim)
+        if parts is None:
+            return ops.lattice_conv(kernel, vol, vmin, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio),
+                                    fill=fill, **kw)
+        return ops.lattice_conv(kernel, vol, vmin, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
                                 parts=parts, fill=fill, **kw)
 
 

@@ -708,7 +708,12 @@ def neighbor_counts(row_splits):
     return out
 
 
-GRID_MAX_CELLS = 1 << 31  # dense cell table of the lattice bounding box: 4 bytes per cell, at most 8 GiB
+GRID_MAX_CELLS = 1 << 31  # dense cell table of the lattice bounding box: 4 bytes per cell, at most 8 GiB ...
+# ... and at most this many cells per particle (+ a floor): a few particles that left the scene (a splash; a particle falling
+# forever) stretch the bounding box, and a table that grows with it is a fresh multi-GB hipMalloc in every step of the
+# rollout (measured on the 100k-particle dam break: 6 -> 8 GB per step until the 8 GiB cap).  Beyond it: the sort-based form.
+GRID_MAX_CELLS_PER_POINT = 64
+GRID_MIN_CELLS = 1 << 22
 
 
 class GridTooSparse(RuntimeError):
@@ -739,7 +744,7 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, re
     cells = int(hdr[24:32].view(torch.int64).item())
     if cells < 0:
         raise _lib.DmcfError("grid_pos: positions are not finite")
-    if cells > GRID_MAX_CELLS:
+    if cells > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
         raise GridTooSparse(f"{cells} lattice cells in the bounding box")
     table = torch.empty(max(cells, 1), dtype=torch.int32, device=pos.device)
     _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes, _ptr(table),

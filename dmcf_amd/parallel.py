@@ -385,8 +385,10 @@ class GhostPlan:
 class ShardedSimulator:
     """``step(state) -> state`` on the particles this rank owns.
 
-    state = dict(pos, vel, acc|None, box, box_normals, gid): owned fluid particles (``gid`` = global particle
-    id, int64, carried through migration), owned boundary particles (static).  The network is the model's OWN
+    state = dict(pos, vel, acc|None, box, box_normals, gid): fluid particles this rank holds (``gid`` = global particle
+    id, int64, carried through migration; a step starts by handing every particle to the owner of its advected position and
+    returns the particles it then computed, so between steps a particle may sit slightly outside its holder's block), owned
+    boundary particles (static).  The network is the model's OWN
     ``forward`` (models/hrnet.py, sym_net.py, cconv.py): this class only installs ``model.conv_hook``, through which
     every ContinuousConv call of the forward pass gets its input rows extended by the ghosts within the layer's radius."""
 
@@ -503,7 +505,26 @@ class ShardedSimulator:
         dev = state["pos"].device
         self._plans, self._sets, self._lattices, self._wide, self._name_of, self._shared = {}, {}, {}, {}, {}, {}
         pos0, vel0, acc = state["pos"], state["vel"], state.get("acc")
+        gid = state["gid"]
         box_all, bfeats_all = state["box"], state["box_normals"]
+        # Migration FIRST, by the ADVECTED positions: the network convolves the integrated positions (pbf_model.py:318), so a
+        # rank must own the particles whose integrated position lies in its block -- then every output point of a layer is
+        # inside its owner's block and a halo of the layer's radius holds all its neighbours.  (Owning by the positions the
+        # step starts from leaves outputs up to dt |v| outside their block, where the neighbours' ghost test -- distance to
+        # the BLOCK -- no longer covers them.)  One stable sort by owner, one host round trip (the send counts), two
+        # all-to-all-v (payload; global ids with the receive counts the first one produced).
+        if comm.world > 1:
+            adv, _ = m.integrate_pos_vel(pos0, vel0, acc)
+            own = self.decomp.owner(adv)
+            payload = torch.cat([pos0, vel0] + ([acc] if acc is not None else []), dim=1)
+            order = torch.argsort(own, stable=True)
+            counts = torch.bincount(own, minlength=comm.world).tolist()
+            recv = comm.all_to_all(list(torch.split(payload[order], counts, dim=0)))
+            rc = [int(r.shape[0]) for r in recv]
+            payload = torch.cat(recv, dim=0)
+            gid = torch.cat(comm.all_to_all(list(torch.split(gid[order], counts, dim=0)), recv_counts=rc), dim=0)
+            pos0, vel0 = payload[:, 0:3].contiguous(), payload[:, 3:6].contiguous()
+            acc = payload[:, 6:9].contiguous() if acc is not None else None
         d = m.transform([pos0, vel0, acc, None, box_all, bfeats_all])
         _pos, _vel, acc_t, _, box, bfeats = d
         pos, vel = m.integrate_pos_vel(_pos, _vel, acc_t)
@@ -624,21 +645,7 @@ class ShardedSimulator:
         new_pos, new_vel = m.compute_new_pos_vel(_pos, _vel, pos2, vel2, pos_correction)
         new_pos, new_vel = m.inv_transform([new_pos, new_vel], None)
 
-        # migration: every particle goes to the owner of its new position: one stable sort by owner, one host round trip
-        # (the send counts), two all-to-all-v (payload; global ids with the receive counts the first one produced)
-        own = self.decomp.owner(new_pos)
-        gid = state["gid"]
-        payload = torch.cat([new_pos, new_vel] + ([acc] if acc is not None else []), dim=1)
-        if comm.world > 1:
-            order = torch.argsort(own, stable=True)
-            counts = torch.bincount(own, minlength=comm.world).tolist()
-            recv = comm.all_to_all(list(torch.split(payload[order], counts, dim=0)))
-            rc = [int(r.shape[0]) for r in recv]
-            payload = torch.cat(recv, dim=0)
-            gid = torch.cat(comm.all_to_all(list(torch.split(gid[order], counts, dim=0)), recv_counts=rc), dim=0)
-        new_state = dict(pos=payload[:, 0:3].contiguous(), vel=payload[:, 3:6].contiguous(),
-                         acc=payload[:, 6:9].contiguous() if acc is not None else None,
-                         box=box_all, box_normals=bfeats_all, gid=gid)
+        new_state = dict(pos=new_pos.contiguous(), vel=new_vel.contiguous(), acc=acc, box=box_all, box_normals=bfeats_all, gid=gid)
         return new_state
 
 

@@ -487,7 +487,15 @@ class ContinuousConv(torch.nn.Module):
             return None
         # (None too when the scene reaches so far from the origin that the nominal offsets d * voxel of this form and the
         # reference's differences of rounded positions part by more than the parity bar allows: lattice.MAX_X_OVER_EXTENT)
-        return lattice.pair(inp_positions, out_positions, extent)
+        lp = lattice.pair(inp_positions, out_positions, extent)
+        if lp is not None:
+            # a bounding box blown up by stray particles (a splash, a particle that left the scene): the dense zero-filled
+            # volume would be mostly empty, or not fit the kernel's 32-bit addressing -- the neighbour-list form does not care
+            cells = lp.volume_cells(ops, extent, inp_features.device)
+            if (cells * self.in_channels > lattice.MAX_VOLUME_FLOATS
+                    or cells > max(1 << 20, lattice.MAX_CELLS_PER_POINT * inp_positions.shape[0])):
+                return None
+        return lp
 
     call = forward
 

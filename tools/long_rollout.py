@@ -81,6 +81,8 @@ def main():
             rec["oracle_rel_err"] = float(np.abs(pos.cpu().numpy() - pos_ref).max() / np.abs(pos_ref).max())
             worst_parity = max(worst_parity, rec["oracle_rel_err"])
         recs.append(rec)
+        if os.environ.get("ROLLOUT_VERBOSE") and (t % 10 == 0 or rec["repeated"] or rec["device_allocs"]):
+            print(json.dumps(rec), flush=True)
         if not finite:
             break
     ms = np.array([r["ms"] for r in recs])
