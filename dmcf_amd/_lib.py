@@ -38,7 +38,6 @@ class CconvArgs(ctypes.Structure):
         ("flags", ctypes.c_int32),
         ("bias", ctypes.c_void_p),
         ("out", ctypes.c_void_p),
-        ("geometry", ctypes.c_void_p),
         ("n_pairs", ctypes.c_int64),
         ("neighbors_row_count", ctypes.c_void_p),
     ]
@@ -81,7 +80,7 @@ class LatticeConvArgs(ctypes.Structure):
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
-    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_kernel_name", "dmcf_cconv_geometry_bytes", "dmcf_cconv_geometry",
+    "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_kernel_name",
     "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
     "dmcf_lattice_conv_batch_workspace_bytes", "dmcf_lattice_conv_forward_batch",
     "dmcf_reduce_subarrays_sum",
@@ -144,10 +143,6 @@ def lib():
     L.dmcf_lattice_conv_batch_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32]
     L.dmcf_lattice_conv_forward_batch.restype = c.c_int
     L.dmcf_lattice_conv_forward_batch.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
-    L.dmcf_cconv_geometry_bytes.restype = c.c_size_t
-    L.dmcf_cconv_geometry_bytes.argtypes = [c.c_int64]
-    L.dmcf_cconv_geometry.restype = c.c_int
-    L.dmcf_cconv_geometry.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_reduce_subarrays_sum.restype = c.c_int
     L.dmcf_reduce_subarrays_sum.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
     L.dmcf_fps_workspace_bytes.restype = c.c_size_t

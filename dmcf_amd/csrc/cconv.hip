@@ -51,7 +51,7 @@ constexpr int kStage = 64 * (kWStride + kFStride + 1);  // floats per wave: weig
 // model was tried and removed: the extra v_readlane / bit-field work in the splat loop, which is co-limited
 // by instruction issue and the LDS pipe, cost more (+48 % kernel time) than the conflicts it removed.
 
-template <int CC, bool GENERIC, bool GEO>
+template <int CC, bool GENERIC>
 __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,9 +121,6 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         // Software pipeline over batches of 32 neighbours per half-wave: the (index, distance) loads run two
         // batches ahead and the dependent (position, feature) gathers one batch ahead of the splat that
         // consumes them, so the ~2 us index -> gather latency chain overlaps the LDS-bound phase 2.
-        // GEO: the per-pair geometry (window value, base cell, the three "+1" axis weights) comes from a cache
-        // built once per (neighbour search, filter geometry) by cconv_geometry_kernel and shared by every layer
-        // and channel chunk that uses the same search -- no position gather, no ball->cube map here.
         auto load_idx = [&](int bi, int& j, f32x4& g, int& gb, bool& valid) {
             const int64_t pp = rb + 32 * (int64_t)bi + pl;
             valid = pp < re;
@@ -132,12 +129,7 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
             g = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
             if (valid) {
                 j = p.idx[pp];
-                if constexpr (GEO) {
-                    g = p.geo4[pp];
-                    gb = p.geob[pp];
-                } else {
-                    if (p.nval) g.w = p.nval[pp];
-                }
+                if (p.nval) g.w = p.nval[pp];
             }
         };
         auto gather = [&](int j, bool valid, float& px, float& py, float& pz, float (&f)[CC]) {
@@ -159,11 +151,9 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                     for (int u = 0; u < CC; ++u)
                         if (c0 + u < cin) f[u] = fp[u];
                 }
-                if constexpr (!GEO) {
-                    px = p.inp_pos[3 * (int64_t)j];
-                    py = p.inp_pos[3 * (int64_t)j + 1];
-                    pz = p.inp_pos[3 * (int64_t)j + 2];
-                }
+                px = p.inp_pos[3 * (int64_t)j];
+                py = p.inp_pos[3 * (int64_t)j + 1];
+                pz = p.inp_pos[3 * (int64_t)j + 2];
             }
         };
         int jA, jB, gbA, gbB;
@@ -189,34 +179,26 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
                 float a = 0.0f;
                 int bx = 0, by = 0, bz = 0;
                 float wx0 = 1.0f, wx1 = 0.0f, wy0 = 1.0f, wy1 = 0.0f, wz0 = 1.0f, wz1 = 0.0f;
-                if constexpr (GEO) {
-                    a = gA.w;  // 0 for invalid lanes
-                    if (vA) nsum += a;
-                    if (p.inp_imp && vA) a *= p.inp_imp[jA];
-                    wx1 = gA.x; wy1 = gA.y; wz1 = gA.z;
-                    wx0 = 1.0f - wx1; wy0 = 1.0f - wy1; wz0 = 1.0f - wz1;
-                    bx = gbA & 255; by = (gbA >> 8) & 255; bz = (gbA >> 16) & 255;
-                } else {
-                    float x = 0.0f, y = 0.0f, z = 0.0f;
-                    if (vA) {
-                        x = gx - ox;
-                        y = gy - oy;
-                        z = gz - oz;
-                        a = window_value(p.window, p.nval ? gA.w : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-                        nsum += a;
-                        if (p.inp_imp) a *= p.inp_imp[jA];
-                        filter_coords<GENERIC>(x, y, z, p);
-                    }
-                    if (GENERIC) {
-                        axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
-                        axis_weights(y, p.sy, p.interp, by, wy0, wy1);
-                        axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
-                    } else {
-                        axis_weights_linear(x, p.sx, bx, wx0, wx1);
-                        axis_weights_linear(y, p.sy, by, wy0, wy1);
-                        axis_weights_linear(z, p.sz, bz, wz0, wz1);
-                    }
+                float x = 0.0f, y = 0.0f, z = 0.0f;
+                if (vA) {
+                    x = gx - ox;
+                    y = gy - oy;
+                    z = gz - oz;
+                    a = window_value(p.window, p.nval ? gA.w : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+                    nsum += a;
+                    if (p.inp_imp) a *= p.inp_imp[jA];
+                    filter_coords<GENERIC>(x, y, z, p);
                 }
+                if (GENERIC) {
+                    axis_weights(x, p.sx, p.interp, bx, wx0, wx1);
+                    axis_weights(y, p.sy, p.interp, by, wy0, wy1);
+                    axis_weights(z, p.sz, p.interp, bz, wz0, wz1);
+                } else {
+                    axis_weights_linear(x, p.sx, bx, wx0, wx1);
+                    axis_weights_linear(y, p.sy, by, wy0, wy1);
+                    axis_weights_linear(z, p.sz, bz, wz0, wz1);
+                }
+            
                 base = bz * PS + (by * p.sx + bx) * CC;
                 bst[lane] = base;
                 // corner weights in Open3D's product order (x-weight * y-weight) * z-weight
@@ -361,33 +343,6 @@ __global__ __launch_bounds__(kThreads, 4) void cconv_kernel(const CconvParams p)
         float* dst = p.out + ii * cout + o;
         if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
         *dst = v;
-    }
-}
-
-// Per-pair geometry of one (neighbour search, filter geometry): window value, base cell and the three "+1"
-// axis weights of the trilinear lookup (flag set of every DMCF model: volume preserving map, linear
-// interpolation, align_corners).  One wavefront per output row, lanes stride the row.
-__global__ __launch_bounds__(256) void cconv_geometry_kernel(const CconvParams p, f32x4* __restrict__ geo4,
-                                                             int32_t* __restrict__ geob) {
-    const int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (i >= p.n_out) return;
-    const int lane = lane_id();
-    const int64_t rb = p.rs[i];
-    int64_t re = p.cnt ? rb + p.cnt[i] : p.rs[i + 1];
-    if (re > p.pair_cap) re = rb;
-    const float ox = p.out_pos[3 * i], oy = p.out_pos[3 * i + 1], oz = p.out_pos[3 * i + 2];
-    for (int64_t pp = rb + lane; pp < re; pp += 64) {
-        const int j = p.idx[pp];
-        float x = p.inp_pos[3 * (int64_t)j] - ox, y = p.inp_pos[3 * (int64_t)j + 1] - oy, z = p.inp_pos[3 * (int64_t)j + 2] - oz;
-        const float a = window_value(p.window, p.nval ? p.nval[pp] : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-        filter_coords<false>(x, y, z, p);
-        int bx, by, bz;
-        float w0, wx1, wy1, wz1;
-        axis_weights_linear(x, p.sx, bx, w0, wx1);
-        axis_weights_linear(y, p.sy, by, w0, wy1);
-        axis_weights_linear(z, p.sz, bz, w0, wz1);
-        geo4[pp] = (f32x4){wx1, wy1, wz1, a};
-        geob[pp] = bx | (by << 8) | (bz << 16);
     }
 }
 
@@ -585,8 +540,6 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.rs = a->neighbors_row_splits;
     p.cnt = a->neighbors_row_count;
     p.nval = a->neighbors_value;
-    p.geo4 = nullptr;
-    p.geob = nullptr;
     p.n_out = a->n_out;
     p.n_inp = a->n_inp;
     p.pair_cap = a->n_pairs;
@@ -604,7 +557,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     if (cconv_z3_eligible(a, dz, dy, dx)) return cconv_z3_launch(p, a, workspace, stream);
     if (cconv_cls_eligible(a, dz, dy, dx)) return cconv_cls_launch(p, a, workspace, stream);
     if (cconv_blk_eligible(a, dz, dy, dx)) return cconv_blk_launch(p, a, workspace, stream);
-    if (!a->geometry && cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
+    if (cconv_mfma_eligible(p.K, p.cin, p.cout)) return cconv_mfma_launch(p, a, dz, dy, dx, workspace, stream);
     // the generic LDS-splat kernel: its own filter packing and LDS budget (every specialised kernel above packs its own
     // layout into the same workspace and has its own limits)
     const LaunchCfg cfg = make_cfg(dx, dy, dz, p.cin, p.cout);
@@ -632,21 +585,11 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     // the flag set every DMCF model uses (models/pbf_model.py:210-221) gets a specialised instantiation
     const bool generic = !specialised(a);
-    const bool geo = a->geometry != nullptr;
-    if (geo) {
-        if (generic || dx > 255 || dy > 255 || dz > 255) return DMCF_EINVAL;
-        const int64_t P = a->n_pairs;
-        if (P < 0 || ((uintptr_t)a->geometry & 15)) return DMCF_EINVAL;
-        p.geo4 = (const f32x4_t*)a->geometry;
-        p.geob = (const int32_t*)((const char*)a->geometry + (size_t)P * 16);
-    }
     const void* fn;
     if (cfg.CC == 8)
-        fn = generic ? (const void*)cconv_kernel<8, true, false>
-                     : (geo ? (const void*)cconv_kernel<8, false, true> : (const void*)cconv_kernel<8, false, false>);
+        fn = generic ? (const void*)cconv_kernel<8, true> : (const void*)cconv_kernel<8, false>;
     else
-        fn = generic ? (const void*)cconv_kernel<4, true, false>
-                     : (geo ? (const void*)cconv_kernel<4, false, true> : (const void*)cconv_kernel<4, false, false>);
+        fn = generic ? (const void*)cconv_kernel<4, true> : (const void*)cconv_kernel<4, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfg.lds);
     if (e != hipSuccess) { g_last_hip_error = (int)e; return DMCF_ELAUNCH; }
     void* kargs[] = {(void*)&p};
@@ -672,52 +615,11 @@ int dmcf_cconv_kernel_name(const dmcf_cconv_args* a, char* name, size_t name_byt
         snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false");
     else if (cconv_blk_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_blk_kernel<%d>", ntt);
-    else if (!a->geometry && cconv_mfma_eligible(dz * dy * dx, cin, cout))
+    else if (cconv_mfma_eligible(dz * dy * dx, cin, cout))
         snprintf(name, name_bytes, "cconv_mfma_kernel");
     else
         snprintf(name, name_bytes, "cconv_kernel<%d>", make_cfg(dx, dy, dz, cin, cout).CC);
     return DMCF_OK;
-}
-
-size_t dmcf_cconv_geometry_bytes(int64_t n_pairs) {
-    if (n_pairs < 0) return 0;
-    return align_up((size_t)n_pairs * 20 + 16, 256);
-}
-
-int dmcf_cconv_geometry(const dmcf_cconv_args* a, void* geometry, size_t geometry_bytes, dmcf_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    int rc = validate(a, false);
-    if (rc != DMCF_OK) return rc;
-    if (!specialised(a)) return DMCF_EUNSUPPORTED;
-    if (a->n_pairs < 0 || !geometry || ((uintptr_t)geometry & 15)) return DMCF_EINVAL;
-    if (geometry_bytes < dmcf_cconv_geometry_bytes(a->n_pairs)) return DMCF_EWORKSPACE;
-    if (a->n_out == 0 || a->n_pairs == 0) return DMCF_OK;
-    if (!a->inp_positions || !a->neighbors_index) return DMCF_EINVAL;
-    int dz, dy, dx;
-    full_dims(a, dz, dy, dx);
-    if (dx > 255 || dy > 255 || dz > 255) return DMCF_EUNSUPPORTED;
-    CconvParams p = {};
-    p.sx = dx; p.sy = dy; p.sz = dz;
-    p.out_pos = a->out_positions;
-    p.inp_pos = a->inp_positions;
-    p.idx = a->neighbors_index;
-    p.rs = a->neighbors_row_splits;
-    p.cnt = a->neighbors_row_count;
-    p.nval = a->neighbors_value;
-    p.n_out = a->n_out;
-    p.pair_cap = a->n_pairs;
-    p.inv_extent = 1.0f / a->extent;
-    const float radius = 0.5f * a->extent;
-    p.inv_r2 = 1.0f / (radius * radius);
-    p.window_fac = a->window_fac;
-    p.window = a->window;
-    p.mapping = a->coordinate_mapping;
-    p.interp = a->interpolation;
-    p.flags = a->flags;
-    const unsigned grid = (unsigned)((a->n_out + 3) / 4);
-    hipLaunchKernelGGL(cconv_geometry_kernel, dim3(grid), dim3(256), 0, stream, p, (f32x4*)geometry,
-                       (int32_t*)((char*)geometry + (size_t)a->n_pairs * 16));
-    return check_launch();
 }
 
 }  // extern "C"

@@ -501,7 +501,6 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "lds" / "mfma" / "blk" / "cls" / "direct": force one implementation
     if (e && e[0] != 'c') return false;
     if (dx != 4 || dy != 4 || dz != 4) return false;
-    if (a->geometry) return false;
     if (a->coordinate_mapping != DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING || a->interpolation != DMCF_INTERP_LINEAR ||
         !(a->flags & DMCF_FLAG_ALIGN_CORNERS) || (a->flags & DMCF_FLAG_NORMALIZE))
         return false;

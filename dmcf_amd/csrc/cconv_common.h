@@ -18,8 +18,6 @@ struct CconvParams {
     const int64_t* rs;
     const int32_t* cnt;    // optional pairs per row (padded lists: row i = [rs[i], rs[i] + cnt[i])); NULL = CSR
     const float* nval;
-    const f32x4_t* geo4;   // optional per-pair geometry cache: {w1x, w1y, w1z, a}
-    const int32_t* geob;   //   and packed base cell bx | by << 8 | bz << 16
     int64_t n_out;
     int64_t n_inp;     // rows of inp_pos / inp_feat (the bound of the kernels' buffer resources)
     int64_t pair_cap;  // entries the neighbour buffers hold; rows reaching past it are treated as empty (a search

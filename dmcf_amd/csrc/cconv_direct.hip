@@ -268,7 +268,7 @@ bool cconv_direct_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "direct" forces it where it is possible, any other value disables it
     if (e && e[0] != 'd') return false;
     const int cin = a->filter_dims[3], cout = a->filter_dims[4];
-    if (a->geometry || cout > 4 || cin > 32) return false;
+    if (cout > 4 || cin > 32) return false;
     DirectParams dp;
     if (!direct_cfg(dz, dy, dx, cin, dp)) return false;
     if (e) return true;

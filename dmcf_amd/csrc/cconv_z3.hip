@@ -395,7 +395,7 @@ bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     const char* e = getenv("DMCF_CCONV_KERNEL");  // "z3": force, anything else: never
     if (e && e[0] != 'z') return false;
     if (dx != 4 || dy != 4 || dz != 4) return false;
-    if (a->geometry || (a->flags & DMCF_FLAG_SYMMETRIC)) return false;
+    if (a->flags & DMCF_FLAG_SYMMETRIC) return false;
     if (a->coordinate_mapping != DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING || a->interpolation != DMCF_INTERP_LINEAR ||
         !(a->flags & DMCF_FLAG_ALIGN_CORNERS) || (a->flags & DMCF_FLAG_NORMALIZE))
         return false;

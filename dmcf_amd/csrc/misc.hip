@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* 
 
 extern "C" {
 
-int dmcf_version(void) { return 100; }
+int dmcf_version(void) { return 200; }
 
 const char* dmcf_error_string(int code) {
     switch (code) {

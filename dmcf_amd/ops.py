@@ -287,25 +287,27 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
     flags = 1 if ignore_query_point else 0
     dev = points.device
     row_splits = torch.empty(m + 1, dtype=torch.int64, device=dev)
-    t0 = timer.begin() if timer is not None else None
     if row_stride is not None:
         stride = max(int(row_stride), 1)
         # allocation sizes in coarse buckets (see pair_capacity): the lattice point sets change size every step
         need = m * stride
-        # 1/8 headroom: the stride moves in steps of ~9 % (row_stride) and the lattice sets change size -- without it a
-        # list that grows a little asks for a fresh, slightly larger multi-GB block (a hipMalloc of 70-150 ms in that step)
-        cap = _size_class(need + need // 8)
+        # 1/4 headroom: the stride moves in steps of ~9 % (row_stride) and the lattice sets change size -- without it a
+        # list that grows a little asks for a fresh, slightly larger multi-GB block (a hipMalloc of 25-150 ms in that step)
+        cap = _size_class(need + need // 4)
         # a caller that repeats this search every step passes the capacity it got last time: while that still fits (and
         # is not grossly oversized) the request stays byte-identical, and the caching allocator answers it without a
         # hipMalloc (a fresh 2 GB block costs 20-120 ms; m * stride hovers around a bucket edge for steps on end)
         if capacity_hint is not None and need <= int(capacity_hint) <= 2 * cap:
             cap = int(capacity_hint)
         elif capacity_hint is not None and need > int(capacity_hint):
-            cap = _size_class(need + need // 4)  # outgrown: make this reallocation the last one for a while
+            # outgrown -- a scene that is compressing or heating up keeps growing: 1/2 headroom makes this reallocation the
+            # last one for four or five stride bumps (the rollout of the 1M-particle box outgrew 1/4 five times in 25 steps)
+            cap = _size_class(need + need // 2)
         index = torch.empty(cap, dtype=torch.int32, device=dev)
         dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
         counts = torch.empty(m, dtype=torch.int32, device=dev)
         max_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        t0 = timer.begin() if timer is not None else None  # (after the allocations: a hipMalloc is not kernel time)
         _lib.check(L.dmcf_frs_search_padded(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, stride, _ptr(row_splits),
                                             _ptr(counts), _ptr(index), _ptr(dist) if return_distances else None,
                                             _ptr(max_count), _stream()), "dmcf_frs_search_padded")
@@ -316,6 +318,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         if timer is not None:
             timer.end("frs_search_padded", dict(n_points=n, n_queries=m, pairs=res.total_ref, distances=bool(return_distances)), t0)
         return res
+    t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_frs_count(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, _ptr(row_splits), _stream()),
                "dmcf_frs_count")
     if timer is not None:
@@ -386,7 +389,7 @@ def _empty(t):
 
 def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                 neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
-                normalize, symmetric, sym_axis, bias, out, accumulate, geometry, neighbors_row_count=None):
+                normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None):
     """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
@@ -442,7 +445,6 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
                (FLAG_SYMMETRIC if symmetric else 0) | (FLAG_ACCUMULATE if accumulate else 0))
     a.bias = None if bias is None else bias.data_ptr()
     a.out = None if out is None else out.data_ptr()
-    a.geometry = None if geometry is None else geometry.data_ptr()
     a.n_pairs = neighbors_index.shape[0]
     a.neighbors_row_count = None
     if neighbors_row_count is not None:
@@ -451,33 +453,8 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
         neighbors_row_count = neighbors_row_count.contiguous()
         a.neighbors_row_count = neighbors_row_count.data_ptr()
     keep = (neighbors_row_count, filters, out_positions, inp_positions, inp_features, inp_importance, neighbors_index, neighbors_row_splits,
-            neighbors_value, bias, out, geometry)
+            neighbors_value, bias, out)
     return a, keep
-
-
-def geometry_supported(align_corners, coordinate_mapping, interpolation):
-    """The per-pair geometry cache exists for the flag set every DMCF model uses (models/pbf_model.py:210-221)."""
-    return bool(align_corners) and coordinate_mapping == "ball_to_cube_volume_preserving" and interpolation == "linear"
-
-
-def cconv_geometry(kernel_dims, out_positions, extent, inp_positions, neighbors_index, neighbors_row_splits,
-                   neighbors_value=None, window=None, window_fac=1.0, symmetric=False, sym_axis=2):
-    """dmcf_cconv_geometry: window value + mapped filter coordinates of every neighbour pair, once per
-    (neighbour list, filter geometry).  ``kernel_dims`` = (D, H, W) of the stored kernel.  Returns an opaque
-    uint8 tensor to pass as ``geometry=`` to :func:`cconv_forward` calls with the same operands."""
-    L = _lib.lib()
-    dev = out_positions.device
-    dummy = torch.empty((*[int(k) for k in kernel_dims], 1, 1), dtype=torch.float32, device=dev)
-    a, keep = _cconv_args(dummy, out_positions, extent, inp_positions, None, neighbors_index, neighbors_row_splits,
-                          neighbors_value, window, window_fac, None, True, "ball_to_cube_volume_preserving", "linear",
-                          False, symmetric, sym_axis, None, None, False, None)
-    nbytes = L.dmcf_cconv_geometry_bytes(a.n_pairs)
-    geo = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    t0 = timer.begin() if timer is not None else None
-    _lib.check(L.dmcf_cconv_geometry(ctypes.byref(a), _ptr(geo), nbytes, _stream()), "dmcf_cconv_geometry")
-    if timer is not None:
-        timer.end("cconv_geometry", dict(pairs=int(a.n_pairs)), t0)
-    return geo
 
 
 _STENCILS = {}
@@ -614,11 +591,11 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
 def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
-                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None,
+                  normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False,
                   n_pairs_ref=None, neighbors_row_count=None):
     """One call of dmcf_cconv_forward.  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
-    ``geometry``: optional result of :func:`cconv_geometry` for the same operands."""
+    """
     L = _lib.lib()
     n_out, cout = out_positions.shape[0], filters.shape[4]
     if out is None:
@@ -639,7 +616,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
-                          geometry, neighbors_row_count)
+                          neighbors_row_count)
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None

@@ -35,6 +35,7 @@ class Simulator:
         if self.device.type != "cuda":
             raise RuntimeError("the DMCF hot path runs on the GPU only (no CPU fallback)")
         self.timing = []
+        self._slot0 = 0  # scene slot of inputs[0] (run_rollout feeds its scenes one at a time)
         self.repeated_steps = 0  # steps repeated with exact buffer sizes after a NeighborCapacityExceeded
         # base_pipeline.py:46-63: <main_log_dir | output_dir>/<Model>_<dataset>_<version>
         tag = "_".join([type(model).__name__, dataset.name if dataset is not None and hasattr(dataset, "name") else "",
@@ -55,12 +56,12 @@ class Simulator:
         results = []
         for bi in range(len(inputs)):
             try:
-                with neighbor_cache(estimate=True):
+                with neighbor_cache(estimate=True, key=(id(self.model), bi + self._slot0)):
                     pos, vel = self.model(inputs[bi], training=False)
             except ops.NeighborCapacityExceeded:
                 # a neighbour list grew by more than the slack since the previous step: repeat with exact sizes
                 self.repeated_steps += 1
-                with neighbor_cache(estimate=False):
+                with neighbor_cache(estimate=False, key=(id(self.model), bi + self._slot0)):
                     pos, vel = self.model(inputs[bi], training=False)
             results.append([pos, vel] + list(inputs[bi][2:]))
         return results
@@ -86,7 +87,9 @@ class Simulator:
             torch.cuda.synchronize(self.device)
             start = time.time()
             for i in range(len(inputs)):
+                self._slot0 = i  # each scene keeps its own buffer-size estimates
                 inputs[i] = self.run_inference(inputs[i:i + 1])[0]
+            self._slot0 = 0
             torch.cuda.synchronize(self.device)
             timing.append(time.time() - start)
             for i in range(len(inputs)):

@@ -51,8 +51,19 @@ class _NeighborCache:
         self.pending = []
         self.lists = {}
         self.tables = {}
-        self.geometries = {}
         self.keepalive = []
+        self.key = None
+        self.states = {}  # key -> (hints, caps, expect) of the rollouts that are not the current one
+
+    def select(self, key):
+        """Swap in the estimates (hints / caps / expect) of ``key`` (outermost scope only)."""
+        if key == self.key:
+            return
+        self.states[self.key] = (self.hints, self.caps, self.expect)
+        while len(self.states) > 16:  # a handful of (model, scene) rollouts at a time
+            self.states.pop(next(iter(self.states)))
+        self.hints, self.caps, self.expect = self.states.pop(key, ([], {}, {}))
+        self.key = key
 
     def __enter__(self):
         if self.depth == 0:
@@ -76,7 +87,6 @@ class _NeighborCache:
             lattice.clear()
             self.lists.clear()
             self.tables.clear()
-            self.geometries.clear()
             self.keepalive.clear()
             if exc_type is None and pending:
                 # one synchronisation per step: validate the estimated row capacities, refresh the estimates
@@ -155,19 +165,6 @@ class _NeighborCache:
         return res
 
 
-    def geometry(self, nns, key, build):
-        """Per-pair geometry (dmcf_cconv_geometry) of one neighbour list for one filter geometry: computed by the
-        first layer that needs it, reused by every later layer / channel chunk of the step."""
-        if self.depth == 0:
-            return None  # outside a step nothing is cached; the kernel evaluates window + mapping itself
-        k = (nns.neighbors_index.data_ptr(), int(nns.neighbors_index.shape[0])) + key
-        geo = self.geometries.get(k)
-        if geo is None:
-            geo = build()
-            self.geometries[k] = geo
-        return geo
-
-
 class _PerThreadCache:
     """One _NeighborCache per thread: the virtual ranks of dmcf_amd.parallel.run_local_ranks are threads of one process and
     each must see its own step scope, search order and estimates (a real rank is a process and has one anyway)."""
@@ -196,24 +193,20 @@ class _PerThreadCache:
 
 _CACHE = _PerThreadCache()
 
-# The per-pair geometry cache (dmcf_cconv_geometry) feeds the LDS-splat kernel; the matrix-core kernel that
-# handles every filter of up to 64 cells recomputes the geometry per 16-channel pass at ~15 % of its MFMA time,
-# which is cheaper than writing and re-reading 20 B per pair.  Kept as an opt-in for large filters.
-USE_GEOMETRY_CACHE = False
-
-
 class _CacheScope:
     """``with neighbor_cache(estimate=...)``: enters the process-wide cache; ``estimate`` (outermost scope only)
     turns on buffer sizes estimated from the previous step -- the caller must then be prepared to repeat the step
     on :class:`dmcf_amd.ops.NeighborCapacityExceeded` (Simulator.run_inference does)."""
 
-    def __init__(self, estimate):
+    def __init__(self, estimate, key=None):
         self.estimate = estimate
+        self.key = key
 
     def __enter__(self):
         if _CACHE.depth == 0:
             self.prev = _CACHE.use_hints
             _CACHE.use_hints = bool(self.estimate) and os.environ.get("DMCF_NO_ESTIMATE") != "1"
+            _CACHE._get().select(self.key)
             self.outer = True
         else:
             self.outer = False
@@ -227,9 +220,11 @@ class _CacheScope:
                 _CACHE.use_hints = self.prev
 
 
-def neighbor_cache(estimate=False):
-    """Context manager enabling per-step neighbour-list reuse (see :class:`_NeighborCache`)."""
-    return _CacheScope(estimate)
+def neighbor_cache(estimate=False, key=None):
+    """Context manager enabling per-step neighbour-list reuse (see :class:`_NeighborCache`).  ``key``: whose step this is
+    -- e.g. (model, scene slot) -- so that the estimates one rollout leaves behind (row capacities, consumers per list, by
+    position in the step's search sequence) are not applied to another model or another scene of the same batch."""
+    return _CacheScope(estimate, key)
 
 
 def neighbor_hints():
@@ -440,27 +435,13 @@ class ContinuousConv(torch.nn.Module):
         if symmetric and self.normalize:
             raise NotImplementedError("symmetric=True with normalize=True (DMCF always uses normalize=False, "
                                       "models/pbf_model.py:203)")
-        geometry = None
-        if (USE_GEOMETRY_CACHE and self.nns is not None and user_neighbors_index is None and row_count is None
-                and window not in (None, "explicit")
-                and inp_importance is None and not self.circular
-                and ops.geometry_supported(self.align_corners, self.coordinate_mapping, self.interpolation)):
-            neighbors_index = self.nns.neighbors_index  # exact length: the cache is sized by P
-            if neighbors_value is raw_dist:
-                neighbors_value = self.nns.neighbors_distance
-            kdims = tuple(int(d) for d in kernel.shape[:3])
-            gkey = (kdims, float(extent), window, float(window_fac), bool(symmetric), int(self.sym_axis))
-            geometry = _CACHE.geometry(self.nns, gkey, lambda: ops.cconv_geometry(
-                kdims, out_positions, extent, inp_positions, neighbors_index, neighbors_row_splits,
-                neighbors_value=neighbors_value, window=window, window_fac=window_fac, symmetric=symmetric,
-                sym_axis=self.sym_axis))
         fuse_bias = self.use_bias and not self.use_dense_layer_for_center
         out_features = ops.cconv_forward(
             kernel, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
             neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
-            bias=self.bias if fuse_bias else None, geometry=geometry, n_pairs_ref=n_pairs_ref,
+            bias=self.bias if fuse_bias else None, n_pairs_ref=n_pairs_ref,
             neighbors_row_count=row_count)
         self._conv_output = None if in_step else out_features
         return self._finish(out_features, inp_features)

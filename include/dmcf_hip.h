@@ -170,9 +170,6 @@ typedef struct dmcf_cconv_args {
     int32_t flags;              /* DMCF_FLAG_* */
     const float* bias;          /* [Cout] or NULL; added after normalisation (convolutions.py:466-467) */
     float* out;                 /* [n_out,Cout] */
-    /* optional per-pair geometry cache filled by dmcf_cconv_geometry for the same positions / neighbour list /
-     * extent / filter dims / window; NULL = evaluate window + mapping inside the convolution */
-    const void* geometry;
     int64_t n_pairs;            /* entries in neighbors_index / neighbors_value (>= P = neighbors_row_splits[n_out]);
                                  * rows reaching past it are treated as empty (see dmcf_frs_write pair_capacity) */
     const int32_t* neighbors_row_count; /* optional [n_out]: PADDED lists as written by dmcf_frs_search_padded -- row i is
@@ -182,15 +179,6 @@ typedef struct dmcf_cconv_args {
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);
 
-/* Per-pair geometry cache.  The window value and the ball->cube mapped filter coordinates of a neighbour pair
- * depend only on (positions, neighbour list, extent, filter dims, window) -- not on features, filters or the
- * channel chunk -- and the reference recomputes them in every one of its 18/27/43 continuous_conv calls per step
- * although only 12/12/19 neighbour lists are distinct.  dmcf_cconv_geometry evaluates them once (20 bytes per
- * pair: three axis weights, the window value, the base filter cell); dmcf_cconv_forward then reads them through
- * args->geometry.  Available for the flag set DMCF uses (ball_to_cube_volume_preserving, linear, align_corners);
- * otherwise DMCF_EUNSUPPORTED.  Results are bit-identical with and without the cache. */
-size_t dmcf_cconv_geometry_bytes(int64_t n_pairs);
-int dmcf_cconv_geometry(const dmcf_cconv_args* args, void* geometry, size_t geometry_bytes, dmcf_stream_t stream);
 int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t workspace_bytes,
                        dmcf_stream_t stream);
 /* Diagnostics: the name of the device kernel dmcf_cconv_forward dispatches these arguments to (the dispatch looks at the

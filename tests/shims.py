@@ -20,7 +20,7 @@ def install(monkeypatch):
     def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                       neighbors_value=None, window=None, window_fac=1.0, inp_importance=None, align_corners=True,
                       coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear", normalize=False,
-                      symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, geometry=None, n_pairs_ref=None,
+                      symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, n_pairs_ref=None,
                       neighbors_row_count=None):
         assert neighbors_row_count is None
         radius = np.float32(0.5) * np.float32(extent)
@@ -70,5 +70,4 @@ def install(monkeypatch):
     monkeypatch.setattr(ops, "fixed_radius_search", fixed_radius_search)
     monkeypatch.setattr(ops, "build_spatial_hash_table", build_spatial_hash_table)
     monkeypatch.setattr(ops, "cconv_forward", cconv_forward)
-    monkeypatch.setattr(ops, "geometry_supported", lambda *a: False)
     monkeypatch.setattr(ops, "neighbor_counts", lambda r: torch.diff(r.neighbors_row_splits if isinstance(r, ops.NeighborSearchResult) else r).to(torch.float32))

@@ -281,27 +281,6 @@ def test_scale_properties_200k(oracle, dev):
     assert torch.allclose(b, 2 * a, rtol=1e-4, atol=1e-4 * a.abs().max().item())
 
 
-@pytest.mark.parametrize("ks,sym,cin,cout,dim", [((4, 4, 4), False, 16, 16, 3), ((4, 4, 4), False, 4, 8, 3), ((6, 3, 6), True, 32, 3, 3),
-                                                  ((1, 8, 8), False, 24, 8, 2), ((1, 4, 8), True, 32, 2, 2)])
-def test_geometry_cache_is_bit_identical(oracle, dev, ks, sym, cin, cout, dim, monkeypatch):
-    """dmcf_cconv_geometry + dmcf_cconv_forward(geometry=...) == dmcf_cconv_forward alone, bit for bit
-    (same kernel: the LDS splat, which is the one that consumes the cache)."""
-    from dmcf_amd import ops
-    monkeypatch.setenv("DMCF_CCONV_KERNEL", "lds")
-    rng = np.random.default_rng(3)
-    n, radius = 3000, 0.2 if dim == 3 else 0.06
-    pos = _t(_cloud(n, 31, dim), dev)
-    feat = _t(rng.normal(size=(n, cin)).astype(np.float32), dev)
-    k = _t(rng.uniform(-1, 1, size=(*ks, cin, cout)).astype(np.float32), dev)
-    nns = ops.fixed_radius_search(pos, pos, radius, ignore_query_point=sym, return_distances=True)
-    win = "peak" if sym else "poly6"
-    kw = dict(neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
-    a = ops.cconv_forward(k, pos, 2 * radius, pos, feat, nns.neighbors_index, nns.neighbors_row_splits, **kw)
-    geo = ops.cconv_geometry(ks, pos, 2 * radius, pos, nns.neighbors_index, nns.neighbors_row_splits, **kw)
-    b = ops.cconv_forward(k, pos, 2 * radius, pos, feat, nns.neighbors_index, nns.neighbors_row_splits, geometry=geo, **kw)
-    assert torch.equal(a, b)
-
-
 @pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "direct"])
 @pytest.mark.parametrize("window,sym", [("poly6", False), ("cubic", False), ("peak", True)])
 def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel, window, sym):

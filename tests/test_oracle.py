@@ -251,6 +251,23 @@ def test_against_open3d_golden(oracle):
             ref = g[f"cconv_{name}_{mapping}"]
             assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(oracle.reduce_subarrays_sum(g["rss_values"], g["rss_row_splits"]), g["rss_out"], rtol=1e-6)
+    if "ascc_out" in g:  # captured with --reference: the reference's own ASCC layer, grid_pos and a 10-step rollout
+        conv = oracle.ContinuousConvRef(g["ascc_kernel"], window_function="peak", ignore_query_points=True, symmetric=True,
+                                        sym_axis=1)
+        y = conv(g["ascc_feat"], g["ascc_pos"], g["ascc_pos"], 2 * float(g["ascc_radius"]))
+        assert np.abs(y - g["ascc_out"]).max() <= 1e-5 * np.abs(g["ascc_out"]).max()
+        for stride in (2, 4):
+            for central in (0, 1):
+                got = oracle.grid_pos(g["gridpos_cloud"], np.float32([0.025 * stride] * 3), centralize=bool(central))
+                np.testing.assert_array_equal(got, g[f"gridpos_s{stride}_c{central}"])  # same points in tf.unique order
+        from oracle.model_ref import ModelRef
+        from tools import configs
+        ref = ModelRef(configs.LIQUID3D, dict(np.load(os.path.join(os.path.dirname(path), "liquid3d_weights.npz"))))
+        state = [g["rollout_pos"][0], g["rollout_vel0"], None, None, g["rollout_box"], g["rollout_box_normals"]]
+        for t in range(1, g["rollout_pos"].shape[0]):
+            pos, vel = ref.step(state)
+            assert np.abs(pos - g["rollout_pos"][t]).max() <= 1e-5 * np.abs(g["rollout_pos"][t]).max(), f"rollout step {t}"
+            state = [g["rollout_pos"][t], vel] + state[2:]  # per-step parity from the reference's own states
 
 
 def test_column_fixture_from_the_reference_generator(oracle):

@@ -38,14 +38,8 @@ def main():
         nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=True)
         feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
         W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
-        geo = None
-        if os.environ.get("GEO", "0") == "1":
-            g = lambda: ops.cconv_geometry(ks, out, 2 * R, inp, nns.neighbors_index, nns.neighbors_row_splits,
-                                           neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
-            geo = g()
-            print(f"   geometry build {timed(g):.2f} ms", flush=True)
         f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
-                                      neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1, geometry=geo)
+                                      neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
         f()
         ms = timed(f)
         P = nns.neighbors_index.shape[0]
