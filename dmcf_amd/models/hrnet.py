@@ -59,12 +59,20 @@ class HRNet(PBFNet):
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in self.particle_radii]
         ans_convs = [[feats]]
         ext = None
+        stash = {}       # (layer, inp_scale) -> output of a scale-0 conv of that layer computed one layer early (cross_pairs)
+        relu_next = {}   # inp_scale -> relu of the next layer's input at that scale, when already formed
         for layer in range(len(self.convs)):
-            ans = []
+            n_scales = len(self.convs[layer])
+            ans = [None] * n_scales
             # relu(x_{inp_scale}) is formed once per layer, not once per (scale, inp_scale) as the reference does (:85): the
             # same values, two thirds fewer elementwise kernels
-            relu_in = [torch.relu(t) for t in ans_convs[-1]]
-            for scale in range(len(self.convs[layer])):
+            relu_in = [relu_next.pop(i) if i in relu_next else torch.relu(t) for i, t in enumerate(ans_convs[-1])]
+            relu_next = {}
+            cross = self._cross_layer_pairs(layer, dens)
+            # output scales >= 1 first when a scale-0 conv of this layer is paired with one of the next layer (which reads this
+            # layer's output at that scale): the sums do not depend on the order
+            order = list(range(1, n_scales)) + [0] if cross else list(range(n_scales))
+            for scale in order:
                 importance = self.part_scale if scale == 0 else 1.0
                 inp = []
                 for inp_scale in range(len(ans_convs[-1])):
@@ -73,10 +81,20 @@ class HRNet(PBFNet):
                         feats = torch.cat([feats, feats / dens[inp_scale] ** 2], dim=-1)
                     ext = filter_extent[max(inp_scale, scale)]
                     conv_in = feats if importance == 1.0 else feats * importance
-                    # (the same relu(x_{inp_scale}) feeds every output scale: its widest extent is a hint for the hook)
-                    widest = max(filter_extent[max(inp_scale, s)] for s in range(len(self.convs[layer])))
-                    ans_conv = self.apply_conv(self.convs[layer][scale][0][inp_scale], conv_in, pos[inp_scale], pos[scale], ext,
-                                               widest if conv_in is feats else None)
+                    conv = self.convs[layer][scale][0][inp_scale]
+                    if scale == 0 and (layer, inp_scale) in stash:
+                        ans_conv = stash.pop((layer, inp_scale))  # came out of the previous layer's paired launch
+                    elif scale == 0 and inp_scale in cross:
+                        nxt = torch.relu(ans[inp_scale])  # the next layer's input at this scale: complete (scales >= 1 first)
+                        relu_next[inp_scale] = nxt
+                        nxt_in = nxt if importance == 1.0 else nxt * importance
+                        ans_conv, later = self._paired_convs(conv, self.convs[layer + 1][0][0][inp_scale], conv_in, nxt_in,
+                                                             pos[inp_scale], pos[0], ext)
+                        stash[(layer + 1, inp_scale)] = later
+                    else:
+                        # (the same relu(x_{inp_scale}) feeds every output scale: its widest extent is a hint for the hook)
+                        widest = max(filter_extent[max(inp_scale, s)] for s in range(n_scales))
+                        ans_conv = self.apply_conv(conv, conv_in, pos[inp_scale], pos[scale], ext, widest if conv_in is feats else None)
                     if layer < len(self.denses):
                         if scale == inp_scale:  # :93-99
                             ans_conv = ans_conv + self.denses[layer][scale][0][inp_scale](feats)
@@ -97,14 +115,72 @@ class HRNet(PBFNet):
                     merged = inp[0]
                     for t in inp[1:]:
                         merged = merged + t
-                    ans.append(merged)
+                    ans[scale] = merged
                 else:
-                    ans.append(torch.cat(inp, dim=-1))
+                    ans[scale] = torch.cat(inp, dim=-1)
                 for i in range(1, len(self.convs[layer][scale])):  # :120-131 (k > 0 sub-layers)
-                    ans_conv = self.apply_conv(self.convs[layer][scale][i][0], ans[-1] * importance, pos[scale], pos[scale], ext)
-                    ans_conv = ans_conv + self.denses[layer][scale][i][0](ans[-1])
+                    ans_conv = self.apply_conv(self.convs[layer][scale][i][0], ans[scale] * importance, pos[scale], pos[scale], ext)
+                    ans_conv = ans_conv + self.denses[layer][scale][i][0](ans[scale])
                     if len(ans_convs[-1]) > scale and ans_conv.shape[-1] == ans_convs[-1][scale].shape[-1]:
                         ans_conv = ans_conv + ans_convs[-1][scale]
-                    ans[-1] = ans_conv
+                    ans[scale] = ans_conv
             ans_convs.append(ans)
         return self.out_activation(ans_convs[-1][0])
+
+    # -- two layers, one walk over a neighbour list -------------------------------------------------------------------------
+    def _cross_layer_pairs(self, layer, dens):
+        """Input scales s >= 1 whose conv into scale 0 of THIS layer (pos[s] -> pos[0]) can share its launch with the conv of
+        the NEXT layer on the same list (hrnet.py:85-92: same point sets, same radius, same flags; only features and
+        weights differ).  The next layer's input at scale s is this layer's output at scale s, which does not depend on
+        this layer's scale-0 convs -- so both convs can run once that output exists: one search-list walk, one geometry
+        evaluation per pair instead of two (Liquid3d: conv200_2 + conv300_2, 4 + 8 input channels on the 2.9e8-pair s2 -> s0
+        list).  Restricted to what one 16-channel pass of the class-sorted kernel holds; never inside a sharded step (the
+        ghost exchange is per layer) and never on the first call (the layers build their weights lazily)."""
+        import os
+        from ..utils import convolutions as _convs
+        if (os.environ.get("DMCF_FUSE_CROSS_LAYER", "1") == "0" or self.conv_hook is not None or _convs._CACHE.depth == 0
+                or layer + 1 >= len(self.convs) or not self.add_merge or self.voxel_size is None
+                or (self.dens_norm and dens is not None) or len(self.convs[layer][0]) != 1 or len(self.convs[layer + 1][0]) != 1):
+            return set()
+        out = set()
+        for s in range(1, min(len(self.convs[layer][0][0]), len(self.convs[layer + 1][0][0]), len(self.convs[layer]))):
+            a, b = self.convs[layer][0][0][s], self.convs[layer + 1][0][0][s]
+            if a.kernel is None or b.kernel is None or not a.kernel.is_cuda:
+                continue
+            wa, wb = a.window_function, b.window_function
+            same = (isinstance(wa, _convs.WindowFunction) and isinstance(wb, _convs.WindowFunction) and wa.name == wb.name
+                    and wa.fac == wb.fac and tuple(a.kernel.shape[:3]) == (4, 4, 4) == tuple(b.kernel.shape[:3])
+                    and all(getattr(a, k) == getattr(b, k) for k in (
+                        "align_corners", "coordinate_mapping", "interpolation", "normalize", "use_bias",
+                        "radius_search_ignore_query_points", "radius_search_metric", "use_dense_layer_for_center"))
+                    and not (a.symmetric or b.symmetric or a.circular or b.circular or a.normalize
+                             or a.radius_search_ignore_query_points or a.use_dense_layer_for_center)
+                    and a.activation is None and b.activation is None
+                    and a.kernel.shape[3] % 4 == 0 and b.kernel.shape[3] % 4 == 0
+                    and a.kernel.shape[3] + b.kernel.shape[3] <= 16 and a.filters + b.filters <= 64)
+            if same:
+                out.add(s)
+        return out
+
+    def _paired_convs(self, a, b, feats_a, feats_b, inp_pos, out_pos, extent):
+        """conv a on feats_a and conv b on feats_b, both inp_pos -> out_pos, as ONE convolution: features [fa | fb], the two
+        kernels stacked block-diagonally, outputs [conv_a | conv_b] (every product with a zero block is an exact zero, so
+        each half is the sum its own layer forms, in the order of the shared list)."""
+        from .. import ops
+        from ..utils import convolutions as _convs
+        ca, cb, oa, ob = a.kernel.shape[3], b.kernel.shape[3], a.filters, b.filters
+        feats = torch.cat([feats_a, feats_b], dim=1)
+        kernel = a.kernel.new_zeros((4, 4, 4, ca + cb, oa + ob))
+        kernel[..., :ca, :oa] = a.kernel
+        kernel[..., ca:, oa:] = b.kernel
+        bias = torch.cat([a.bias, b.bias]) if a.use_bias else None
+        radius = float(np.float32(0.5) * np.float32(extent))
+        nns = _convs._CACHE.search(a.fixed_radius_search, inp_pos, out_pos, radius, distances=False)
+        index, row_splits, raw_dist = nns.raw()
+        out = ops.cconv_forward(kernel, out_pos, extent, inp_pos, feats, index, row_splits, neighbors_value=raw_dist,
+                                window=a.window_function.name, window_fac=a.window_function.fac,
+                                align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
+                                interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
+                                neighbors_row_count=getattr(nns, "row_count", None))
+        a.nns = b.nns = None
+        return out[:, :oa], out[:, oa:]

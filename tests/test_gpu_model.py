@@ -242,6 +242,29 @@ def test_fused_input_convs_equal_the_two_layers(dev, monkeypatch):
         assert _rel(pos, pos0) <= 1e-6
 
 
+def test_cross_layer_paired_convs_equal_the_two_layers(dev, monkeypatch):
+    """HRNet._paired_convs: conv200_2 (layer 2, s2 -> s0) and conv300_2 (layer 3, s2 -> s0) of the Liquid3d net share one
+    neighbour list and run as ONE block-diagonal launch from the second step on -- same step as with the two launches."""
+    from dmcf_amd import ops
+    from dmcf_amd.pipelines import Simulator
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("DMCF_FUSE_CROSS_LAYER", fuse)
+        sim = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+        state = scenes.model_inputs(scenes.box_scene(20, seed=9), device=dev)
+        launches = []
+        for _ in range(3):
+            ops.timer = ops.LaunchTimer()
+            state = sim.step([state])[0]
+            recs, ops.timer = ops.timer.results(), None
+            launches.append(sum(1 for k, m, _ in recs if k == "cconv"))
+        res[fuse] = (state[0].cpu().numpy(), state[1].cpu().numpy(), launches)
+    assert res["0"][2] == [17, 17, 17] and res["1"][2] == [16, 16, 16], (res["0"][2], res["1"][2])  # 18 layers, input pair fused
+    assert _rel(res["1"][0], res["0"][0]) <= 1e-6 and _rel(res["1"][1], res["0"][1]) <= 1e-4
+
+
 def test_liquid3d_momentum_conservation(dev):
     """ASCC head: sum of the network output over fluid + boundary particles vanishes (SURVEY section 4 invariant 4)."""
     from tools import configs, scenes
