@@ -498,8 +498,8 @@ def test_bench_line_contract():
     assert set(d["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"} and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and "model" not in d["config"]
     g = d["roofline_groups"]
-    # 18 layers per step: 4 in the lattice form, the two input layers as one launch
-    assert g["neighbour_list"]["launches"] == 2 * 13 and g["lattice"]["launches"] == 2 * 4
+    # 18 layers per step: 4 in the lattice form, the two input layers as one launch, conv200_2 + conv300_2 as one launch
+    assert g["neighbour_list"]["launches"] == 2 * 12 and g["lattice"]["launches"] == 2 * 4
     assert d["roofline"]["kernel"].startswith("dmcf::cconv_") and d["roofline"]["kernel"][6:] in g["by_kernel"]
     assert 0 < g["lattice"]["frac"] < 1 and 0 < g["neighbour_list"]["frac"] < 1
     assert "frs_query" not in d["kernel_ms_per_step"]
