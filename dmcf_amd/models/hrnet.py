@@ -134,11 +134,12 @@ class HRNet(PBFNet):
         weights differ).  The next layer's input at scale s is this layer's output at scale s, which does not depend on
         this layer's scale-0 convs -- so both convs can run once that output exists: one search-list walk, one geometry
         evaluation per pair instead of two (Liquid3d: conv200_2 + conv300_2, 4 + 8 input channels on the 2.9e8-pair s2 -> s0
-        list).  Restricted to what one 16-channel pass of the class-sorted kernel holds; never inside a sharded step (the
-        ghost exchange is per layer) and never on the first call (the layers build their weights lazily)."""
+        list).  Restricted to what one 16-channel pass of the class-sorted kernel holds; never on the first call (the layers
+        build their weights lazily).  Nothing here depends on particle counts: in a sharded step every rank takes the same
+        branch (the paired launch goes through ``conv_hook`` like any other: one ghost exchange for both feature blocks)."""
         import os
         from ..utils import convolutions as _convs
-        if (os.environ.get("DMCF_FUSE_CROSS_LAYER", "1") == "0" or self.conv_hook is not None or _convs._CACHE.depth == 0
+        if (os.environ.get("DMCF_FUSE_CROSS_LAYER", "1") == "0" or _convs._CACHE.depth == 0
                 or layer + 1 >= len(self.convs) or not self.add_merge or self.voxel_size is None
                 or (self.dens_norm and dens is not None) or len(self.convs[layer][0]) != 1 or len(self.convs[layer + 1][0]) != 1):
             return set()
@@ -174,13 +175,16 @@ class HRNet(PBFNet):
         kernel[..., :ca, :oa] = a.kernel
         kernel[..., ca:, oa:] = b.kernel
         bias = torch.cat([a.bias, b.bias]) if a.use_bias else None
-        radius = float(np.float32(0.5) * np.float32(extent))
-        nns = _convs._CACHE.search(a.fixed_radius_search, inp_pos, out_pos, radius, distances=False)
-        index, row_splits, raw_dist = nns.raw()
-        out = ops.cconv_forward(kernel, out_pos, extent, inp_pos, feats, index, row_splits, neighbors_value=raw_dist,
-                                window=a.window_function.name, window_fac=a.window_function.fac,
-                                align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
-                                interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
-                                neighbors_row_count=getattr(nns, "row_count", None))
+
+        def launch(f, pi, po, ext, _):
+            radius = float(np.float32(0.5) * np.float32(ext))
+            nns = _convs._CACHE.search(a.fixed_radius_search, pi, po, radius, distances=False)
+            index, row_splits, raw_dist = nns.raw()
+            return ops.cconv_forward(kernel, po, ext, pi, f, index, row_splits, neighbors_value=raw_dist,
+                                     window=a.window_function.name, window_fac=a.window_function.fac,
+                                     align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
+                                     interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
+                                     neighbors_row_count=getattr(nns, "row_count", None))
+        out = self.apply_conv(launch, feats, inp_pos, out_pos, extent)
         a.nns = b.nns = None
         return out[:, :oa], out[:, oa:]
