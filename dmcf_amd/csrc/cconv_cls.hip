@@ -347,8 +347,10 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             jA = jB;
             nvA = nvB;
             ld_pos(jA, px, py, pz);
+            // (the stream's LAST batch is peeled off both loops: there is no next batch to prepare -- for rows of ~30 pairs,
+            // one batch per point, that was a quarter of the vector instructions)
             if constexpr (narrow) {
-                for (int t = 0; t < NB; ++t) {
+                for (int t = 0; t + 1 < NB; ++t) {
                     // here: (jA, nvA, px, py, pz) = batch t + 1.  One feature round per batch: the loads of batch t + 1 are
                     // issued before the splat of batch t and published after it.
                     const int nslots = oc.cb[9];
@@ -361,14 +363,18 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                     nvA = nvB;
                     ld_pos(jA, px, py, pz);
                     xfence();
-                    if (t + 1 < NB) f_issue(0, ff);
+                    f_issue(0, ff);
                     splat8(nslots);
                     push_rec(nxt, cl, on.pos);
                     oc = on;
                     if (t == nbA - 1) merge(wave);
                 }
+                f_publish(NB - 1, ff);
+                xfence();
+                splat8(oc.cb[9]);
+                if (NB - 1 == nbA - 1) merge(wave);
             } else {
-                for (int t = 0; t < NB; ++t) {
+                for (int t = 0; t + 1 < NB; ++t) {
                     // here: (jA, nvA, px, py, pz) = batch t + 1.  Every wait on a load below finds that load the youngest one
                     // outstanding (or the younger ones long issued): the counter the hardware offers is in order.
                     const int nslots = oc.cb[9];
@@ -389,7 +395,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                     jA = jB;
                     nvA = nvB;
                     ld_pos(jA, px, py, pz);
-                    if (t + 1 < NB) f_issue(0, ff);
+                    f_issue(0, ff);
                     if (two) {
                         xfence();
                         splat(1, nslots);
@@ -397,6 +403,21 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                     push_rec(nxt, cl, on.pos);
                     oc = on;
                     if (t == nbA - 1) merge(wave);
+                }
+                {
+                    const int nslots = oc.cb[9];
+                    const bool two = nslots > kHalfSlots;
+                    f_publish(NB - 1, ff);
+                    if (two) f_issue(1, ff);
+                    xfence();
+                    splat(0, nslots);
+                    if (two) {
+                        xfence();  // (half 0's staging reads are done)
+                        f_publish(NB - 1, ff);
+                        xfence();
+                        splat(1, nslots);
+                    }
+                    if (NB - 1 == nbA - 1) merge(wave);
                 }
             }
         }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         jA = jB;
         nvA = nvB;
         ld_pos(jA, px, py, pz);
-        for (int t = 0; t < NB; ++t) {
+        for (int t = 0; t + 1 < NB; ++t) {
             // here: (jA, nvA, px, py, pz) = batch t + 1, ff = the features of half 0 of batch t
             const bool two = oc.cb[3] > 32;
             f_publish(ff);
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
             jA = jB;
             nvA = nvB;
             ld_pos(jA, px, py, pz);
-            if (t + 1 < NB) f_issue(0, ff);
+            f_issue(0, ff);
             if (two) {
                 zfence();
                 splat(1, oc);
@@ -311,6 +311,20 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
             zfence();
             push_rec(nxt, cl, on.pos);
             oc = on;
+        }
+        // The row's LAST batch, peeled: there is no next batch to prepare.  Rows of ~30 pairs are this batch only, and the
+        // geometry, order and records of a batch that does not exist were a quarter of their vector instructions.
+        {
+            const bool two = oc.cb[3] > 32;
+            f_publish(ff);
+            if (two) f_issue(1, ff);
+            zfence();
+            splat(0, oc);
+            if (two) {
+                f_publish(ff);
+                zfence();
+                splat(1, oc);
+            }
         }
     }
 
