@@ -505,6 +505,27 @@ def test_bench_line_contract():
     assert "frs_query" not in d["kernel_ms_per_step"]
 
 
+def test_full_size_step_against_the_oracle(dev):
+    """BASELINE.json's bench configuration at FULL size against the CPU oracle: one step of the 100^3-particle box
+    (1,124,864 points, 3.4e9 neighbour pairs; about a minute of the host's cores).  Positions within 1e-5 as north_star
+    asks, and the network output within the float32 noise the 40^3 test measures (a few 1e-6 of the largest correction)."""
+    from oracle.model_ref import ModelRef
+    from dmcf_amd.pipelines import Simulator
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    scene = scenes.box_scene(100)
+    model = _build(configs.LIQUID3D, w, dev)
+    sim = Simulator(model, device="cuda")
+    out = sim.step([scenes.model_inputs(scene, device=dev)])[0]
+    ref = ModelRef(configs.LIQUID3D, w)
+    pos_ref, vel_ref = ref.step(scenes.model_inputs(scene))
+    assert ref.pairs > 3.0e9
+    assert _rel(out[0].cpu().numpy(), pos_ref) <= 1e-5
+    cerr = _rel(model.pos_correction.cpu().numpy(), ref.pos_correction)
+    print(f"full size: pos {_rel(out[0].cpu().numpy(), pos_ref):.2e}, correction {cerr:.2e} (vs the float32 oracle)")
+    assert cerr <= 2e-5
+
+
 def test_full_size_step_properties(dev):
     """BASELINE.json's bench configuration at full size (100^3 fluid + 124,864 boundary particles, Liquid3d weights),
     checked through size-independent properties: the step is bit-reproducible (every kernel has a fixed summation
