@@ -629,6 +629,13 @@ class ShardedSimulator:
 
             if not m.use_bnds and type(m).__name__ == "SymNet":
                 raise NotImplementedError("use_bnds=False with the ASCC head in the sharded path")
+            # every ghost plan the layers will ask for, NOW: a derived plan costs two small host round trips (its selection
+            # sizes), and here the queue is short -- inside the forward pass each would drain it
+            if comm.world > 1:
+                for name in list(self._sets):
+                    for r in m.particle_radii:
+                        if float(r) * (1.0 + 1e-5) + 1e-6 <= self._wide[name].width:
+                            self._plan(name, float(np.float32(0.5) * (np.float32(r) * np.float32(2))))
             out = m.run_forward([sets, feats, None, None], None, training=False)
         finally:
             m.conv_hook = None

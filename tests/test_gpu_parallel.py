@@ -143,3 +143,25 @@ def test_two_processes_one_gpu_match_single_rank(tmp_path):
     pos, vel = _assemble(res, n)
     assert np.abs(pos - pos1).max() <= 1e-5 * np.abs(pos1).max()
     assert np.abs(vel - vel1).max() <= 2e-4 * np.abs(vel1).max()
+
+
+def test_sharded_bench_over_rccl_world1(tmp_path):
+    """The N > 1 code path of bench.py -- ShardedSimulator, BlockDecomposition, the pre-sharded scene pieces, TorchDistComm over
+    the "nccl" (= RCCL) backend -- at world size 1, the most a 1-GPU box can run of it: started the way the driver starts a
+    rank (torch.distributed.run), one JSON line, the same particle count in and out."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, DMCF_BENCH_SHARDED="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--side", "24",
+           "--steps", "2", "--warmup", "2", "--cpu-side", "0"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and "1x1x1 blocks" in d["config"]["parallelism"] and d["value"] > 0
+    assert d["roofline_groups"]["neighbour_list"]["launches"] > 0
