@@ -68,6 +68,11 @@ class HRNet(PBFNet):
             # same values, two thirds fewer elementwise kernels
             relu_in = [relu_next.pop(i) if i in relu_next else torch.relu(t) for i, t in enumerate(ans_convs[-1])]
             relu_next = {}
+            if self.ghost_prefetch is not None and not (self.dens_norm and dens is not None) and self.part_scale == 1.0:
+                # sharded step: every input scale of the layer is known now -- start all their ghost exchanges, the
+                # convolutions pick them up one by one
+                self.ghost_prefetch([(relu_in[i], pos[i], max(filter_extent[max(i, s)] for s in range(n_scales)))
+                                     for i in range(len(relu_in))])
             cross = self._cross_layer_pairs(layer, dens)
             # output scales >= 1 first when a scale-0 conv of this layer is paired with one of the next layer (which reads this
             # layer's output at that scale): the sums do not depend on the order

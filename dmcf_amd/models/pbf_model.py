@@ -140,6 +140,7 @@ class PBFNet(BaseModel):
         return conv
 
     conv_hook = None
+    ghost_prefetch = None  # set together with conv_hook by the sharded driver: see HRNet.forward
 
     def apply_conv(self, conv, feats, inp_pos, out_pos, extent, widest_extent=None):
         """Every ContinuousConv call of the forward pass goes through here: ``conv(feats, inp_pos, out_pos, extent, None)``

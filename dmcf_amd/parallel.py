@@ -61,6 +61,12 @@ class Comm:
         Returns recv with recv[r] = what rank r sent to this rank."""
         return [send[0]]
 
+    def all_to_all_start(self, send, recv_counts):
+        """Start the exchange (the receive counts must be known) and return a zero-argument function that waits for it and
+        returns what :meth:`all_to_all` returns.  Communicators without asynchronous collectives run it right away."""
+        recv = self.all_to_all(send, recv_counts=recv_counts)
+        return lambda: recv
+
 
 class TorchDistComm(Comm):
     """torch.distributed communicator: counts then payload, each one all_to_all_single.  Backend "nccl" (= RCCL over xGMI)
@@ -106,6 +112,26 @@ class TorchDistComm(Comm):
         dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
         parts = torch.split(out.to(dev), rc, dim=0)
         return [p.reshape((p.shape[0],) + trailing) for p in parts]
+
+    def all_to_all_start(self, send, recv_counts):
+        """The payload exchange as an asynchronous collective (RCCL runs it on its own stream, next to whatever the compute
+        stream is doing); ``wait()`` makes the compute stream wait for it.  Staged (gloo) exchanges run synchronously."""
+        if self.stage:
+            return super().all_to_all_start(send, recv_counts)
+        dist = self.dist
+        dev = send[0].device
+        trailing = tuple(send[0].shape[1:])
+        width = int(np.prod(trailing)) if trailing else 1
+        sc = [int(s.shape[0]) for s in send]
+        rc = [int(c) for c in recv_counts]
+        inp = torch.cat([s.reshape(s.shape[0], width) for s in send], dim=0).contiguous()
+        out = torch.empty((sum(rc), width), dtype=inp.dtype, device=dev)
+        work = dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group, async_op=True)
+
+        def wait():
+            work.wait()  # (the current stream waits; ``inp`` / ``out`` stay referenced by this closure until then)
+            return [p.reshape((p.shape[0],) + trailing) for p in torch.split(out, rc, dim=0)]
+        return wait
 
 
 class _LocalHub:
@@ -268,6 +294,11 @@ class SlabDecomposition(BlockDecomposition):
         return SlabDecomposition(axis, [lo + (hi - lo) * r / world for r in range(1, world)])
 
 
+# DMCF_SHARD_FORCE_COMM=1: a single rank still runs every feature exchange (of zero ghost rows) -- the only way to drive the
+# asynchronous RCCL calls of the exchange on a 1-GPU box (tests/test_gpu_parallel.py)
+FORCE_COMM = os.environ.get("DMCF_SHARD_FORCE_COMM") == "1"
+
+
 def _bounds_tensor(decomp, ranks, device):
     """float32 [len(ranks), 3, 2]: (lo, hi) per axis of the blocks of ``ranks``."""
     return torch.tensor([[[lo, hi] for lo, hi in decomp.bounds(r)] for r in ranks], dtype=torch.float32, device=device)
@@ -361,10 +392,18 @@ class GhostPlan:
     def extend(self, feats_owned):
         """[n_owned, C] -> [n_owned + n_ghost, C] (owned rows first, ghosts in the order of ``pos_ext``): one all-to-all-v,
         no host round trip (the counts are the plan's)."""
-        if self.comm.world == 1:
+        if self.comm.world == 1 and not FORCE_COMM:
             return feats_owned
         recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx], recv_counts=self.recv_counts)
         return torch.cat([feats_owned] + recv, dim=0).contiguous()
+
+    def extend_start(self, feats_owned):
+        """:meth:`extend`, started now and finished by the returned function (the exchange overlaps whatever is enqueued in
+        between)."""
+        if self.comm.world == 1 and not FORCE_COMM:
+            return lambda: feats_owned
+        wait = self.comm.all_to_all_start([feats_owned[i] for i in self.send_idx], self.recv_counts)
+        return lambda: torch.cat([feats_owned] + wait(), dim=0).contiguous()
 
     def extend_from(self, wide, wide_ext):
         """``extend`` without communication, from the same features already extended by the wider plan this one derives
@@ -463,22 +502,40 @@ class ShardedSimulator:
         inp = self._name_of[id(inp_pos)]
         plan = self._plan(inp, 0.5 * float(extent))
         n_own = feats.shape[0]
-        if self.comm.world == 1:
+        if self.comm.world == 1 and not FORCE_COMM:
             ext = feats
-        elif widest_extent is None or float(widest_extent) <= float(extent):
-            ext = plan.extend(feats)
-            self.exchanged_rows += ext.shape[0] - n_own
         else:
-            wide = self._plan(inp, 0.5 * float(widest_extent))
+            wider = widest_extent is not None and float(widest_extent) > float(extent)
+            wide = self._plan(inp, 0.5 * float(widest_extent)) if wider else plan
             hit = self._shared.get(id(feats))
-            if hit is None or hit[0] is not feats or hit[1] is not wide:
+            if hit is not None and (hit[0] is not feats or hit[1] is not wide):
+                hit = None
+            if hit is not None and callable(hit[2]):
+                hit = (feats, wide, hit[2]())  # started by _ghost_prefetch when the layer began: finish it now
+                self.exchanged_rows += hit[2].shape[0] - n_own
+                self._shared[id(feats)] = hit
+            if hit is None:
                 hit = (feats, wide, wide.extend(feats))
                 self.exchanged_rows += hit[2].shape[0] - n_own
-                if len(self._shared) >= 4:
-                    self._shared.pop(next(iter(self._shared)))
-                self._shared[id(feats)] = hit
-            ext = plan.extend_from(wide, hit[2])
+                if wider:  # other layers will read the same rows at their own widths
+                    while len(self._shared) >= 4:
+                        self._shared.pop(next(iter(self._shared)))
+                    self._shared[id(feats)] = hit
+            ext = hit[2] if plan is wide else plan.extend_from(wide, hit[2])
         return conv(ext, plan.pos_ext, out_pos, extent, None)
+
+    def _ghost_prefetch(self, requests):
+        """model.ghost_prefetch: a layer is about to read these (features, input positions, widest extent) -- start the ghost
+        exchange of ALL of them now.  The first convolution of the layer waits for its own exchange only; the others travel
+        (RCCL's stream) while it computes."""
+        if (self.comm.world == 1 and not FORCE_COMM) or os.environ.get("DMCF_SHARD_PREFETCH", "1") == "0":
+            return
+        for feats, inp_pos, widest_extent in requests:
+            wide = self._plan(self._name_of[id(inp_pos)], 0.5 * float(widest_extent))
+            if id(feats) not in self._shared:
+                while len(self._shared) >= 4:
+                    self._shared.pop(next(iter(self._shared)))
+                self._shared[id(feats)] = (feats, wide, wide.extend_start(feats))
 
     # -- one step ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -554,6 +611,7 @@ class ShardedSimulator:
         n_fluid = pos.shape[0]
         m.all_pos = all_pos  # the ASCC head convolves all_pos -> all_pos (models/sym_net.py)
         m.conv_hook = self._conv_hook
+        m.ghost_prefetch = self._ghost_prefetch
         try:
             r_max = 0.5 * filter_extent[-1]
             multi = any(s != 1 for s in m.strides)
@@ -639,6 +697,7 @@ class ShardedSimulator:
             out = m.run_forward([sets, feats, None, None], None, training=False)
         finally:
             m.conv_hook = None
+            m.ghost_prefetch = None
 
         # postprocess (pbf_model.py:440-489) on the owned fluid particles
         if out.shape[-1] == 1:

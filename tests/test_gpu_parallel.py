@@ -152,7 +152,9 @@ def test_sharded_bench_over_rccl_world1(tmp_path):
     import json
     import subprocess
     import sys
-    env = dict(os.environ, DMCF_BENCH_SHARDED="1")
+    # (DMCF_SHARD_FORCE_COMM: the feature exchanges -- asynchronous all-to-all-v over RCCL, started when a layer begins -- run
+    # although a single rank has no ghosts)
+    env = dict(os.environ, DMCF_BENCH_SHARDED="1", DMCF_SHARD_FORCE_COMM="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
