@@ -331,9 +331,11 @@ class GhostPlan:
         self.send_idx = [empty] * world
         self.recv_counts = [0] * world
         self.in_parent = None
+        self.parent = parent
         w2 = self.width * self.width
         if world == 1:
             self.ghost_pos = pos_owned[:0]
+            self.in_parent = empty
         elif parent is None:
             peers = decomp.neighbours(rank, self.width)
             if peers and self.n_owned:
@@ -361,7 +363,6 @@ class GhostPlan:
             self.ghost_pos = torch.cat(recv, dim=0)
         else:
             assert parent.n_owned == self.n_owned and self.width <= parent.width
-            self.parent = parent
             # sender side: the rows of the wide lists that are within the narrower width of the peer's block
             peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
             if peers:
