@@ -669,14 +669,18 @@ class ShardedSimulator:
                     # (one tiny all-reduce) holds owned and ghost points alike.  Only the INPUT volumes are that large
                     # (zero-filled, 4 B x Cin per cell); the kernel walks the output box.  A rank without candidates
                     # contributes nothing to the union.
+                    # gbox is None for a rank whose candidate set is empty (it then has no points of this lattice and joins any
+                    # union) -- or whose grid_pos took the sort-based form (bounding box too sparse): its points are NOT known
+                    # to lie in the others' boxes, so the last entry vetoes the lattice form on every rank
                     big_i = 1 << 40
+                    unknown = 1 if (gbox is None and g.shape[0] > 0) else 0
                     if gbox is not None:
                         blo, bdims = list(gbox[0]), list(gbox[1])
                         ext = [v for k in range(3) for v in (-blo[k], blo[k] + bdims[k] - 1)]
                     else:
                         ext = [-big_i] * 6
-                    ext = comm.all_reduce(torch.tensor(ext, dtype=torch.int64, device=dev), "max").tolist()
-                    if ext[0] > -big_i:
+                    ext = comm.all_reduce(torch.tensor(ext + [unknown], dtype=torch.int64, device=dev), "max").tolist()
+                    if ext[0] > -big_i and ext[6] == 0:
                         ulo = [-ext[2 * k] for k in range(3)]
                         udims = [ext[2 * k + 1] + ext[2 * k] + 1 for k in range(3)]
                         self._lattices[name] = (center, [float(v) for v in vs], (ulo, udims), center_host)
