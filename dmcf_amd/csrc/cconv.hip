@@ -612,7 +612,8 @@ int dmcf_cconv_kernel_name(const dmcf_cconv_args* a, char* name, size_t name_byt
     else if (cconv_z3_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_z3_kernel<%d>", ntt);
     else if (cconv_cls_eligible(a, dz, dy, dx))
-        snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false");
+        snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false",
+                 cin <= 16 ? "true" : "false");
     else if (cconv_blk_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_blk_kernel<%d>", ntt);
     else if (cconv_mfma_eligible(dz * dy * dx, cin, cout))

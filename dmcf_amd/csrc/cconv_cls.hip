@@ -63,7 +63,9 @@ __device__ __forceinline__ void xfence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NTT, bool NARROW, bool SYM>
+// SINGLE: the layer is one 16-channel chunk (every layer this kernel serves by default): the contraction's accumulators then
+// live only from the chunk's barrier to the epilogue, not across the batch loop, where every register counts
+template <int NTT, bool NARROW, bool SYM, bool SINGLE>
 __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -423,6 +425,10 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         }
         merge(wave + kCWaves);
         __syncthreads();
+        if constexpr (SINGLE) {
+#pragma unroll
+            for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        }
         // ---------------- contraction of this channel chunk on the matrix cores ----------------
         // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4; blocks of channels past the chunk's end are skipped.
         const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
@@ -558,13 +564,16 @@ int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     const bool sym = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
     const void* fn;
-#define CLS_PICK(NARROW, SYM)                                                                                      \
-    (NT <= 1 ? (const void*)cconv_cls_kernel<1, NARROW, SYM>                                                        \
-             : (NT <= 2 ? (const void*)cconv_cls_kernel<2, NARROW, SYM> : (const void*)cconv_cls_kernel<4, NARROW, SYM>))
+#define CLS_PICK(NARROW, SYM, SINGLE)                                                                              \
+    (NT <= 1 ? (const void*)cconv_cls_kernel<1, NARROW, SYM, SINGLE>                                                \
+             : (NT <= 2 ? (const void*)cconv_cls_kernel<2, NARROW, SYM, SINGLE>                                     \
+                        : (const void*)cconv_cls_kernel<4, NARROW, SYM, SINGLE>))
     if (p.cin <= 8)
-        fn = sym ? CLS_PICK(true, true) : CLS_PICK(true, false);
+        fn = sym ? CLS_PICK(true, true, true) : CLS_PICK(true, false, true);
+    else if (nchunks == 1)
+        fn = sym ? CLS_PICK(false, true, true) : CLS_PICK(false, false, true);
     else
-        fn = sym ? CLS_PICK(false, true) : CLS_PICK(false, false);
+        fn = sym ? CLS_PICK(false, true, false) : CLS_PICK(false, false, false);
 #undef CLS_PICK
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClsLds);
     if (e != hipSuccess) {

@@ -31,6 +31,7 @@ def main():
              ("L8  16->16 s0->s1 R0.2", s0, s1, 0.2, 16, 16, (4, 4, 4), "poly6", False),
              ("L6   8->32 s1->s0 R0.2", s1, s0, 0.2, 8, 32, (4, 4, 4), "poly6", False),
              ("L7   4->32 s1->s0 R0.2", s1, s0, 0.2, 4, 32, (4, 4, 4), "poly6", False),
+             ("LP  12->64 s2->s0 R0.4", grid_pos(s0, np.float32([0.1] * 3), centralize=True), s0, 0.4, 12, 64, (4, 4, 4), "poly6", False),
              ("L4  24->4  s0->s2 R0.4", s0, grid_pos(s0, np.float32([0.1] * 3), centralize=True), 0.4, 24, 4, (4, 4, 4), "poly6", False),
              ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
     for name, inp, out, R, cin, cout, ks, win, sym in cases:
