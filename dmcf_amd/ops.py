@@ -291,18 +291,20 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         stride = max(int(row_stride), 1)
         # allocation sizes in coarse buckets (see pair_capacity): the lattice point sets change size every step
         need = m * stride
-        # 1/4 headroom: the stride moves in steps of ~9 % (row_stride) and the lattice sets change size -- without it a
-        # list that grows a little asks for a fresh, slightly larger multi-GB block (a hipMalloc of 25-150 ms in that step)
-        cap = _size_class(need + need // 4)
+        # 1/2 headroom (HBM is plentiful: the lists of the 1M-particle scene are 9 of 288 GB): the stride moves in steps of ~9 %
+        # (row_stride) while a scene compresses or heats up, and a list that outgrows its buffer asks for a fresh multi-GB
+        # block -- a hipMalloc of 25-150 ms behind a drained queue in that step; run to run the driver's 20-step window of
+        # the bench scene cost 73 or 83 ms per step depending on how long its three reallocations happened to take
+        cap = _size_class(need + need // 2)
         # a caller that repeats this search every step passes the capacity it got last time: while that still fits (and
         # is not grossly oversized) the request stays byte-identical, and the caching allocator answers it without a
         # hipMalloc (a fresh 2 GB block costs 20-120 ms; m * stride hovers around a bucket edge for steps on end)
         if capacity_hint is not None and need <= int(capacity_hint) <= 2 * cap:
             cap = int(capacity_hint)
         elif capacity_hint is not None and need > int(capacity_hint):
-            # outgrown -- a scene that is compressing or heating up keeps growing: 1/2 headroom makes this reallocation the
-            # last one for four or five stride bumps (the rollout of the 1M-particle box outgrew 1/4 five times in 25 steps)
-            cap = _size_class(need + need // 2)
+            # outgrown -- a scene that is compressing or heating up keeps growing: doubling makes this reallocation the last
+            # one for a long while (the rollout of the 1M-particle box outgrew 1/4 headroom five times in 25 steps)
+            cap = _size_class(2 * need)
         index = torch.empty(cap, dtype=torch.int32, device=dev)
         dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
         counts = torch.empty(m, dtype=torch.int32, device=dev)
