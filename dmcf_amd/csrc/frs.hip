@@ -337,8 +337,10 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 if (h2 >= 0.0f) {
                     const float hx = __builtin_amdgcn_sqrtf(h2) * 1.0001f;
                     const float slack = 1e-4f * radius + 4.8e-7f * (fabsf(q[0]) + radius);
-                    const int xlo = max(cell_coord(q[0] - hx - slack, h->origin[0], h->inv_cell[0], h->dims[0]), lo[0]);
-                    const int xhi = min(cell_coord(q[0] + hx + slack, h->origin[0], h->inv_cell[0], h->dims[0]), hi[0]);
+                    // (clamped INTO the grid like lo / hi: a chord that lies entirely beyond the grid's x range still has to
+                    // visit the border cell, which holds the points binned from out there)
+                    const int xlo = max(min(cell_coord(q[0] - hx - slack, h->origin[0], h->inv_cell[0], h->dims[0]), h->dims[0] - 1), lo[0]);
+                    const int xhi = min(max(cell_coord(q[0] + hx + slack, h->origin[0], h->inv_cell[0], h->dims[0]), 0), hi[0]);
                     if (xlo <= xhi) {
                         start = (int32_t)cell_start[base + xlo];
                         len = (int32_t)cell_start[base + xhi + 1] - start;

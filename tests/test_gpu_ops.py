@@ -94,6 +94,25 @@ def test_frs_edge_cases(oracle, dev):
     assert np.all(np.diff(rh) <= np.diff(rs)) and 0 < rs[-1] - rh[-1] < 0.01 * rs[-1]
     # queries far outside the bounding box of the points
     _check_search(oracle, dev, a, b[:100].copy(), 0.2, False)
+    # a bulk plus OUTLIERS with neighbours of their own: the grid covers mean +- 3 sigma of the points (frs_finish_header),
+    # everything beyond is binned into its border cells, and queries out there must still find each other -- small clusters
+    # beyond every face, edge and corner of the bulk's box, a few singles, queries = all points (symmetric lists).  (A first
+    # version of that grid dropped the rows of a query whose whole chord lay beyond the grid's x range: the momentum
+    # residual of the 3200-step rollout went from 1e-7 to 1e-4.)
+    rng = np.random.default_rng(12)
+    bulk = rng.uniform(0, 1, size=(6000, 3)).astype(np.float32)
+    out = []
+    for sx in (-1, 0, 1):
+        for sy in (-1, 0, 1):
+            for sz in (-1, 0, 1):
+                if (sx, sy, sz) != (0, 0, 0):
+                    c = np.float32([0.5 + 25.0 * sx, 0.5 + 17.0 * sy, 0.5 + 31.0 * sz])
+                    out.append(c + rng.uniform(-0.025, 0.025, size=(12, 3)).astype(np.float32))
+    out.append(rng.uniform(-40, 40, size=(30, 3)).astype(np.float32))
+    pts = np.concatenate([bulk] + out).astype(np.float32)
+    for ign in (False, True):
+        idx, rs, d = _check_search(oracle, dev, pts, pts.copy(), 0.1, ign, bruteforce=True)
+        assert int(np.diff(rs)[6000:6000 + 26 * 12].min()) >= (11 if ign else 12)  # every cluster member sees its cluster
     # all points identical
     same = np.zeros((300, 3), np.float32) + np.float32(0.25)
     _check_search(oracle, dev, same, same[:10].copy(), 0.1, False)
