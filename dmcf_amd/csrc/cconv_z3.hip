@@ -361,8 +361,35 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
 #pragma unroll
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     float* Brow = Bt + wave * kZRow;
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
-        const int nch = min(16, cin - 16 * chunk);
+    // The filter fragments of this wave's k' blocks -- blk = (z * 4 + y) * 4 + channel / 4 for t = wave + 16 it, blocks of
+    // channels past the chunk's end are skipped -- are requested for a WHOLE chunk at once, chunk 0's (and, with at most 32
+    // output channels, chunk 1's) before the B rows are written: their round trip runs under the tile's first barrier.  The
+    // loop this replaces loaded a block's fragments right before its matrix instructions: one exposed L2 round trip per
+    // block, 6 - 8 per tile, ~1500 clocks each with all 16 waves of the CU in the same phase (tools/ztrace.py).
+    constexpr int kIt = 64 / kZWaves;          // blocks of a chunk per wave: t = wave + 16 it < 16 nq
+    constexpr bool kBoth = kIt * NTT <= 8;     // registers for the fragments of both chunks
+    auto nq_of = [&](int chunk) { return (min(16, cin - 16 * chunk) + 3) >> 2; };
+    auto w_issue = [&](int chunk, f32x4 (&bw)[kIt][NTT]) {
+        const int nq = nq_of(chunk);
+        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            if (kZWaves * it < 16 * nq) {
+                const int t = wave + kZWaves * it;
+                const int blk = (t / nq) * 4 + t % nq;
+                const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+#pragma unroll
+                for (int n = 0; n < NTT; ++n)
+                    if (n < p.NT) bw[it][n] = *(const f32x4*)(wb + n * 64);
+            }
+        }
+    };
+    f32x4 bw[kBoth ? 2 : 1][kIt][NTT];
+    w_issue(0, bw[0]);
+    if (kBoth && p.nchunks > 1) w_issue(1, bw[kBoth ? 1 : 0]);
+#pragma unroll
+    for (int chunk = 0; chunk < 2; ++chunk) {
+        if (chunk >= p.nchunks) break;
         if ((jn >> 4) == chunk) {
             const int col = ((jn & 15) ^ (wave & 15)) << 2;
 #pragma unroll
@@ -371,24 +398,27 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 for (int yb = 0; yb < 2; ++yb) *(f32x4*)(Brow + (z * 4 + 2 * yb + hk) * 64 + col) = T[z][yb];
         }
         __syncthreads();
-        // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4; blocks of channels past the chunk's end are skipped
-        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
-        const int nq = (nch + 3) >> 2;
-        for (int t = wave; t < 16 * nq; t += kZWaves) {
-            const int blk = (t / nq) * 4 + t % nq;
-            const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
-            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+        const int nq = nq_of(chunk);
+        f32x4(&bc)[kIt][NTT] = bw[kBoth ? chunk : 0];
 #pragma unroll
-            for (int n = 0; n < NTT; ++n) {
-                if (n < p.NT) {
-                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+        for (int it = 0; it < kIt; ++it) {
+            if (kZWaves * it < 16 * nq) {
+                const int t = wave + kZWaves * it;
+                const int blk = (t / nq) * 4 + t % nq;
+                const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+#pragma unroll
+                for (int n = 0; n < NTT; ++n) {
+                    if (n < p.NT) {
+                        const f32x4 bv = bc[it][n];
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                    }
                 }
             }
         }
+        if (!kBoth && chunk + 1 < p.nchunks) w_issue(chunk + 1, bw[0]);
         __syncthreads();
     }
 
