@@ -24,6 +24,14 @@
 #include "cconv_common.h"
 
 namespace dmcf {
+// Diagnostic build (make -C dmcf_amd/csrc trace -> variants/TRACE.so, read by tools/ztrace.py): cycle stamps at the phase
+// boundaries of the kernel, summed over every 16th tile.  Compiled out of the product library.
+#ifdef ZX_TRACE
+__device__ unsigned long long g_ztrace[16];
+#define ZT(k) { const uint64_t now_ = __builtin_readcyclecounter(); zt[k] += now_ - zlast; zlast = now_; }
+#else
+#define ZT(k)
+#endif
 
 constexpr int kZWaves = 16;
 constexpr int kZThreads = 64 * kZWaves;
@@ -284,6 +292,11 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         __builtin_amdgcn_s_setprio(0);
     };
 
+#ifdef ZX_TRACE
+    uint64_t zt[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    uint64_t zlast = __builtin_readcyclecounter();
+    const uint64_t zstart = zlast;
+#endif
     if (NB > 0) {
         int jA, jB, cl;
         float nvA, nvB, px, py, pz;
@@ -300,6 +313,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         jA = jB;
         nvA = nvB;
         ld_pos(jA, px, py, pz);
+        ZT(0)
         for (int t = 0; t + 1 < NB; ++t) {
             // here: (jA, nvA, px, py, pz) = batch t + 1, ff = the features of half 0 of batch t
             const bool two = oc.cb[3] > 32;
@@ -307,25 +321,31 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
             ld_idx(t + 2, jB, nvB);
             if (two) f_issue(1, ff);
             zfence();
+            ZT(1)
             splat(0, oc);
+            ZT(2)
             // geometry + order of the next batch; its indices replace this batch's (all read by now)
             const f32x4 nxt = geom(t + 1, jA, nvA, px, py, pz, cl);
             const Order on = order(cl);
             zfence();
             push_index(jA, cl, on.pos);
             zfence();
+            ZT(3)
             if (two) f_publish(ff);
             jA = jB;
             nvA = nvB;
             ld_pos(jA, px, py, pz);
             f_issue(0, ff);
+            ZT(4)
             if (two) {
                 zfence();
                 splat(1, oc);
             }
+            ZT(5)
             zfence();
             push_rec(nxt, cl, on.pos);
             oc = on;
+            ZT(6)
         }
         // The row's LAST batch, peeled: there is no next batch to prepare.  Rows of ~30 pairs are this batch only, and the
         // geometry, order and records of a batch that does not exist were a quarter of their vector instructions.
@@ -341,6 +361,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 splat(1, oc);
             }
         }
+        ZT(7)
     }
 
     // B_i of this lane's channel jn, rows y = 2 yb + hk: D layout of 32x32x2 is lane (rows 8 b + 4 (lane >> 5) + r, column
@@ -398,6 +419,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 for (int yb = 0; yb < 2; ++yb) *(f32x4*)(Brow + (z * 4 + 2 * yb + hk) * 64 + col) = T[z][yb];
         }
         __syncthreads();
+        if (chunk == 0) { ZT(13) }
         const int nq = nq_of(chunk);
         f32x4(&bc)[kIt][NTT] = bw[kBoth ? chunk : 0];
 #pragma unroll
@@ -422,6 +444,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         __syncthreads();
     }
 
+    ZT(14)
     // ---------------- cross-wave reduction + epilogue ----------------
     float* red = Bt;  // [kZWaves][16][16*NT]
     const int ncol = 16 * p.NT;
@@ -433,6 +456,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         }
     }
     __syncthreads();
+    ZT(15)
     for (int e = tid; e < ZTM * cout; e += kZThreads) {
         const int ptt = e / cout, o = e % cout;
         const int64_t ii = pt0 + ptt;
@@ -445,7 +469,26 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
         *dst = v;
     }
+#ifdef ZX_TRACE
+    ZT(9)
+    if (lane == 0 && (tile & 15) == 0) {
+        for (int k = 0; k < 16; ++k) if (k < 10 || k > 12) atomicAdd(&g_ztrace[k], zt[k]);
+        atomicAdd(&g_ztrace[10], zlast - zstart);
+        atomicAdd(&g_ztrace[11], 1ull);
+        atomicAdd(&g_ztrace[12], (unsigned long long)NB);
+    }
+#endif
 }
+#ifdef ZX_TRACE
+}
+extern "C" int dmcf_ztrace(unsigned long long* out) {
+    unsigned long long z[16] = {0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmcf::g_ztrace), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dmcf::g_ztrace), z, sizeof(z));
+    return 0;
+}
+namespace dmcf {
+#endif
 
 static constexpr size_t kZ3Lds = (size_t)(ZTM * kZRow + kZWaves * kZWaveF) * sizeof(float);
 
