@@ -610,10 +610,10 @@ int dmcf_cconv_kernel_name(const dmcf_cconv_args* a, char* name, size_t name_byt
     if (cconv_direct_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_direct_kernel<%d, %s>", cout, specialised(a) ? "false" : "true");
     else if (cconv_z3_eligible(a, dz, dy, dx))
-        snprintf(name, name_bytes, "cconv_z3_kernel<%d>", ntt);
+        snprintf(name, name_bytes, "cconv_z3_kernel<%d, %s>", ntt, cconv_plain(a) ? "true" : "false");
     else if (cconv_cls_eligible(a, dz, dy, dx))
-        snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false",
-                 cin <= 16 ? "true" : "false");
+        snprintf(name, name_bytes, "cconv_cls_kernel<%d, %s, %s, %s, %s>", ntt, cin <= 8 ? "true" : "false", sym ? "true" : "false",
+                 cin <= 16 ? "true" : "false", !sym && cconv_plain(a) ? "true" : "false");
     else if (cconv_blk_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_blk_kernel<%d>", ntt);
     else if (cconv_mfma_eligible(dz * dy * dx, cin, cout))

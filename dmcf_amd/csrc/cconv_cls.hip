@@ -65,7 +65,8 @@ __device__ __forceinline__ void xfence() {
 
 // SINGLE: the layer is one 16-channel chunk (every layer this kernel serves by default): the contraction's accumulators then
 // live only from the chunk's barrier to the epilogue, not across the batch loop, where every register counts
-template <int NTT, bool NARROW, bool SYM, bool SINGLE>
+// PLAIN: see cconv_plain() in cconv_common.h
+template <int NTT, bool NARROW, bool SYM, bool SINGLE, bool PLAIN>
 __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,6 +80,9 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
     const int64_t pt0 = (int64_t)tile * CTM;
+    const int window = PLAIN ? (int)DMCF_WINDOW_POLY6 : p.window;
+    const float* const nval = PLAIN ? nullptr : p.nval;
+    const float* const imp = PLAIN ? nullptr : p.inp_imp;
     constexpr bool symmetric = SYM;  // the antisymmetric form (a template parameter: plain layers skip its 12 adds per feature round)
 
     // splat roles (A / B operands of 16x16x4): tile row m = lane & 15 = (z', y', x), pair k = lane >> 4, channel lane & 15
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             } else if (ok) {
                 j = p.idx[(pp ? rb1 : rb0) + o];
             }
-            if (p.nval && ok) nv = p.nval[(pp ? rb1 : rb0) + o];
+            if (nval && ok) nv = nval[(pp ? rb1 : rb0) + o];
         };
         auto ld_pos = [&](int j, float& x, float& y, float& z) {  // a scalar base + one 24-bit multiply
             const float* q = (const float*)((const char*)p.inp_pos + (size_t)__umul24((uint32_t)j, 12u));
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             x -= pp ? oxs[1] : oxs[0];
             y -= pp ? oys[1] : oys[0];
             z -= pp ? ozs[1] : ozs[0];
-            float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-            if (p.inp_imp) a *= p.inp_imp[j];
+            float a = window_value(window, nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+            if (imp) a *= imp[j];
             filter_coords<false>(x, y, z, p);
             c.x = fminf(3.0f, fmaxf(0.0f, x));
             y = fminf(3.0f, fmaxf(0.0f, y));
@@ -564,16 +568,20 @@ int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     const bool sym = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
     const void* fn;
-#define CLS_PICK(NARROW, SYM, SINGLE)                                                                              \
-    (NT <= 1 ? (const void*)cconv_cls_kernel<1, NARROW, SYM, SINGLE>                                                \
-             : (NT <= 2 ? (const void*)cconv_cls_kernel<2, NARROW, SYM, SINGLE>                                     \
-                        : (const void*)cconv_cls_kernel<4, NARROW, SYM, SINGLE>))
+    const bool plain = !sym && cconv_plain(a);  // (ASCC's window is not poly6: no antisymmetric plain instantiations)
+#define CLS_PICK(NARROW, SYM, SINGLE, PLAIN)                                                                       \
+    (NT <= 1 ? (const void*)cconv_cls_kernel<1, NARROW, SYM, SINGLE, PLAIN>                                         \
+             : (NT <= 2 ? (const void*)cconv_cls_kernel<2, NARROW, SYM, SINGLE, PLAIN>                              \
+                        : (const void*)cconv_cls_kernel<4, NARROW, SYM, SINGLE, PLAIN>))
+#define CLS_PICK2(NARROW, SINGLE) \
+    (sym ? CLS_PICK(NARROW, true, SINGLE, false) : (plain ? CLS_PICK(NARROW, false, SINGLE, true) : CLS_PICK(NARROW, false, SINGLE, false)))
     if (p.cin <= 8)
-        fn = sym ? CLS_PICK(true, true, true) : CLS_PICK(true, false, true);
+        fn = CLS_PICK2(true, true);
     else if (nchunks == 1)
-        fn = sym ? CLS_PICK(false, true, true) : CLS_PICK(false, false, true);
+        fn = CLS_PICK2(false, true);
     else
-        fn = sym ? CLS_PICK(false, true, false) : CLS_PICK(false, false, false);
+        fn = CLS_PICK2(false, false);
+#undef CLS_PICK2
 #undef CLS_PICK
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kClsLds);
     if (e != hipSuccess) {

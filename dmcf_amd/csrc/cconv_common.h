@@ -235,6 +235,13 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_cls_packed_floats(int cin, int cout);
 int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 int cconv_cls_pack(const dmcf_cconv_args* a, float* packed, hipStream_t stream);  // enqueues the packing, returns the chunk count
+// The "plain" layer: poly6 window on squared distances re-formed from the positions, no per-point importance -- every CConv of
+// the networks here once the lists carry no distances.  Splats D and E have instantiations with these three choices compiled
+// in: the window's branch ladder, the distance / importance loads and their predicates otherwise run once per batch.
+inline bool cconv_plain(const dmcf_cconv_args* a) {
+    return a->window == DMCF_WINDOW_POLY6 && !a->neighbors_value && !a->inp_importance;
+}
+
 // cconv_z3.hip
 bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 int cconv_z3_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);

@@ -67,12 +67,16 @@ __device__ __forceinline__ uint32_t zlds(const void* q) {
 // ("memory": the compiler must not move the staging stores of the batch around these reads)
 #define ZREAD(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
-template <int NTT>
+// PLAIN: see cconv_plain() in cconv_common.h
+template <int NTT, bool PLAIN>
 __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cin = p.cin, cout = p.cout;
+    const int window = PLAIN ? (int)DMCF_WINDOW_POLY6 : p.window;
+    const float* const nval = PLAIN ? nullptr : p.nval;
+    const float* const imp = PLAIN ? nullptr : p.inp_imp;
     float* Bt = smem;                                    // [ZTM][kZRow], 4-float groups XOR-swizzled by the row
     float* Fst = Bt + wave * kZRow;                      // [32 slots][32 channels]: this wave's B row, free until the merge
     float* Rec = smem + ZTM * kZRow + wave * kZWaveF;    // [64 slots][kZRec]
@@ -120,8 +124,8 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     const int NB = (nt + kZPairs - 1) / kZPairs;
     // the row as a buffer of nt entries: entries past its end (and the lanes past a batch's 61 pairs) read as index 0
     const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)(p.idx + rb), 0, nt * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(p.nval ? p.nval + rb : p.inp_pos), 0,
-                                                                         p.nval ? nt * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(nval ? nval + rb : p.inp_pos), 0,
+                                                                         nval ? nt * 4 : 0, 0x00020000);
 
     f32x16 t0, t1, t2;
 #pragma unroll
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     auto ld_idx = [&](int t, int& j, float& nv) {
         const uint32_t off = lane < kZPairs ? (uint32_t)(kZPairs * t + lane) * 4u : kZOob;
         j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, off, 0, 0);
-        nv = p.nval ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rV, off, 0, 0)) : 0.0f;
+        nv = nval ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rV, off, 0, 0)) : 0.0f;
     };
     // (lanes without a pair hold index 0: a valid row, unused.  A scalar base + 32-bit lane offset; the 96-bit buffer load
     // builtin of this compiler loses two of its three components here)
@@ -146,8 +150,8 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
         x -= ox;
         y -= oy;
         z -= oz;
-        float a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-        if (p.inp_imp) a *= p.inp_imp[j];
+        float a = window_value(window, nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+        if (imp) a *= imp[j];
         filter_coords<false>(x, y, z, p);
         c.x = fminf(3.0f, fmaxf(0.0f, x));
         c.y = fminf(3.0f, fmaxf(0.0f, y));
@@ -522,8 +526,13 @@ int cconv_z3_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hi
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
-    const void* fn = NT <= 1 ? (const void*)cconv_z3_kernel<1>
-                             : (NT <= 2 ? (const void*)cconv_z3_kernel<2> : (const void*)cconv_z3_kernel<4>);
+    const void* fn;
+    if (cconv_plain(a))
+        fn = NT <= 1 ? (const void*)cconv_z3_kernel<1, true>
+                     : (NT <= 2 ? (const void*)cconv_z3_kernel<2, true> : (const void*)cconv_z3_kernel<4, true>);
+    else
+        fn = NT <= 1 ? (const void*)cconv_z3_kernel<1, false>
+                     : (NT <= 2 ? (const void*)cconv_z3_kernel<2, false> : (const void*)cconv_z3_kernel<4, false>);
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kZ3Lds);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

@@ -36,11 +36,14 @@ def main():
              ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
     for name, inp, out, R, cin, cout, ks, win, sym in cases:
         if os.environ.get('ONLY') and not any(name.startswith(o) for o in os.environ['ONLY'].split(',')): continue
-        nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=True)
+        # lists without distances, as the networks use them (the window is evaluated on distances re-formed from the positions: the
+        # 'plain' instantiations of splats D / E); MB_DIST=1: with the distance array
+        dist = os.environ.get('MB_DIST') == '1'
+        nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=dist)
         feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
         W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
         f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
-                                      neighbors_value=nns.neighbors_distance, window=win, symmetric=sym, sym_axis=1)
+                                      neighbors_value=nns.neighbors_distance if dist else None, window=win, symmetric=sym, sym_axis=1)
         f()
         ms = timed(f)
         P = nns.neighbors_index.shape[0]
