@@ -40,6 +40,7 @@ class CconvArgs(ctypes.Structure):
         ("out", ctypes.c_void_p),
         ("n_pairs", ctypes.c_int64),
         ("neighbors_row_count", ctypes.c_void_p),
+        ("filter_tile_mask", ctypes.c_uint32),
     ]
 
 

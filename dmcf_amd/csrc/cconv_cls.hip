@@ -441,9 +441,11 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             const int blk = (t / nq) * 4 + t % nq;
             const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % CTM) * kCRow + ((blk * 16 + mg * 4) ^ ((mi % CTM) << 2)));
             const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+            // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
+            const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
 #pragma unroll
             for (int n = 0; n < NTT; ++n) {
-                if (n < p.NT) {
+                if (n < p.NT && ((wm >> n) & 1)) {
                     const f32x4 bv = *(const f32x4*)(wb + n * 64);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);

@@ -32,6 +32,7 @@ struct CconvParams {
     int nblocks;   // sz*PS/16 : 16-wide k blocks per chunk
     int NT;        // ceil(cout/16)
     int nchunks;   // ceil(cin/CC)
+    uint32_t wmask;  // filter blocks worth multiplying: bit 4 * (channel quad) + (16-column tile); all ones without a hint
     int bfloats;   // floats reserved for B / the reduction buffer (whichever is larger)
     int ntiles, tiles_per_xcd;
     int KT;        // matrix-core splat only: number of 16-cell tiles (ceil(K/16))

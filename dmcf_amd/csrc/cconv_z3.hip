@@ -403,9 +403,10 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 const int t = wave + kZWaves * it;
                 const int blk = (t / nq) * 4 + t % nq;
                 const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));  // (all-zero filter blocks: not fetched)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
-                    if (n < p.NT) bw[it][n] = *(const f32x4*)(wb + n * 64);
+                    if (n < p.NT && ((wm >> n) & 1)) bw[it][n] = *(const f32x4*)(wb + n * 64);
             }
         }
     };
@@ -432,9 +433,10 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 const int t = wave + kZWaves * it;
                 const int blk = (t / nq) * 4 + t % nq;
                 const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
 #pragma unroll
                 for (int n = 0; n < NTT; ++n) {
-                    if (n < p.NT) {
+                    if (n < p.NT && ((wm >> n) & 1)) {
                         const f32x4 bv = bc[it][n];
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
                         acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);

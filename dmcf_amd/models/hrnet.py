@@ -180,6 +180,8 @@ class HRNet(PBFNet):
         kernel[..., :ca, :oa] = a.kernel
         kernel[..., ca:, oa:] = b.kernel
         bias = torch.cat([a.bias, b.bias]) if a.use_bias else None
+        # (the two zero blocks of the stacked kernel are neither fetched nor multiplied by the contraction)
+        mask = ops.block_diagonal_tile_mask([(0, ca, 0, oa), (ca, ca + cb, oa, oa + ob)])
 
         def launch(f, pi, po, ext, _):
             radius = float(np.float32(0.5) * np.float32(ext))
@@ -189,7 +191,7 @@ class HRNet(PBFNet):
                                      window=a.window_function.name, window_fac=a.window_function.fac,
                                      align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
                                      interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
-                                     neighbors_row_count=getattr(nns, "row_count", None))
+                                     neighbors_row_count=getattr(nns, "row_count", None), filter_tile_mask=mask)
         out = self.apply_conv(launch, feats, inp_pos, out_pos, extent)
         a.nns = b.nns = None
         return out[:, :oa], out[:, oa:]

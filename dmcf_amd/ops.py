@@ -391,7 +391,7 @@ def _empty(t):
 
 def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                 neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
-                normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None):
+                normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None, filter_tile_mask=0):
     """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
@@ -449,6 +449,7 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     a.out = None if out is None else out.data_ptr()
     a.n_pairs = neighbors_index.shape[0]
     a.neighbors_row_count = None
+    a.filter_tile_mask = int(filter_tile_mask) & 0xffffffff
     if neighbors_row_count is not None:
         if neighbors_row_count.dtype != torch.int32 or neighbors_row_count.shape[0] != n_out:
             raise TypeError("neighbors_row_count must be int32 [n_out]")
@@ -590,12 +591,26 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
     return out
 
 
+def block_diagonal_tile_mask(blocks):
+    """``filter_tile_mask`` of include/dmcf_hip.h for a filter whose only non-zero entries lie in the given blocks
+    ``[(c0, c1, o0, o1), ...]`` (input channels c0 .. c1 - 1 into output channels o0 .. o1 - 1): bit 4 * (c / 4) + o / 16 for
+    every (c, o) of a block.  0 (no hint) when the filter does not fit the mask (c >= 32 or o >= 64)."""
+    mask = 0
+    for c0, c1, o0, o1 in blocks:
+        if c1 > 32 or o1 > 64:
+            return 0
+        for q in range(c0 // 4, (c1 + 3) // 4):
+            for n in range(o0 // 16, (o1 + 15) // 16):
+                mask |= 1 << (4 * q + n)
+    return mask
+
+
 def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
                   normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False,
-                  n_pairs_ref=None, neighbors_row_count=None):
-    """One call of dmcf_cconv_forward.  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
+                  n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0):
+    """One call of dmcf_cconv_forward.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
     """
     L = _lib.lib()
@@ -618,7 +633,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
-                          neighbors_row_count)
+                          neighbors_row_count, filter_tile_mask)
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None

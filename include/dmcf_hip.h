@@ -175,6 +175,12 @@ typedef struct dmcf_cconv_args {
     const int32_t* neighbors_row_count; /* optional [n_out]: PADDED lists as written by dmcf_frs_search_padded -- row i is
                                    neighbors_index[row_splits[i] .. row_splits[i] + row_count[i]); NULL = CSR rows
                                    [row_splits[i], row_splits[i+1]) */
+    uint32_t filter_tile_mask; /* optional hint about filter blocks that are ALL ZERO (the block-diagonal filters of two layers
+                                  launched as one, models/hrnet.py:85-92 twice on one list): bit 4 * (c / 4) + o / 16 is set
+                                  when input channels 4 (c / 4) .. + 3 have a non-zero weight into output channels
+                                  16 (o / 16) .. + 15 in some filter cell (c < 32, o < 64).  0 = no hint (every block is
+                                  multiplied).  Kernels may skip the fetch and the products of unset blocks; results are
+                                  identical for finite features (a skipped product is an exact zero). */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);

@@ -73,3 +73,13 @@ def test_ops_refuse_cpu_tensors(hip_lib):
     from dmcf_amd import ops, _lib
     with pytest.raises(_lib.DmcfError):
         ops.fixed_radius_search(torch.zeros(4, 3), torch.zeros(4, 3), 0.5)
+
+
+def test_block_diagonal_tile_mask():
+    """filter_tile_mask of include/dmcf_hip.h: bit 4 * (c / 4) + o / 16 for the channels / outputs of every non-zero block."""
+    from dmcf_amd import ops
+    # conv200_2 (4 -> 32) + conv300_2 (8 -> 32): quad 0 feeds column tiles 0, 1; quads 1, 2 feed tiles 2, 3
+    assert ops.block_diagonal_tile_mask([(0, 4, 0, 32), (4, 12, 32, 64)]) == 0b1100_1100_0011
+    # blocks that straddle a quad / a tile set both
+    assert ops.block_diagonal_tile_mask([(0, 6, 0, 8), (6, 8, 8, 24)]) == 0b0011_0001
+    assert ops.block_diagonal_tile_mask([(0, 40, 0, 16)]) == 0 and ops.block_diagonal_tile_mask([(0, 4, 0, 80)]) == 0

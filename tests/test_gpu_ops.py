@@ -327,6 +327,40 @@ def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel
         ops.cconv_forward(k, out, 2 * radius, pos, feat, bare.neighbors_index, bare.neighbors_row_splits, window="explicit")
 
 
+@pytest.mark.parametrize("kernel,ca,cb,oa,ob", [("cls", 4, 8, 32, 32), ("cls", 8, 4, 16, 8), ("z3", 8, 16, 32, 32), ("z3", 16, 12, 16, 16),
+                                                  ("blk", 4, 8, 32, 32), (None, 4, 8, 32, 32)])
+def test_filter_tile_mask_of_a_block_diagonal_pair(oracle, dev, monkeypatch, kernel, ca, cb, oa, ob):
+    """Two layers on one list as ONE launch (models/hrnet.py:85-92 twice): features [fa | fb], filters stacked block-diagonally,
+    filter_tile_mask naming the non-zero blocks.  The hint changes nothing (kernels that ignore it included), each half equals
+    its own layer's launch, and the oracle agrees."""
+    from dmcf_amd import ops
+    if kernel:
+        monkeypatch.setenv("DMCF_CCONV_KERNEL", kernel)
+    rng = np.random.default_rng(5)
+    n, m, radius = 2500, 1400, 0.3
+    inp, out = _cloud(n, 51), _cloud(m, 52)
+    fa, fb = rng.normal(size=(n, ca)).astype(np.float32), rng.normal(size=(n, cb)).astype(np.float32)
+    wa = rng.uniform(-1, 1, size=(4, 4, 4, ca, oa)).astype(np.float32)
+    wb = rng.uniform(-1, 1, size=(4, 4, 4, cb, ob)).astype(np.float32)
+    w = np.zeros((4, 4, 4, ca + cb, oa + ob), np.float32)
+    w[..., :ca, :oa], w[..., ca:, oa:] = wa, wb
+    mask = ops.block_diagonal_tile_mask([(0, ca, 0, oa), (ca, ca + cb, oa, oa + ob)])
+    assert mask != 0 and mask != ops.block_diagonal_tile_mask([(0, ca + cb, 0, oa + ob)])
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=False)
+    idx, rs = nns.neighbors_index, nns.neighbors_row_splits
+    call = lambda filt, feat, **kw: ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), idx, rs,
+                                                      window="poly6", **kw)
+    both = np.concatenate([fa, fb], 1)
+    plain, hinted = call(w, both), call(w, both, filter_tile_mask=mask)
+    assert torch.equal(plain, hinted)
+    oi, orr, od = oracle.fixed_radius_search(inp, out, radius, False)
+    imp = oracle.window("poly6", od / np.float32(radius) ** 2)
+    ref_a = oracle.continuous_conv(wa, out, 2 * radius, inp, fa, oi, orr, imp, f64=True)
+    ref_b = oracle.continuous_conv(wb, out, 2 * radius, inp, fb, oi, orr, imp, f64=True)
+    _close(hinted[:, :oa].cpu().numpy(), ref_a)
+    _close(hinted[:, oa:].cpu().numpy(), ref_b)
+
+
 @pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
