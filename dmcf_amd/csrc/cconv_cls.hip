@@ -47,6 +47,34 @@ constexpr int kXst = 512;         // floats per wave outside the B tile: 24 grou
 constexpr int kCMaxNT = 4;
 constexpr int kNoPair = 9;
 
+// The nine class tiles (9 x 4 registers) live in v92 .. v127, outside the compiler's allocation (amdgpu_num_vgpr on the
+// kernel; every asm statement that touches them lists them as clobbered): the splat addresses the accumulator operands of
+// its matrix instruction RELATIVE to M0 = 4 * class (s_set_gpr_idx_on, mode src2 | dst -- it applies to v_mfma on gfx950,
+// tools/ubench/mfma_gpr_idx.hip), which only works on consecutive registers, and a tuple of 36 has no register class.  The
+// computed jump into a table of nine matrix instructions this replaces cost 5 scalar instructions and two taken branches per
+// group of four pairs: 9 % of the 3e8-pair layers (measured with the jump removed).
+#define CLS_TILE_REGS                                                                                                     \
+    "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", \
+        "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121",    \
+        "v122", "v123", "v124", "v125", "v126", "v127"
+// (on gfx90a and later the attribute counts HALF of the unified file -- the compiler doubles it: 46 = v0 .. v91; it also rounds
+// up to the allocation granule of 8)
+constexpr int kClsCompilerVgprs = 46;
+
+__device__ __forceinline__ void cls_zero_tiles() {
+    asm volatile(
+        "v_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\t"
+        "v_mov_b32 v96, 0\n\tv_mov_b32 v97, 0\n\tv_mov_b32 v98, 0\n\tv_mov_b32 v99, 0\n\t"
+        "v_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\t"
+        "v_mov_b32 v104, 0\n\tv_mov_b32 v105, 0\n\tv_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\t"
+        "v_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\tv_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\t"
+        "v_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\t"
+        "v_mov_b32 v116, 0\n\tv_mov_b32 v117, 0\n\tv_mov_b32 v118, 0\n\tv_mov_b32 v119, 0\n\t"
+        "v_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\tv_mov_b32 v122, 0\n\tv_mov_b32 v123, 0\n\t"
+        "v_mov_b32 v124, 0\n\tv_mov_b32 v125, 0\n\tv_mov_b32 v126, 0\n\tv_mov_b32 v127, 0"
+        ::: "memory", CLS_TILE_REGS);
+}
+
 struct ClsRec {  // per pair, in the registers of the owner lane
     float x;     // clamped filter coordinate in [0, 3]
     f32x4 w;     // window * wz(z') * wy(y'), index 2 z' + y'
@@ -67,7 +95,7 @@ __device__ __forceinline__ void xfence() {
 // live only from the chunk's barrier to the epilogue, not across the batch loop, where every register counts
 // PLAIN: see cconv_plain() in cconv_common.h
 template <int NTT, bool NARROW, bool SYM, bool SINGLE, bool PLAIN>
-__global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvParams p) {
+__global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCompilerVgprs))) void cconv_cls_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -139,9 +167,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             nbs[pp] = (nts[pp] + 63) >> 6;
         }
         const int nbA = nbs[0], NB = nbs[0] + nbs[1];
-        f32x4 tl[9];
-#pragma unroll
-        for (int c = 0; c < 9; ++c) tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        cls_zero_tiles();
 
         // ONE buffer over both rows of the wave (they are 8 rows apart in the list): offsets past a row's end are replaced by
         // an out-of-range one and read as index 0 (a valid point, unused)
@@ -230,7 +256,7 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
                 float* g = Gs + (pos >> 2) * kGrp + (pos & 3);
                 g[16] = c.x;
                 *(f32x4*)(g + 3 * (pos & 3)) = c.w;
-                if ((pos & 3) == 0) Cst[pos >> 2] = (unsigned char)(16 * cls + 12);  // see splat
+                if ((pos & 3) == 0) Cst[pos >> 2] = (unsigned char)(4 * cls);  // see splat
             }
         };
         // 16-byte feature loads of half h of the ordered batch (narrow chunks: h = 0, the whole batch): three groups of 16
@@ -260,9 +286,8 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         };
         // Splat of half h: the (at most 12) groups at fixed staging addresses -- no address arithmetic -- each into the tile
         // of its class.  The class of a group is wave uniform: the owner of a group's first slot left it in Cst (as the
-        // byte offset of the class's case), three broadcast reads bring the 12 bytes into scalar registers and a computed
-        // jump picks the in-place matrix instruction.  Hand scheduled (tools/gen_cls_splat.py): with a C++ switch the
-        // compiler copies the nine tiles around every case.
+        // register distance of the class's tile from tile 0), three broadcast reads bring the 12 bytes into scalar registers and
+        // M0-relative addressing picks the accumulator of the matrix instruction.  Hand scheduled (tools/gen_cls_splat.py).
         auto splat = [&](int h, int nslots) {
             const int lo = kHalfSlots * h;
             const int ng = (min(lo + kHalfSlots, nslots) - lo) >> 2;  // wave uniform
@@ -276,11 +301,10 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             uint32_t sc;
             asm volatile(
 #include "cconv_cls_splat.inc"
-                : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]),
-                  "+v"(tl[8]), [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
+                : [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
                   [a] "=&v"(av), [sc] "=&s"(sc)
                 : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2)
-                : "vcc", "scc", "memory");
+                : "scc", "m0", "memory", CLS_TILE_REGS);
         };
         // the same for a whole batch staged with 8 channels per slot (columns 8..15 of the tiles repeat 0..7: never read)
         auto splat8 = [&](int nslots) {
@@ -296,12 +320,11 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
             uint32_t sc;
             asm volatile(
 #include "cconv_cls_splat8.inc"
-                : "+v"(tl[0]), "+v"(tl[1]), "+v"(tl[2]), "+v"(tl[3]), "+v"(tl[4]), "+v"(tl[5]), "+v"(tl[6]), "+v"(tl[7]),
-                  "+v"(tl[8]), [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
+                : [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
                   [a] "=&v"(av), [sc] "=&s"(sc)
                 : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c[0]), [c1] "s"(c[1]),
                   [c2] "s"(c[2]), [c3] "s"(c[3]), [c4] "s"(c[4]), [c5] "s"(c[5])
-                : "vcc", "scc", "memory");
+                : "scc", "m0", "memory", CLS_TILE_REGS);
         };
         // Merge the 9 tiles into the point's B row and clear them.  D layout of 16x16x4: lane (group G = lane >> 4 =
         // (z', y'), channel lane & 15), register r = x  ->  k' = ((bz + z') * 4 + by + y') * 64 + channel * 4 + x.
@@ -309,28 +332,46 @@ __global__ __launch_bounds__(kCThreads, 4) void cconv_cls_kernel(const CconvPara
         // in three rounds of classes with disjoint rows.
         auto merge = [&](int pt) {
             float* Brow = Bt + pt * kCRow;
-            // the tiles were written by hand-issued matrix instructions: cover their write -> VALU read distance here
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
-            xfence();  // the staging lives in the row of the second point
             const int gz = lane >> 5, gy = (lane >> 4) & 1;
             const int col = (mn ^ (pt & 15)) << 2;
-            auto at = [&](int c) { return (f32x4*)(Brow + ((c / 3 + gz) * 4 + (c % 3) + gy) * 64 + col); };
-            auto put = [&](int c) {
-                *at(c) = tl[c];
-                tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            };
-            auto add = [&](int c) {
-                f32x4* q = at(c);
-                *q = *q + tl[c];
-                tl[c] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
-            };
-            put(0); put(2); put(6); put(8);
-            xfence();  // the next round adds to rows other lanes wrote
-            add(1); add(7);
-            xfence();
-            add(3); add(5);
-            xfence();
-            add(4);
+            // tile c goes to rows (c / 3 + gz, c % 3 + gy): byte offset (c / 3) * 1024 + (c % 3) * 256 from this lane's base
+            const uint32_t mb = cls_lds_addr(Brow + (gz * 4 + gy) * 64 + col);
+            xfence();  // the staging lives in the row of the second point
+            asm volatile(
+                // the tiles were written by matrix instructions: cover their write -> read distance
+                "s_nop 7\n\ts_nop 7\n\ts_nop 7\n\t"
+                // The four classes with even (bz, by) tile the 16 (z, y) rows exactly: plain stores.  The other five are added to
+                // them through the registers of tile 0, free once it is stored (the LDS operations of a wave execute in order:
+                // a read finds the stores -- and the sums -- before it; ds_add_f32 instead costs 11 000 clocks per point).
+                "ds_write_b128 %[b], v[92:95] offset:0\n\t"       // class 0
+                "ds_write_b128 %[b], v[100:103] offset:512\n\t"   // class 2
+                "ds_write_b128 %[b], v[116:119] offset:2048\n\t"  // class 6
+                "ds_write_b128 %[b], v[124:127] offset:2560\n\t"  // class 8
+                "ds_read_b128 v[92:95], %[b] offset:256\n\t"  // class 1
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f32 v92, v92, v96\n\tv_add_f32 v93, v93, v97\n\tv_add_f32 v94, v94, v98\n\tv_add_f32 v95, v95, v99\n\t"
+                "ds_write_b128 %[b], v[92:95] offset:256\n\t"
+                "ds_read_b128 v[92:95], %[b] offset:2304\n\t"  // class 7
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f32 v92, v92, v120\n\tv_add_f32 v93, v93, v121\n\tv_add_f32 v94, v94, v122\n\tv_add_f32 v95, v95, v123\n\t"
+                "ds_write_b128 %[b], v[92:95] offset:2304\n\t"
+                "ds_read_b128 v[92:95], %[b] offset:1024\n\t"  // class 3
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f32 v92, v92, v104\n\tv_add_f32 v93, v93, v105\n\tv_add_f32 v94, v94, v106\n\tv_add_f32 v95, v95, v107\n\t"
+                "ds_write_b128 %[b], v[92:95] offset:1024\n\t"
+                "ds_read_b128 v[92:95], %[b] offset:1536\n\t"  // class 5
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f32 v92, v92, v112\n\tv_add_f32 v93, v93, v113\n\tv_add_f32 v94, v94, v114\n\tv_add_f32 v95, v95, v115\n\t"
+                "ds_write_b128 %[b], v[92:95] offset:1536\n\t"
+                "ds_read_b128 v[92:95], %[b] offset:1280\n\t"  // class 4
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_add_f32 v92, v92, v108\n\tv_add_f32 v93, v93, v109\n\tv_add_f32 v94, v94, v110\n\tv_add_f32 v95, v95, v111\n\t"
+                "ds_write_b128 %[b], v[92:95] offset:1280\n\t"
+                "s_waitcnt lgkmcnt(0)"
+                :
+                : [b] "v"(mb)
+                : "memory", CLS_TILE_REGS);
+            cls_zero_tiles();
             xfence();
         };
 
