@@ -40,11 +40,23 @@ constexpr int kZRow = 1024;       // floats per B row: k' = (z * 4 + y) * 64 + c
 constexpr int kZPairs = 61;       // pairs per batch
 constexpr int kZSlots = 64;       // + padding to even class sizes
 constexpr int kZRec = 12;         // floats per slot record: hat(X - x) (4), w[z'] * hat(Y - y) (8)
-constexpr int kZWaveF = kZSlots * kZRec + kZSlots;  // per wave outside the B tile: records + indices
+constexpr int kZWaveF = kZSlots * kZRec + kZSlots + 8;  // per wave outside the B tile: records + indices + 32 class bytes
 constexpr int kZMaxNT = 4;
 constexpr int kZNoPair = 3;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The three plane-class tiles (3 x 16 registers) live in v80 .. v127, outside the compiler's allocation (amdgpu_num_vgpr on
+// the kernel -- on gfx90a and later the attribute counts HALF of the unified file: 40 = v0 .. v79 -- and every asm statement
+// that touches them lists them as clobbered): the splat addresses the accumulator operands of its matrix instruction relative
+// to M0 = 16 * class (s_set_gpr_idx_on, mode src2 | dst; tools/ubench/mfma_gpr_idx.hip), so a group's class is data, not
+// control flow -- no class runs, no single groups between them (tools/gen_z3_splat.py).
+#define Z3_TILE_REGS                                                                                                      \
+    "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96",   \
+        "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", \
+        "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",   \
+        "v126", "v127"
+constexpr int kZ3CompilerVgprs = 40;
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void zfence() {
@@ -69,7 +81,7 @@ __device__ __forceinline__ uint32_t zlds(const void* q) {
 
 // PLAIN: see cconv_plain() in cconv_common.h
 template <int NTT, bool PLAIN>
-__global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParams p) {
+__global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3CompilerVgprs))) void cconv_z3_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -81,6 +93,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     float* Fst = Bt + wave * kZRow;                      // [32 slots][32 channels]: this wave's B row, free until the merge
     float* Rec = smem + ZTM * kZRow + wave * kZWaveF;    // [64 slots][kZRec]
     int* Jst = (int*)(Rec + kZSlots * kZRec);            // [64 slots] neighbour index, -1: padding
+    unsigned char* Cst = (unsigned char*)(Jst + kZSlots);  // [32 groups] 16 * plane class of the group
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
     const int64_t pt0 = (int64_t)tile * ZTM;
@@ -127,9 +140,18 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(nval ? nval + rb : p.inp_pos), 0,
                                                                          nval ? nt * 4 : 0, 0x00020000);
 
-    f32x16 t0, t1, t2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t0[r] = t1[r] = t2[r] = 0.0f;
+    {  // t0 = v[80:95], t1 = v[96:111], t2 = v[112:127]
+        asm volatile(
+            "v_mov_b32 v80, 0\n\tv_mov_b32 v81, 0\n\tv_mov_b32 v82, 0\n\tv_mov_b32 v83, 0\n\tv_mov_b32 v84, 0\n\tv_mov_b32 v85, 0\n\t"
+            "v_mov_b32 v86, 0\n\tv_mov_b32 v87, 0\n\tv_mov_b32 v88, 0\n\tv_mov_b32 v89, 0\n\tv_mov_b32 v90, 0\n\tv_mov_b32 v91, 0\n\t"
+            "v_mov_b32 v92, 0\n\tv_mov_b32 v93, 0\n\tv_mov_b32 v94, 0\n\tv_mov_b32 v95, 0\n\tv_mov_b32 v96, 0\n\tv_mov_b32 v97, 0\n\t"
+            "v_mov_b32 v98, 0\n\tv_mov_b32 v99, 0\n\tv_mov_b32 v100, 0\n\tv_mov_b32 v101, 0\n\tv_mov_b32 v102, 0\n\tv_mov_b32 v103, 0\n\t"
+            "v_mov_b32 v104, 0\n\tv_mov_b32 v105, 0\n\tv_mov_b32 v106, 0\n\tv_mov_b32 v107, 0\n\tv_mov_b32 v108, 0\n\tv_mov_b32 v109, 0\n\t"
+            "v_mov_b32 v110, 0\n\tv_mov_b32 v111, 0\n\tv_mov_b32 v112, 0\n\tv_mov_b32 v113, 0\n\tv_mov_b32 v114, 0\n\tv_mov_b32 v115, 0\n\t"
+            "v_mov_b32 v116, 0\n\tv_mov_b32 v117, 0\n\tv_mov_b32 v118, 0\n\tv_mov_b32 v119, 0\n\tv_mov_b32 v120, 0\n\tv_mov_b32 v121, 0\n\t"
+            "v_mov_b32 v122, 0\n\tv_mov_b32 v123, 0\n\tv_mov_b32 v124, 0\n\tv_mov_b32 v125, 0\n\tv_mov_b32 v126, 0\n\tv_mov_b32 v127, 0"
+            ::: "memory", Z3_TILE_REGS);
+    }
 
     auto valid = [&](int t) -> bool { return lane < kZPairs && kZPairs * t + lane < nt; };
     auto ld_idx = [&](int t, int& j, float& nv) {
@@ -203,6 +225,7 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
             *(f32x4*)(r) = hx;
             *(f32x4*)(r + 4) = c.z * hy;
             *(f32x4*)(r + 8) = c.w * hy;
+            if ((pos & 1) == 0) Cst[pos >> 1] = (unsigned char)(16 * cls);  // (a class has an even number of slots)
         }
     };
     // feature rows of half h of the ordered batch: four groups of 8 slots, lane = (slot, 4 channels)
@@ -223,76 +246,24 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     const uint32_t a_hx = zlds(Rec + kZRec * hk + (lane & 3));
     const uint32_t a_wy = zlds(Rec + kZRec * hk + 4 + 4 * zc + ((lane >> 2) & 3));
     const uint32_t a_f = zlds(Fst + 32 * hk + jn);
-    // Running operand addresses of a half: the three class runs of a half walk its groups in order, so the addresses carry on
-    // from one run into the next (only the accumulator tile changes).
-    uint32_t qx = 0, qw = 0, qf = 0;
-#define ZGROUP4(tl, O)                                                                                                   \
-    {                                                                                                                    \
-        float x0, x1, x2, x3, w0, w1, w2, w3, b0, b1, b2, b3;                                                            \
-        ZREAD(x0, qx, (O) * 384 + 0);                                                                                    \
-        ZREAD(w0, qw, (O) * 384 + 0);                                                                                    \
-        ZREAD(b0, qf, (O) * 1024 + 0);                                                                                   \
-        ZREAD(x1, qx, (O) * 384 + 96);                                                                                   \
-        ZREAD(w1, qw, (O) * 384 + 96);                                                                                   \
-        ZREAD(b1, qf, (O) * 1024 + 256);                                                                                 \
-        ZREAD(x2, qx, (O) * 384 + 192);                                                                                  \
-        ZREAD(w2, qw, (O) * 384 + 192);                                                                                  \
-        ZREAD(b2, qf, (O) * 1024 + 512);                                                                                 \
-        ZREAD(x3, qx, (O) * 384 + 288);                                                                                  \
-        ZREAD(w3, qw, (O) * 384 + 288);                                                                                  \
-        ZREAD(b3, qf, (O) * 1024 + 768);                                                                                 \
-        asm volatile("s_waitcnt lgkmcnt(0)"                                                                              \
-                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3), "+v"(b0), "+v"(b1), \
-                       "+v"(b2), "+v"(b3));                                                                              \
-        const float a0 = w0 * x0, a1 = w1 * x1, a2 = w2 * x2, a3 = w3 * x3;                                              \
-        /* the four dependent matrix instructions back to back: an instruction of this wave between two of them costs */ \
-        /* ~40 clocks of the matrix pipe (MI355X_MICROARCH.md) */                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-        tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, tl, 0, 0, 0);                                                  \
-        tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, tl, 0, 0, 0);                                                  \
-        tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a2, b2, tl, 0, 0, 0);                                                  \
-        tl = __builtin_amdgcn_mfma_f32_32x32x2f32(a3, b3, tl, 0, 0, 0);                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                               \
-    }
-    // n groups of one plane class into that class's tile: eight at a time (24 reads at immediate offsets, one multiply per
-    // matrix instruction, three address bumps), then four, then single groups
-    auto run = [&](f32x16& tl, int n) {
-        for (; n >= 8; n -= 8) {
-            ZGROUP4(tl, 0)
-            ZGROUP4(tl, 1)
-            qx += 8u * 8u * kZRec;
-            qw += 8u * 8u * kZRec;
-            qf += 2048u;
-        }
-        if (n >= 4) {
-            ZGROUP4(tl, 0)
-            qx += 4u * 8u * kZRec;
-            qw += 4u * 8u * kZRec;
-            qf += 1024u;
-            n -= 4;
-        }
-        for (; n > 0; --n) {
-            float x0, w0, b0;
-            ZREAD(x0, qx, 0);
-            ZREAD(w0, qw, 0);
-            ZREAD(b0, qf, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x0), "+v"(w0), "+v"(b0));
-            tl = __builtin_amdgcn_mfma_f32_32x32x2f32(w0 * x0, b0, tl, 0, 0, 0);
-            qx += 8u * kZRec;
-            qw += 8u * kZRec;
-            qf += 256u;
-        }
-    };
+    // Half h of the ordered batch: groups 16 h .. min(16 h + 16, slots / 2) - 1 at fixed staging addresses, their classes as 16
+    // bytes in four scalar registers (tools/gen_z3_splat.py).
     auto splat = [&](int h, const Order& o) {
-        const int lo = 16 * h, hi = min(16 * h + 16, o.cb[3] >> 1);
-        const int c1 = min(max(o.cb[1] >> 1, lo), hi), c2 = min(max(o.cb[2] >> 1, lo), hi);  // class boundaries inside the half
-        qx = a_hx + (uint32_t)(8 * kZRec) * (uint32_t)lo;   // 2 slots x kZRec floats x 4 bytes per group
-        qw = a_wy + (uint32_t)(8 * kZRec) * (uint32_t)lo;
-        qf = a_f;                                           // the staging holds this half's slots from its start
+        const int ng = min(16, (o.cb[3] >> 1) - 16 * h);  // wave uniform
+        const uint32_t px = a_hx + (uint32_t)(8 * kZRec * 16) * (uint32_t)h;
+        const uint32_t pw = a_wy + (uint32_t)(8 * kZRec * 16) * (uint32_t)h;
+        const u32x4z cw = *(const u32x4z*)(Cst + 16 * h);
+        const uint32_t c0 = __builtin_amdgcn_readfirstlane(cw.x), c1 = __builtin_amdgcn_readfirstlane(cw.y),
+                       c2 = __builtin_amdgcn_readfirstlane(cw.z), c3 = __builtin_amdgcn_readfirstlane(cw.w);
+        float x0, x1, x2, x3, w0, w1, w2, w3, f0, f1, f2, f3;
+        uint32_t s0, s1;
         __builtin_amdgcn_s_setprio(3);  // the wave that reaches its splat first gets the matrix pipe: -3 .. 7 %
-        run(t0, c1 - lo);
-        run(t1, c2 - c1);
-        run(t2, hi - c2);
+        asm volatile(
+#include "cconv_z3_splat.inc"
+            : [x0] "=&v"(x0), [x1] "=&v"(x1), [x2] "=&v"(x2), [x3] "=&v"(x3), [w0] "=&v"(w0), [w1] "=&v"(w1), [w2] "=&v"(w2),
+              [w3] "=&v"(w3), [f0] "=&v"(f0), [f1] "=&v"(f1), [f2] "=&v"(f2), [f3] "=&v"(f3), [s0] "=&s"(s0), [s1] "=&s"(s1)
+            : [px] "v"(px), [pw] "v"(pw), [pf] "v"(a_f), [ng] "s"(ng), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2), [c3] "s"(c3)
+            : "scc", "m0", "memory", Z3_TILE_REGS);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -371,16 +342,10 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     // B_i of this lane's channel jn, rows y = 2 yb + hk: D layout of 32x32x2 is lane (rows 8 b + 4 (lane >> 5) + r, column
     // lane & 31), register 4 b + r; with m = z' * 16 + y * 4 + x that is z' = b >> 1, y = 2 (b & 1) + hk, x = r.  Planes
     // shared by two classes are added here, in registers: no read-modify-write in LDS.
-    f32x4 T[4][2];
-#pragma unroll
-    for (int yb = 0; yb < 2; ++yb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            T[0][yb][r] = t0[4 * yb + r];
-            T[1][yb][r] = t0[4 * (2 + yb) + r] + t1[4 * yb + r];
-            T[2][yb][r] = t1[4 * (2 + yb) + r] + t2[4 * yb + r];
-            T[3][yb][r] = t2[4 * (2 + yb) + r];
-        }
+    // The merged tile stays in the fixed registers, in place: plane 0 = v80 .. v87, plane 1 = v88 .. v95 (+= t1's lower half),
+    // plane 2 = v104 .. v111 (+= t2's lower half), plane 3 = v120 .. v127 -- the contraction below has the compiler's 80
+    // registers to itself.  (The tiles were written by matrix instructions: the s_nops cover their write -> read distance.)
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\tv_add_f32 v88, v88, v96\n\tv_add_f32 v89, v89, v97\n\tv_add_f32 v90, v90, v98\n\tv_add_f32 v91, v91, v99\n\tv_add_f32 v92, v92, v100\n\tv_add_f32 v93, v93, v101\n\tv_add_f32 v94, v94, v102\n\tv_add_f32 v95, v95, v103\n\tv_add_f32 v104, v104, v112\n\tv_add_f32 v105, v105, v113\n\tv_add_f32 v106, v106, v114\n\tv_add_f32 v107, v107, v115\n\tv_add_f32 v108, v108, v116\n\tv_add_f32 v109, v109, v117\n\tv_add_f32 v110, v110, v118\n\tv_add_f32 v111, v111, v119" ::: "memory", Z3_TILE_REGS);
 
     f32x4 acc[NTT];
 #pragma unroll
@@ -392,13 +357,17 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
     // loop this replaces loaded a block's fragments right before its matrix instructions: one exposed L2 round trip per
     // block, 6 - 8 per tile, ~1500 clocks each with all 16 waves of the CU in the same phase (tools/ztrace.py).
     constexpr int kIt = 64 / kZWaves;          // blocks of a chunk per wave: t = wave + 16 it < 16 nq
-    constexpr bool kBoth = kIt * NTT <= 8;     // registers for the fragments of both chunks
+    // (fragments + accumulators must fit the compiler's 80 registers: both chunks at once up to two column tiles, two
+    // blocks at a time for four)
+    constexpr int kPre = NTT <= 2 ? kIt : 2;   // blocks whose fragments are requested together
+    constexpr bool kBoth = NTT <= 2;           // registers for the fragments of both chunks
     auto nq_of = [&](int chunk) { return (min(16, cin - 16 * chunk) + 3) >> 2; };
-    auto w_issue = [&](int chunk, f32x4 (&bw)[kIt][NTT]) {
+    auto w_issue = [&](int chunk, int it0, f32x4 (&bw)[kPre][NTT]) {
         const int nq = nq_of(chunk);
         const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
 #pragma unroll
-        for (int it = 0; it < kIt; ++it) {
+        for (int q = 0; q < kPre; ++q) {
+            const int it = it0 + q;
             if (kZWaves * it < 16 * nq) {
                 const int t = wave + kZWaves * it;
                 const int blk = (t / nq) * 4 + t % nq;
@@ -406,47 +375,56 @@ __global__ __launch_bounds__(kZThreads, 1) void cconv_z3_kernel(const CconvParam
                 const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));  // (all-zero filter blocks: not fetched)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
-                    if (n < p.NT && ((wm >> n) & 1)) bw[it][n] = *(const f32x4*)(wb + n * 64);
+                    if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
             }
         }
     };
-    f32x4 bw[kBoth ? 2 : 1][kIt][NTT];
-    w_issue(0, bw[0]);
-    if (kBoth && p.nchunks > 1) w_issue(1, bw[kBoth ? 1 : 0]);
+    f32x4 bw[kBoth ? 2 : 1][kPre][NTT];
+    w_issue(0, 0, bw[0]);
+    if (kBoth && p.nchunks > 1) w_issue(1, 0, bw[kBoth ? 1 : 0]);
 #pragma unroll
     for (int chunk = 0; chunk < 2; ++chunk) {
         if (chunk >= p.nchunks) break;
         if ((jn >> 4) == chunk) {
             const int col = ((jn & 15) ^ (wave & 15)) << 2;
-#pragma unroll
-            for (int z = 0; z < 4; ++z)
-#pragma unroll
-                for (int yb = 0; yb < 2; ++yb) *(f32x4*)(Brow + (z * 4 + 2 * yb + hk) * 64 + col) = T[z][yb];
+            // row (z * 4 + 2 yb + hk) of the B row: byte offset z * 1024 + yb * 512 from this lane's base
+            const uint32_t rb = zlds(Brow + hk * 64 + col);
+            asm volatile(
+                "ds_write_b128 %0, v[80:83] offset:0\n\tds_write_b128 %0, v[84:87] offset:512\n\t"
+                "ds_write_b128 %0, v[88:91] offset:1024\n\tds_write_b128 %0, v[92:95] offset:1536\n\t"
+                "ds_write_b128 %0, v[104:107] offset:2048\n\tds_write_b128 %0, v[108:111] offset:2560\n\t"
+                "ds_write_b128 %0, v[120:123] offset:3072\n\tds_write_b128 %0, v[124:127] offset:3584"
+                :: "v"(rb) : "memory", Z3_TILE_REGS);
         }
         __syncthreads();
         if (chunk == 0) { ZT(13) }
         const int nq = nq_of(chunk);
-        f32x4(&bc)[kIt][NTT] = bw[kBoth ? chunk : 0];
+        f32x4(&bc)[kPre][NTT] = bw[kBoth ? chunk : 0];
 #pragma unroll
-        for (int it = 0; it < kIt; ++it) {
-            if (kZWaves * it < 16 * nq) {
-                const int t = wave + kZWaves * it;
-                const int blk = (t / nq) * 4 + t % nq;
-                const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
-                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
+        for (int it0 = 0; it0 < kIt; it0 += kPre) {
 #pragma unroll
-                for (int n = 0; n < NTT; ++n) {
-                    if (n < p.NT && ((wm >> n) & 1)) {
-                        const f32x4 bv = bc[it][n];
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
-                        acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+            for (int q = 0; q < kPre; ++q) {
+                const int it = it0 + q;
+                if (kZWaves * it < 16 * nq) {
+                    const int t = wave + kZWaves * it;
+                    const int blk = (t / nq) * 4 + t % nq;
+                    const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+                    const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
+#pragma unroll
+                    for (int n = 0; n < NTT; ++n) {
+                        if (n < p.NT && ((wm >> n) & 1)) {
+                            const f32x4 bv = bc[q][n];
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                        }
                     }
                 }
             }
+            if (it0 + kPre < kIt && kZWaves * (it0 + kPre) < 16 * nq) w_issue(chunk, it0 + kPre, bw[kBoth ? chunk : 0]);
         }
-        if (!kBoth && chunk + 1 < p.nchunks) w_issue(chunk + 1, bw[0]);
+        if (!kBoth && chunk + 1 < p.nchunks) w_issue(chunk + 1, 0, bw[0]);
         __syncthreads();
     }
 
