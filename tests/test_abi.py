@@ -83,3 +83,22 @@ def test_block_diagonal_tile_mask():
     # blocks that straddle a quad / a tile set both
     assert ops.block_diagonal_tile_mask([(0, 6, 0, 8), (6, 8, 8, 24)]) == 0b0011_0001
     assert ops.block_diagonal_tile_mask([(0, 40, 0, 16)]) == 0 and ops.block_diagonal_tile_mask([(0, 4, 0, 80)]) == 0
+
+
+def test_generated_splat_sources_are_current(tmp_path, monkeypatch):
+    """dmcf_amd/csrc/cconv_*_splat*.inc are generated (tools/gen_cls_splat.py, tools/gen_z3_splat.py) and committed: the
+    committed text must be what the generators write."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "dmcf_amd", "csrc")
+    names = ["cconv_cls_splat.inc", "cconv_cls_splat8.inc", "cconv_z3_splat.inc"]
+    committed = {n: open(os.path.join(csrc, n)).read() for n in names}
+    real_join = os.path.join
+    # the generators write next to the kernels: send their output to a scratch directory instead
+    monkeypatch.setattr(os.path, "join", lambda *a: real_join(str(tmp_path), a[-1]) if a[-1] in names else real_join(*a))
+    for gen in ("gen_cls_splat", "gen_z3_splat"):
+        spec = importlib.util.spec_from_file_location(gen, real_join(root, "tools", gen + ".py"))
+        spec.loader.exec_module(importlib.util.module_from_spec(spec))
+    for n in names:
+        assert open(real_join(str(tmp_path), n)).read() == committed[n], n
