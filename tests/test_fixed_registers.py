@@ -1,0 +1,57 @@
+"""Build-time contract of the splat kernels that keep their class tiles in FIXED registers (cconv_cls.hip: v92 .. v127,
+cconv_z3.hip: v80 .. v127): the compiler must stay below them -- that rests on how this toolchain reads
+`amdgpu_num_vgpr` (half of the unified register file on gfx90a and later) -- and the kernel descriptors must still ask for all
+128 registers.  Cross-compiles the two files to assembly (no GPU needed) and reads it."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dmcf_amd", "csrc")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _assembly(tmp_path, name, extra=()):
+    out = tmp_path / (name + ".s")
+    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", *extra, "--cuda-device-only", "-S",
+           os.path.join(CSRC, name + ".hip"), "-o", str(out)]
+    subprocess.run(cmd, check=True, capture_output=True, timeout=900)
+    return out.read_text().split("\n")
+
+
+def _highest_compiler_register(lines):
+    """Highest VGPR number in instructions the COMPILER emitted (outside inline asm), per kernel."""
+    per_kernel, kernel, inasm = {}, None, False
+    for l in lines:
+        m = re.match(r"^(_ZN4dmcf\w+):", l)
+        if m:
+            kernel = m.group(1)
+            per_kernel[kernel] = -1
+            continue
+        if "ASMSTART" in l:
+            inasm = True
+        elif "ASMEND" in l:
+            inasm = False
+        if kernel is None or inasm or not l.startswith("\t") or l.lstrip().startswith((".", ";")):
+            continue
+        code = l.split(";")[0]
+        regs = [int(x) for x in re.findall(r"\bv(\d+)\b", code)] + [int(b) for _, b in re.findall(r"v\[(\d+):(\d+)\]", code)]
+        if regs:
+            per_kernel[kernel] = max(per_kernel[kernel], max(regs))
+    return per_kernel
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
+@pytest.mark.parametrize("name,first_tile,extra", [("cconv_z3", 80, ()), ("cconv_cls", 92, ("-fno-slp-vectorize",))])
+def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, extra):
+    lines = _assembly(tmp_path, name, extra)
+    top = {k: v for k, v in _highest_compiler_register(lines).items() if "kernel" in k and "pack" not in k}
+    assert top, "no kernels found"
+    for kernel, reg in top.items():
+        assert 0 <= reg < first_tile, f"{kernel}: the compiler uses v{reg}, the tiles start at v{first_tile}"
+    text = "\n".join(lines)
+    counts = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", text)]
+    assert counts.count(128) >= len(top)  # every splat kernel owns all 128 registers (tiles included)
+    assert f"v[{first_tile}:{first_tile + (15 if name == 'cconv_z3' else 3)}]" in text
