@@ -189,7 +189,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
                        dmcf_stream_t stream);
 /* Diagnostics: the name of the device kernel dmcf_cconv_forward dispatches these arguments to (the dispatch looks at the
  * layer -- filter shape, channel counts, flags -- never at the neighbour list), as rocprofv3 prints it without the
- * namespace, e.g. "cconv_z3_kernel<1>".  bench.py groups its per-launch HIP-event timings by it. */
+ * namespace, e.g. "cconv_z3_kernel<1, true>".  bench.py groups its per-launch HIP-event timings by it. */
 int dmcf_cconv_kernel_name(const dmcf_cconv_args* args, char* name, size_t name_bytes);
 
 /* ------------------------------------------------------------------------------------------------
