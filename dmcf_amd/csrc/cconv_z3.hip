@@ -17,8 +17,10 @@
 // hands it to the contraction in two halves of 16 channels through the 64 KB B tile the other kernels use.
 //
 // Per 61-pair batch (61 pairs + at most 3 padding slots = 64 slots = 32 instructions): geometry (lane = pair), order by
-// plane with 3 ballots, {X, Y, w0, w1} and the index to the pair's slot, feature rows of half a batch at a time by 16-byte
-// loads (lane = (slot, 4 channels)) into a 4 KB staging area, one ds_read per operand and instruction.
+// plane with 3 ballots, the slot's record (the four hat(X - x) and the eight w[z'] hat(Y - y)), its feature row's offset and
+// its group's class byte to the pair's slot, feature rows of half a batch at a time by 16-byte loads (lane = (slot, 4
+// channels)) into a 4 KB staging area; the splat of a half is one hand-scheduled block (tools/gen_z3_splat.py): groups of two
+// slots at static staging offsets, three ds_read_b32 and one multiply per matrix instruction, the tile picked by M0.
 #include <stdlib.h>
 
 #include "cconv_common.h"
@@ -44,7 +46,6 @@ constexpr int kZWaveF = kZSlots * kZRec + kZSlots + 8;  // per wave outside the 
 constexpr int kZMaxNT = 4;
 constexpr int kZNoPair = 3;
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // The three plane-class tiles (3 x 16 registers) live in v80 .. v127, outside the compiler's allocation (amdgpu_num_vgpr on
 // the kernel -- on gfx90a and later the attribute counts HALF of the unified file: 40 = v0 .. v79 -- and every asm statement
@@ -57,7 +58,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
         "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125",   \
         "v126", "v127"
 constexpr int kZ3CompilerVgprs = 40;
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void zfence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -74,10 +74,6 @@ constexpr uint32_t kZOob = 0xffffffffu;  // a byte offset no buffer holds: the l
 __device__ __forceinline__ uint32_t zlds(const void* q) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)q;
 }
-// ds_read_b32 at an IMMEDIATE offset from a lane address: the splat loop then has no address arithmetic (the compiler's
-// form of the same loop advanced six pointers per four matrix instructions: 21 VALU operations, 12 of them useful)
-// ("memory": the compiler must not move the staging stores of the batch around these reads)
-#define ZREAD(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off) : "memory")
 
 // PLAIN: see cconv_plain() in cconv_common.h
 template <int NTT, bool PLAIN>
