@@ -17,8 +17,8 @@
 //   3. pushes {X, w[4]}, the class of each group of 4 slots and the neighbour index to the pair's slot of the ordered
 //      batch in LDS, and loads the feature rows of the ordered slots (16 bytes per lane, half a batch ahead),
 //   4. splats: a hand-scheduled block (tools/gen_cls_splat.py -> cconv_cls_splat.inc) reads each group's operands at
-//      fixed LDS offsets, one group ahead, and jumps to the in-place matrix instruction of the group's class tile:
-//      36 VGPRs hold the whole 64-cell x 16-channel B_i of the output point.
+//      fixed LDS offsets, one group ahead, and issues ONE matrix instruction whose accumulator registers are addressed
+//      relative to M0 = 4 * class: 36 VGPRs (v92 .. v127, see below) hold the whole 64-cell x 16-channel B_i of the point.
 // When a point's last batch is done its 9 tiles are merged into the point's row of the B tile [16 points][64 cells x 16
 // channels] in LDS (four stores, five 4-float read-modify-writes), which the contraction with the packed filter reads as
 // in cconv_blk.hip.

@@ -245,9 +245,15 @@ def reserve_device_memory(gib, device=None):
     """Hand ``gib`` GiB of device memory to torch's caching allocator as ONE segment and release it into the pool (the
     allocator splits a cached block, it cannot join two segments): the multi-GB list buffers of a rollout -- and the bigger
     ones a scene grows into -- are then carved out of memory the process already owns instead of a fresh hipMalloc in the
-    middle of a step (0.1 - 0.3 s each on an MI355X, with everything else queued behind it).  Optional; one GPU has 288 GB."""
-    block = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=device)
+    middle of a step (0.1 - 0.3 s each on an MI355X, with everything else queued behind it).  Optional; one GPU has 288 GB.
+    Returns the GiB actually reserved (0 when the device does not have that much to spare: the rollout then allocates as it
+    goes)."""
+    try:
+        block = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=device)
+    except torch.cuda.OutOfMemoryError:
+        return 0.0
     del block
+    return float(gib)
 
 
 def pair_capacity(total):
