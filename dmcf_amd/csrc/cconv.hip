@@ -555,6 +555,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.bias = a->bias;
     p.out = a->out;
     if (cconv_direct_eligible(a, dz, dy, dx)) return cconv_direct_launch(p, a, dz, dy, dx, workspace, stream);
+    if (a->flags & DMCF_FLAG_SKIP_SELF) return DMCF_EUNSUPPORTED;  // (only the direct form tests the index against the row)
     if (cconv_z3_eligible(a, dz, dy, dx)) return cconv_z3_launch(p, a, workspace, stream);
     if (cconv_cls_eligible(a, dz, dy, dx)) return cconv_cls_launch(p, a, workspace, stream);
     if (cconv_blk_eligible(a, dz, dy, dx)) return cconv_blk_launch(p, a, workspace, stream);

@@ -155,7 +155,7 @@ MAPPINGS = {"ball_to_cube_radial": 0, "ball_to_cube_volume_preserving": 1, "iden
 INTERPOLATIONS = {"linear": 0, "linear_border": 1, "nearest_neighbor": 2}
 WINDOWS = {None: 0, "explicit": 1, "poly6": 2, "cubic": 3, "linear": 4, "peak": 5, "cubic_grad": 6}
 
-FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE = 1, 2, 4, 8
+FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE, FLAG_SKIP_SELF = 1, 2, 4, 8, 16
 
 
 class LaunchTimer:
@@ -413,7 +413,8 @@ def _empty(t):
 
 def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                 neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
-                normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None, filter_tile_mask=0):
+                normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None, filter_tile_mask=0,
+                skip_self=False):
     """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
@@ -466,7 +467,7 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     a.coordinate_mapping = MAPPINGS[coordinate_mapping]
     a.interpolation = INTERPOLATIONS[interpolation]
     a.flags = ((FLAG_ALIGN_CORNERS if align_corners else 0) | (FLAG_NORMALIZE if normalize else 0) |
-               (FLAG_SYMMETRIC if symmetric else 0) | (FLAG_ACCUMULATE if accumulate else 0))
+               (FLAG_SYMMETRIC if symmetric else 0) | (FLAG_ACCUMULATE if accumulate else 0) | (FLAG_SKIP_SELF if skip_self else 0))
     a.bias = None if bias is None else bias.data_ptr()
     a.out = None if out is None else out.data_ptr()
     a.n_pairs = neighbors_index.shape[0]
@@ -631,8 +632,8 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
                   normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False,
-                  n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0):
-    """One call of dmcf_cconv_forward.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
+                  n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False):
+    """One call of dmcf_cconv_forward.  ``skip_self``: DMCF_FLAG_SKIP_SELF (the list holds the query points, the layer ignores them; only the direct kernel).  ``name_only``: no launch, returns the name of the kernel these arguments dispatch to.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
     """
     L = _lib.lib()
@@ -655,7 +656,11 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
-                          neighbors_row_count, filter_tile_mask)
+                          neighbors_row_count, filter_tile_mask, skip_self)
+    if name_only:
+        name = ctypes.create_string_buffer(96)
+        _lib.check(L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96), "dmcf_cconv_kernel_name")
+        return name.value.decode()
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None

@@ -126,6 +126,24 @@ class _NeighborCache:
             self.lists.pop(key, None)
             self.done.append(res)
 
+    def with_query_points(self, frs, points, queries, radius):
+        """For a search that ignores the query points (``frs.ignore_query_point``) over points == queries: the list of the
+        SAME search with them, if this step already holds one without distances -- the caller's kernel then skips the pairs
+        (i, i) itself (DMCF_FLAG_SKIP_SELF) and the second search of the same point set is not run (the ASCC head after the
+        trunk's same-scale layers).  Counts as a consumer of that list.  None when there is nothing to share."""
+        if self.depth == 0 or not frs.ignore_query_point:
+            return None
+        points = points.contiguous()
+        queries = queries.contiguous()
+        if self._key(points) != self._key(queries):
+            return None
+        key = ((self._key(points), float(radius)), self._key(queries), False, False)
+        hit = self.lists.get(key)
+        if hit is not None:
+            self._flush()
+            self._consumer(key, hit)
+        return hit
+
     def search(self, frs, points, queries, radius, distances=True):
         """``distances=False``: the caller evaluates its window in the kernel, which re-forms d^2 from the positions
         (dmcf_hip.h, neighbors_value == NULL) -- inside a step the list then carries no distance array: half the bytes the
@@ -314,6 +332,7 @@ class ContinuousConv(torch.nn.Module):
         self.bias = None
         self._device = device
         self.nns = None
+        self._direct_kernel = None  # is this layer served by cconv_direct_kernel (learnt at its first call in a step)
 
     # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
     def build(self, in_channels, device=None):
@@ -365,6 +384,7 @@ class ContinuousConv(torch.nn.Module):
         else:
             extent = float(np.float32(extents))
         window, window_fac, neighbors_value, n_pairs_ref, row_count = None, 1.0, None, None, None
+        skip_self = False
         if user_neighbors_index is not None and user_neighbors_row_splits is not None:  # :341-349
             neighbors_index, neighbors_row_splits = user_neighbors_index, user_neighbors_row_splits
             if user_neighbors_importance is not None and user_neighbors_importance.numel() > 0:
@@ -391,8 +411,13 @@ class ContinuousConv(torch.nn.Module):
                 self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
                                                     hash_table=fixed_radius_search_hash_table)
             else:
-                self.nns = _CACHE.search(self.fixed_radius_search, inp_positions, out_positions, radius,
-                                         distances=not isinstance(self.window_function, WindowFunction))
+                shared = None
+                if self._shares_list():
+                    shared = _CACHE.with_query_points(self.fixed_radius_search, inp_positions, out_positions, radius)
+                skip_self = shared is not None
+                self.nns = shared if skip_self else _CACHE.search(
+                    self.fixed_radius_search, inp_positions, out_positions, radius,
+                    distances=not isinstance(self.window_function, WindowFunction))
             # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
             row_count = getattr(self.nns, "row_count", None)  # padded rows of the single-pass search
@@ -442,9 +467,29 @@ class ContinuousConv(torch.nn.Module):
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
             bias=self.bias if fuse_bias else None, n_pairs_ref=n_pairs_ref,
-            neighbors_row_count=row_count)
+            neighbors_row_count=row_count, skip_self=skip_self)
+        if self._direct_kernel is None and in_step and self.radius_search_ignore_query_points:
+            # (asked once per layer: the dispatch looks at the layer, never at the list)
+            self._direct_kernel = ops.cconv_forward(
+                kernel, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
+                neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
+                align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
+                interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
+                neighbors_row_count=row_count, name_only=True).startswith("cconv_direct_kernel")
+            if self._shares_list() and user_neighbors_index is None and fixed_radius_search_hash_table is None:
+                # announce this layer as one more consumer of the list it will take from the next step on (the cache hands a
+                # list's buffers back after the number of consumers it saw in the previous step)
+                _CACHE.with_query_points(self.fixed_radius_search, inp_positions, out_positions,
+                                         float(np.float32(0.5) * np.float32(extent)))
         self._conv_output = None if in_step else out_features
         return self._finish(out_features, inp_features)
+
+    def _shares_list(self):
+        """May this layer take the list of the same search WITH the query points (see _NeighborCache.with_query_points)?  Only
+        a layer that ignores them, evaluates a named window in the kernel and is served by the kernel that implements
+        DMCF_FLAG_SKIP_SELF; DMCF_SHARE_LISTS=0 turns it off."""
+        return (self.radius_search_ignore_query_points and self._direct_kernel is True and self.radius_search_metric == "L2"
+                and isinstance(self.window_function, WindowFunction) and os.environ.get("DMCF_SHARE_LISTS", "1") != "0")
 
     def _finish(self, out_features, inp_features):
         if self.use_dense_layer_for_center:  # :462-464

@@ -550,3 +550,28 @@ def test_full_size_step_properties(dev):
     assert torch.all(tot <= 2e-5 * out.double().abs().sum(0)), tot
     corr = model.pos_correction
     assert corr.shape == (100 ** 3, 3) and float(corr.abs().max()) < 0.05  # a sub-particle-spacing correction
+
+
+def test_ascc_head_shares_the_trunk_list(dev, monkeypatch):
+    """Liquid3d: from the second step on the ASCC head takes the s0 -> s0 list of the trunk (searched WITH the query points)
+    and skips the pairs (i, i) in the kernel (DMCF_FLAG_SKIP_SELF): one search less per step, the same positions bit for
+    bit (the other pairs keep their order; a zero-weight pair adds an exact zero)."""
+    from dmcf_amd import ops
+    from dmcf_amd.pipelines import Simulator
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    res = {}
+    for share in ("1", "0"):
+        monkeypatch.setenv("DMCF_SHARE_LISTS", share)
+        sim = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+        state = scenes.model_inputs(scenes.box_scene(20, seed=9), device=dev)
+        searches = []
+        for _ in range(3):
+            ops.timer = ops.LaunchTimer()
+            state = sim.step([state])[0]
+            recs, ops.timer = ops.timer.results(), None
+            searches.append(sum(1 for k, m, _ in recs if k.startswith("frs_search")))
+        res[share] = (searches, state[0].clone())
+    assert res["0"][0][1] == res["0"][0][2] and res["1"][0][0] == res["0"][0][0]  # the first step learns the head's kernel
+    assert res["1"][0][1] == res["0"][0][1] - 1 and res["1"][0][2] == res["0"][0][2] - 1
+    assert torch.equal(res["1"][1], res["0"][1])

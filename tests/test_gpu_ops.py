@@ -327,6 +327,35 @@ def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel
         ops.cconv_forward(k, out, 2 * radius, pos, feat, bare.neighbors_index, bare.neighbors_row_splits, window="explicit")
 
 
+def test_skip_self_flag_shares_the_list_with_query_points(dev, monkeypatch):
+    """DMCF_FLAG_SKIP_SELF: an ASCC layer (ignores its query points) on the list searched WITH them gives the bits of the list
+    searched without -- the pair (i, i) carries weight zero, the other pairs keep their order; kernels other than the direct
+    form refuse the flag."""
+    from dmcf_amd import _lib, ops
+    g = torch.Generator().manual_seed(3)
+    pos = torch.rand(4000, 3, generator=g).to(dev)
+    feat = torch.randn(4000, 32, generator=g).to(dev)
+    k = torch.randn(6, 3, 6, 32, 3, generator=g).to(dev)
+    radius = 0.11
+    with_self = ops.fixed_radius_search(pos, pos, radius, return_distances=False)
+    without = ops.fixed_radius_search(pos, pos, radius, ignore_query_point=True, return_distances=False)
+    assert int(with_self.neighbors_row_splits[-1]) == int(without.neighbors_row_splits[-1]) + pos.shape[0]
+    kw = dict(window="peak", symmetric=True, sym_axis=1)
+    assert ops.cconv_forward(k, pos, 2 * radius, pos, feat, with_self.neighbors_index, with_self.neighbors_row_splits,
+                             name_only=True, **kw).startswith("cconv_direct_kernel")
+    a = ops.cconv_forward(k, pos, 2 * radius, pos, feat, without.neighbors_index, without.neighbors_row_splits, **kw)
+    b = ops.cconv_forward(k, pos, 2 * radius, pos, feat, with_self.neighbors_index, with_self.neighbors_row_splits,
+                          skip_self=True, **kw)
+    assert torch.equal(a, b) and float(a.abs().max()) > 0
+    c = ops.cconv_forward(k, pos, 2 * radius, pos, feat, with_self.neighbors_index, with_self.neighbors_row_splits, **kw)
+    assert not torch.equal(a, c) or True  # (the antisymmetric filter gives the pair (i, i) weight 0 +- rounding either way)
+    k4 = torch.randn(4, 2, 4, 8, 3, generator=g).to(dev)
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "cls")
+    with pytest.raises(_lib.DmcfError):
+        ops.cconv_forward(k4, pos, 2 * radius, pos, feat[:, :8].contiguous(), with_self.neighbors_index,
+                          with_self.neighbors_row_splits, skip_self=True, **kw)
+
+
 @pytest.mark.parametrize("kernel,ca,cb,oa,ob", [("cls", 4, 8, 32, 32), ("cls", 8, 4, 16, 8), ("z3", 8, 16, 32, 32), ("z3", 16, 12, 16, 16),
                                                   ("blk", 4, 8, 32, 32), (None, 4, 8, 32, 32)])
 def test_filter_tile_mask_of_a_block_diagonal_pair(oracle, dev, monkeypatch, kernel, ca, cb, oa, ob):
