@@ -1,0 +1,62 @@
+"""Ghost fractions of the block-sharded rollout, measured with VIRTUAL ranks on one MI355X: the ranks
+are threads of one process (dmcf_amd.parallel.LocalComm), every one runs the real HIP kernels on its own block of ONE box of
+(gx*side) x (gy*side) x (gz*side) fluid particles -- the scene pieces `bench.py --gpus N` gives its ranks.  Prints, per rank
+and per point set, owned points, ghosts of the set's widest plan and of the per-layer plans derived from it, and the rows /
+bytes of features exchanged per step.
+usage: python tools/ghost_fraction.py [side=100] [gx gy gz = 2 2 2] [steps=2]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dmcf_amd import models, parallel  # noqa: E402
+from dmcf_amd.utils import tf_checkpoint as tc  # noqa: E402
+from tools import configs, scenes  # noqa: E402
+
+
+def main():
+    side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    grid = [int(x) for x in sys.argv[2:5]] if len(sys.argv) > 4 else [2, 2, 2]
+    steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    world = grid[0] * grid[1] * grid[2]
+    dev = torch.device("cuda:0")
+    h = 0.05
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * side * h for g in grid], grid)
+    weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
+
+    def rank_fn(comm):
+        cfg = configs.LIQUID3D
+        model = getattr(models, cfg["name"])(**cfg)
+        tc.load_into_model(model, weights, device=dev)
+        sim = parallel.ShardedSimulator(model, comm, decomp)
+        state = parallel.shard_scene(scenes.box_block_scene(side, grid, comm.rank), decomp, comm.rank, dev, presharded=True)
+        rows = []
+        for _ in range(steps):
+            before = sim.exchanged_rows
+            state = sim.step(state)
+            rows.append(sim.exchanged_rows - before)
+        sets = {}
+        for name, pos in sim._sets.items():
+            plans = {f"{w:g}": int(p.ghost_pos.shape[0]) for (n, w), p in sorted(sim._plans.items()) if n == name}
+            sets[str(name)] = dict(owned=int(pos.shape[0]), widest=float(sim._wide[name].width),
+                                   ghosts_widest=int(sim._wide[name].ghost_pos.shape[0]), ghosts_by_width=plans)
+        return dict(rank=comm.rank, block=decomp.coords(comm.rank), fluid=int(state["pos"].shape[0]), sets=sets,
+                    feature_rows_per_step=rows[-1])
+
+    res = parallel.run_local_ranks(world, rank_fn)
+    out = dict(side=side, grid=grid, fluid_total=side ** 3 * world, ranks=res)
+    print(json.dumps(out))
+    # summary on stderr
+    for r in res:
+        s = r["sets"]
+        line = ", ".join(f"{k}: {v['owned']} owned + {v['ghosts_widest']} ghosts ({100.0 * v['ghosts_widest'] / max(v['owned'], 1):.1f} % at width {v['widest']:g})"
+                         for k, v in s.items())
+        print(f"rank {r['rank']} block {r['block']}: {line}; {r['feature_rows_per_step']} feature rows received per step", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
