@@ -682,7 +682,18 @@ class ShardedSimulator:
                     ext = comm.all_reduce(torch.tensor(ext + [unknown], dtype=torch.int64, device=dev), "max").tolist()
                     if ext[0] > -big_i and ext[6] == 0:
                         ulo = [-ext[2 * k] for k in range(3)]
-                        udims = [ext[2 * k + 1] + ext[2 * k] + 1 for k in range(3)]
+                        uhi = [ext[2 * k + 1] for k in range(3)]
+                        # THIS rank's part of the union: the cells within the widest ghost width of its block (owned points lie
+                        # in the block, ghosts within that distance of it); the union only bounds the outer, open sides.  The
+                        # dense volumes of the lattice form are zero-filled and walked box by box: with the union box of eight
+                        # ranks the four lattice layers took 3x the time of the single-rank step (1.8 against 0.6 ms each).
+                        for k, (b_lo, b_hi) in enumerate(self.decomp.bounds(comm.rank)):
+                            v = float(vs[k])
+                            if v > 1e-5 and b_lo != -float("inf"):
+                                ulo[k] = max(ulo[k], int(np.floor((b_lo - wide_w - center_host[k]) / v)) - 2)
+                            if v > 1e-5 and b_hi != float("inf"):
+                                uhi[k] = min(uhi[k], int(np.ceil((b_hi + wide_w - center_host[k]) / v)) + 2)
+                        udims = [max(uhi[k] - ulo[k] + 1, 1) for k in range(3)]
                         self._lattices[name] = (center, [float(v) for v in vs], (ulo, udims), center_host)
                         lattice.register_points(g, center, vs, ("sharded", center.data_ptr()), (ulo, udims),
                                                 center_host=center_host)

@@ -2,11 +2,13 @@
 are threads of one process (dmcf_amd.parallel.LocalComm), every one runs the real HIP kernels on its own block of ONE box of
 (gx*side) x (gy*side) x (gz*side) fluid particles -- the scene pieces `bench.py --gpus N` gives its ranks.  Prints, per rank
 and per point set, owned points, ghosts of the set's widest plan and of the per-layer plans derived from it, and the rows /
-bytes of features exchanged per step.
+bytes of features exchanged per step, and the wall time of a step of all ranks divided by their number (the GPU time a
+rank's step costs, ghosts and exchanges included -- the ranks' kernels serialise on the one device).
 usage: python tools/ghost_fraction.py [side=100] [gx gy gz = 2 2 2] [steps=2]"""
 import json
 import os
 import sys
+import time
 
 import numpy as np
 import torch
@@ -34,10 +36,16 @@ def main():
         tc.load_into_model(model, weights, device=dev)
         sim = parallel.ShardedSimulator(model, comm, decomp)
         state = parallel.shard_scene(scenes.box_block_scene(side, grid, comm.rank), decomp, comm.rank, dev, presharded=True)
-        rows = []
+        rows, times = [], []
         for _ in range(steps):
             before = sim.exchanged_rows
+            torch.cuda.synchronize(dev)
+            comm.hub.barrier.wait()
+            t0 = time.perf_counter()
             state = sim.step(state)
+            torch.cuda.synchronize(dev)
+            comm.hub.barrier.wait()
+            times.append(time.perf_counter() - t0)
             rows.append(sim.exchanged_rows - before)
         sets = {}
         for name, pos in sim._sets.items():
@@ -45,11 +53,14 @@ def main():
             sets[str(name)] = dict(owned=int(pos.shape[0]), widest=float(sim._wide[name].width),
                                    ghosts_widest=int(sim._wide[name].ghost_pos.shape[0]), ghosts_by_width=plans)
         return dict(rank=comm.rank, block=decomp.coords(comm.rank), fluid=int(state["pos"].shape[0]), sets=sets,
-                    feature_rows_per_step=rows[-1])
+                    feature_rows_per_step=rows[-1], step_seconds=times)
 
     res = parallel.run_local_ranks(world, rank_fn)
     out = dict(side=side, grid=grid, fluid_total=side ** 3 * world, ranks=res)
     print(json.dumps(out))
+    last = max(r["step_seconds"][-1] for r in res)
+    print(f"last step: {1e3 * last:.1f} ms for all {world} ranks on ONE GPU = {1e3 * last / world:.1f} ms of GPU time per rank and step "
+          "(the ranks' kernels share the device; their host work overlaps)", file=sys.stderr)
     # summary on stderr
     for r in res:
         s = r["sets"]
