@@ -299,12 +299,14 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
                            c2 = __builtin_amdgcn_readfirstlane(cw[2]);
             float xa, wa, fa, xb, wb, fb, av;
             uint32_t sc;
+            __builtin_amdgcn_s_setprio(3);  // the wave in its splat gets the matrix pipe first (16 -> 16: -2 %)
             asm volatile(
 #include "cconv_cls_splat.inc"
                 : [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
                   [a] "=&v"(av), [sc] "=&s"(sc)
                 : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c0), [c1] "s"(c1), [c2] "s"(c2)
                 : "scc", "m0", "memory", CLS_TILE_REGS);
+            __builtin_amdgcn_s_setprio(0);
         };
         // the same for a whole batch staged with 8 channels per slot (columns 8..15 of the tiles repeat 0..7: never read)
         auto splat8 = [&](int nslots) {
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
             for (int q = 0; q < 6; ++q) c[q] = __builtin_amdgcn_readfirstlane(cw[q]);
             float xa, wa, fa, xb, wb, fb, av;
             uint32_t sc;
+            __builtin_amdgcn_s_setprio(3);
             asm volatile(
 #include "cconv_cls_splat8.inc"
                 : [xa] "=&v"(xa), [wa] "=&v"(wa), [fa] "=&v"(fa), [xb] "=&v"(xb), [wb] "=&v"(wb), [fb] "=&v"(fb),
@@ -325,6 +328,7 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
                 : [px] "v"(px), [pw] "v"(pw), [pf] "v"(pf), [xm] "v"(xm), [ng] "s"(ng), [c0] "s"(c[0]), [c1] "s"(c[1]),
                   [c2] "s"(c[2]), [c3] "s"(c[3]), [c4] "s"(c[4]), [c5] "s"(c[5])
                 : "scc", "m0", "memory", CLS_TILE_REGS);
+            __builtin_amdgcn_s_setprio(0);
         };
         // Merge the 9 tiles into the point's B row and clear them.  D layout of 16x16x4: lane (group G = lane >> 4 =
         // (z', y'), channel lane & 15), register r = x  ->  k' = ((bz + z') * 4 + by + y') * 64 + channel * 4 + x.
