@@ -212,8 +212,9 @@ class PBFNet(BaseModel):
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in self.particle_radii]  # :328
         # boundary particles outside the fluid AABB +- 2 r_max are dropped every step (:330-336)
         pt = pos.t().contiguous()  # [3, N]: row reductions (a strided column reduction of [N, 3] is ~0.6 ms each)
-        lo = pt.amin(dim=1) - filter_extent[-1]
-        hi = pt.amax(dim=1) + filter_extent[-1]
+        mn, mx = torch.aminmax(pt, dim=1)  # (one pass over the positions instead of two)
+        lo = mn - filter_extent[-1]
+        hi = mx + filter_extent[-1]
         fltr = ((box >= lo) & (box <= hi)).all(dim=1)
         box = box[fltr]
         bfeats = bfeats[fltr]
