@@ -755,3 +755,16 @@ def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
                           nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
                           bias=_t(bias, dev)).cpu().numpy()
     _close(y, z.astype(np.float64))
+
+
+def test_reserve_device_memory(dev):
+    """ops.reserve_device_memory hands the caching allocator one block and reports what it got; a request the device cannot
+    satisfy is not an error (the rollout then allocates as it goes)."""
+    from dmcf_amd import ops
+    before = torch.cuda.memory_reserved(dev)
+    assert ops.reserve_device_memory(0.5, dev) == 0.5
+    assert torch.cuda.memory_reserved(dev) >= before + (1 << 29) - (1 << 21)
+    a = torch.empty(1 << 28, dtype=torch.uint8, device=dev)  # carved out of the reserved block: no new segment
+    assert torch.cuda.memory_reserved(dev) < before + (1 << 29) + (1 << 28)
+    del a
+    assert ops.reserve_device_memory(1 << 20, dev) == 0.0  # a million GiB
