@@ -99,10 +99,9 @@ def parse_args(argv=None):
     ap.add_argument("--side", type=int, default=100, help="fluid cube edge in particles per GPU (100 -> 1M particles)")
     ap.add_argument("--cpu-side", type=int, default=46, help="edge of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--layers-json", default=None, help="write the per-launch table here")
-    ap.add_argument("--reserve-gib", type=float, default=48.0,
-                    help="device memory handed to the caching allocator before the warm-up steps (0 = none): the neighbour "
-                         "lists outgrow their padded buffers while the scene compresses, and a fresh multi-GB hipMalloc in "
-                         "the middle of the timed steps stalls the queue for 0.1 - 0.3 s")
+    ap.add_argument("--reserve-gib", type=float, default=None,
+                    help="override Simulator(reserve_gib=...) (default: the product's own 'auto' rule, 40 KiB per particle handed "
+                         "to the caching allocator before the first step; 0 = none)")
     ap.add_argument("--decomp", default="blocks", choices=["blocks", "slabs"])
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduction logic only, on the gloo backend without a GPU (CPU test)")
@@ -223,8 +222,9 @@ def main():
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, weights, device=dev)
     extra = {}
+    sim_kw = {} if args.reserve_gib is None else dict(reserve_gib=args.reserve_gib)
     if not sharded:
-        sim = Simulator(model, device=f"cuda:{local_rank}")
+        sim = Simulator(model, device=f"cuda:{local_rank}", **sim_kw)
         scene = scenes.box_scene(args.side)
         n_fluid = scene["pos"].shape[0]
         n_total = n_fluid
@@ -239,7 +239,7 @@ def main():
         grid = block_grid(world) if args.decomp == "blocks" else [world, 1, 1]
         h = 0.05
         decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * args.side * h for g in grid], grid)
-        ssim = parallel.ShardedSimulator(model, comm, decomp)
+        ssim = parallel.ShardedSimulator(model, comm, decomp, **sim_kw)
         scene = scenes.box_block_scene(args.side, grid, rank)
         n_fluid = scene["pos"].shape[0]
         state = parallel.shard_scene(scene, decomp, rank, dev, presharded=True)
@@ -255,8 +255,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    if args.reserve_gib > 0 and not args.dry_run:
-        ops.reserve_device_memory(args.reserve_gib, dev)
     for _ in range(args.warmup):
         state = step(state)
     if os.environ.get("DMCF_BENCH_DEBUG"):

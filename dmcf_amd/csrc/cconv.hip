@@ -539,7 +539,8 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.idx = a->neighbors_index;
     p.rs = a->neighbors_row_splits;
     p.cnt = a->neighbors_row_count;
-    p.wmask = a->filter_tile_mask ? a->filter_tile_mask : 0xffffffffu;
+    // (the hint covers input channels < 32 and output channels < 64: wider layers multiply every block)
+    p.wmask = (a->filter_tile_mask && a->filter_dims[3] <= 32 && a->filter_dims[4] <= 64) ? a->filter_tile_mask : 0xffffffffu;
     p.nval = a->neighbors_value;
     p.n_out = a->n_out;
     p.n_inp = a->n_inp;

@@ -487,7 +487,8 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
             const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % CTM) * kCRow + ((blk * 16 + mg * 4) ^ ((mi % CTM) << 2)));
             const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
             // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
-            const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
+            const int wq = 4 * chunk + t % nq;  // channel quad; the mask holds quads 0 .. 7
+            const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
 #pragma unroll
             for (int n = 0; n < NTT; ++n) {
                 if (n < p.NT && ((wm >> n) & 1)) {

@@ -156,7 +156,9 @@ __global__ __launch_bounds__(1024, 1) void cconv_direct_kernel(const DirectParam
                     y = gy - oy;
                     z = gz - oz;
                     a = window_value(p.window, p.nval ? nvA : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
-                    if ((p.flags & DMCF_FLAG_SKIP_SELF) && jA == (int)i) a = 0.0f;  // the list holds the query point itself
+                    // the list holds the query points; the search this flag replaces drops every point AT the query position
+                    // (frs.hip, ignore_query_point compares positions), so coincident particles go with the point itself
+                    if ((p.flags & DMCF_FLAG_SKIP_SELF) && ((x == 0.0f && y == 0.0f && z == 0.0f) || jA == (int)i)) a = 0.0f;
                     nsum += a;
                     if (p.inp_imp) a *= p.inp_imp[jA];
                     filter_coords<GENERIC>(x, y, z, p);

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
                 const int t = wave + kZWaves * it;
                 const int blk = (t / nq) * 4 + t % nq;
                 const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
-                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));  // (all-zero filter blocks: not fetched)
+                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
                     if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);

@@ -249,18 +249,22 @@ def build_spatial_hash_table(points, radius, n_queries=None, **_ignored):
 
 
 def reserve_device_memory(gib, device=None):
-    """Hand ``gib`` GiB of device memory to torch's caching allocator as ONE segment and release it into the pool (the
-    allocator splits a cached block, it cannot join two segments): the multi-GB list buffers of a rollout -- and the bigger
-    ones a scene grows into -- are then carved out of memory the process already owns instead of a fresh hipMalloc in the
-    middle of a step (0.1 - 0.3 s each on an MI355X, with everything else queued behind it).  Optional; one GPU has 288 GB.
-    Returns the GiB actually reserved (0 when the device does not have that much to spare: the rollout then allocates as it
-    goes)."""
+    """Make torch's caching allocator hold ONE free block of at least ``gib`` GiB (the allocator splits a cached block, it
+    cannot join two segments): the multi-GB list buffers of a rollout -- and the bigger ones a scene grows into -- are then
+    carved out of memory the process already owns instead of a fresh hipMalloc in the middle of a step (0.1 - 0.3 s each on
+    an MI355X, with everything else queued behind it).  Optional; one GPU has 288 GB.  ``Simulator(reserve_gib=...)`` calls it.
+
+    Returns the GiB this call took FROM THE DEVICE: ``gib`` when a new segment was created, 0.0 when the pool already held a
+    free block that large (nothing to do -- the promise holds) and -1.0 when the device does not have that much to spare (the
+    rollout then allocates as it goes)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    before = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     try:
-        block = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=device)
+        block = torch.empty(int(gib * (1 << 30)), dtype=torch.uint8, device=dev)
     except torch.cuda.OutOfMemoryError:
-        return 0.0
+        return -1.0
     del block
-    return float(gib)
+    return float(gib) if torch.cuda.memory_stats(dev).get("num_device_alloc", 0) > before else 0.0
 
 
 def pair_capacity(total):

@@ -432,11 +432,13 @@ class ShardedSimulator:
     ``forward`` (models/hrnet.py, sym_net.py, cconv.py): this class only installs ``model.conv_hook``, through which
     every ContinuousConv call of the forward pass gets its input rows extended by the ghosts within the layer's radius."""
 
-    def __init__(self, model, comm, decomp):
+    def __init__(self, model, comm, decomp, reserve_gib="auto"):
         self.model = model
         self.comm = comm
         self.decomp = decomp
         assert decomp.world == comm.world
+        self.reserve_gib = reserve_gib  # as Simulator(reserve_gib=...): one block for the caching allocator before the first step
+        self.reserved_gib = None
         self.exchanged_rows = 0
         self.host_syncs = 0
         m = model
@@ -545,6 +547,12 @@ class ShardedSimulator:
         step (single pass, no host round trips); whether any rank outgrew an estimate is agreed with ONE tiny all-reduce
         after the step -- the validation happens when the cache scope closes, i.e. after every collective of the step --
         and then all ranks repeat the step with the exact search."""
+        if self.reserved_gib is None:
+            from .pipelines.simulator import reserve_for_scene
+            self.reserved_gib = 0.0
+            if state["pos"].is_cuda:
+                self.reserved_gib = reserve_for_scene(self.reserve_gib, int(state["pos"].shape[0] + state["box"].shape[0]),
+                                                      state["pos"].device)
         try:
             with neighbor_cache(estimate=True):
                 out = self._step(state)

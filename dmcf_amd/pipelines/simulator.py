@@ -22,10 +22,33 @@ from ..utils.convolutions import neighbor_cache
 log = logging.getLogger(__name__)
 
 
+# 1M fluid + 0.12M boundary particles peak at 16 GB of live buffers and ~45 GB of pool once the lists have grown (DESIGN.md
+# section 4.1): 40 KiB per point
+RESERVE_BYTES_PER_POINT = 40 * 1024
+
+
+def reserve_for_scene(reserve_gib, n_points, device):
+    """The ``reserve_gib`` rule of Simulator / ShardedSimulator for a scene of ``n_points`` particles (fluid + boundary): "auto" =
+    RESERVE_BYTES_PER_POINT each, at most a quarter of the device, nothing below 0.25 GiB (small scenes: the allocator's own
+    growth is a few MB).  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
+    gib = reserve_gib
+    if gib == "auto":
+        gib = n_points * RESERVE_BYTES_PER_POINT / 2 ** 30
+        gib = min(gib, torch.cuda.get_device_properties(device).total_memory / 2 ** 30 / 4)
+        if gib < 0.25:
+            gib = 0
+    return ops.reserve_device_memory(float(gib), device) if gib else 0.0
+
+
 class Simulator:
     def __init__(self, model, dataset=None, name="Simulator", main_log_dir="./logs/", device="cuda", split="train",
-                 **kwargs):
-        self.cfg = Config(dict(kwargs, name=name, main_log_dir=main_log_dir, device=device, split=split))
+                 reserve_gib="auto", **kwargs):
+        """``reserve_gib`` (not in the reference; a ``pipeline:`` key like the others): device memory handed to torch's
+        caching allocator as one block before the first step (ops.reserve_device_memory), so that the multi-GB neighbour-list
+        buffers of a large scene -- and the bigger ones it grows into -- never wait for a hipMalloc in the middle of a rollout.
+        "auto" = RESERVE_BYTES_PER_POINT per particle (fluid + boundary) of the first scene, at most a quarter of the device;
+        0 / None = none."""
+        self.cfg = Config(dict(kwargs, name=name, main_log_dir=main_log_dir, device=device, split=split, reserve_gib=reserve_gib))
         self.name = name
         self.model = model
         self.dataset = dataset
@@ -35,6 +58,8 @@ class Simulator:
         if self.device.type != "cuda":
             raise RuntimeError("the DMCF hot path runs on the GPU only (no CPU fallback)")
         self.timing = []
+        self.reserve_gib = reserve_gib
+        self.reserved_gib = None  # what the first step took from the device (None: not asked yet)
         self._slot0 = 0  # scene slot of inputs[0] (run_rollout feeds its scenes one at a time)
         self.repeated_steps = 0  # steps repeated with exact buffer sizes after a NeighborCapacityExceeded
         # base_pipeline.py:46-63: <main_log_dir | output_dir>/<Model>_<dataset>_<version>
@@ -50,9 +75,16 @@ class Simulator:
             x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
         return x.to(self.device, dtype=torch.float32)
 
+    def _reserve(self, inputs):
+        """Once, before the first step: see ``reserve_gib`` in __init__."""
+        n = max((int(s[0].shape[0]) + (int(s[4].shape[0]) if s[4] is not None else 0) for s in inputs), default=0)
+        self.reserved_gib = reserve_for_scene(self.reserve_gib, n, self.device)
+
     @torch.no_grad()
     def run_inference(self, inputs):
         """simulator.py:57-71."""
+        if self.reserved_gib is None:
+            self._reserve(inputs)
         results = []
         for bi in range(len(inputs)):
             try:
@@ -107,7 +139,7 @@ class Simulator:
         if not ckpt_path:
             log.info("No checkpoint")
             return 0
-        prefix = ckpt_path
+        prefix, epoch = ckpt_path, 0  # an explicit checkpoint prefix: epoch 0 (base_pipeline.py:171-175)
         if os.path.isdir(ckpt_path):
             import glob
             import re
@@ -117,10 +149,12 @@ class Simulator:
                 log.info("No checkpoint")
                 return 0
             prefix = idx[-1][:-len(".index")]
+            # the newest checkpoint of a directory (manager.latest_checkpoint): 'ckpt-<n>' was written at the end of epoch
+            # (n - 1) * save_ckpt_freq, the run continues with the next one (base_pipeline.py:176-185)
+            epoch = tc.checkpoint_epoch(prefix, int(self.cfg.get("save_ckpt_freq", 1) or 1))
         log.info("Loading checkpoint %s", prefix)
         tc.load_into_model(self.model, tc.load_checkpoint(prefix), device=self.device)
-        m = __import__("re").findall(r"(\d+)$", os.path.basename(prefix))
-        return int(m[0]) if m else 0
+        return epoch
 
     def run_test(self, epoch=None):
         """simulator.py:111-165: roll out every scene of the test split over its full length and write
@@ -146,6 +180,9 @@ class Simulator:
             output = [(pos, {"name": "pred", "type": "PARTICLE"}), (data["pos"], {"name": "gt", "type": "PARTICLE"}),
                       (data["box"][0], {"name": "bnd", "type": "PARTICLE"})]
             path = os.path.join(out_dir, "%04d.hdf5" % epoch)
+            for stale in os.listdir(out_dir):  # simulator.py:156-160: one result file per scene directory
+                if stale.endswith((".hdf5", ".npz")):
+                    os.remove(os.path.join(out_dir, stale))
             try:
                 write_results(path, self.model.name, output)
             except ImportError:

@@ -191,7 +191,8 @@ def load_into_model(model, weights, device="cuda", strict=True):
     return loaded
 
 
-def checkpoint_epoch(path):
-    """Epoch recovered from the checkpoint name like the reference (pipelines/base_pipeline.py:182-184)."""
+def checkpoint_epoch(path, save_ckpt_freq=1):
+    """Epoch recovered from the name of a checkpoint manager's newest checkpoint, like the reference
+    (pipelines/base_pipeline.py:182-185): ``(n - 1) * save_ckpt_freq + 1`` for ``ckpt-<n>``."""
     nums = re.findall(r"\d+", os.path.basename(path))
-    return int(nums[-1]) - 1 if nums else 0
+    return (int(nums[-1]) - 1) * int(save_ckpt_freq) + 1 if nums else 0

@@ -148,8 +148,9 @@ enum dmcf_window {
 #define DMCF_FLAG_NORMALIZE 2
 #define DMCF_FLAG_SYMMETRIC 4  /* ASCC: filters is the stored half kernel, see above */
 #define DMCF_FLAG_ACCUMULATE 8 /* out += result instead of out = result (add_merge, models/hrnet.py:115-116) */
-#define DMCF_FLAG_SKIP_SELF 16 /* pairs with neighbors_index[p] == the output row carry weight zero: a list searched WITH the
-                                  query points serves a layer that ignores them (radius_search_ignore_query_points,
+#define DMCF_FLAG_SKIP_SELF 16 /* pairs with neighbors_index[p] == the output row -- and pairs whose two positions are EQUAL, which
+                                  is the test the search applies (ignore_query_point drops every point at the query position) --
+                                  carry weight zero: a list searched WITH the query points serves a layer that ignores them (radius_search_ignore_query_points,
                                   utils/convolutions.py:207-210) when its outputs are its first n_out inputs -- the ASCC
                                   head then shares the list of the trunk's same-scale layers instead of searching again.
                                   Only the kernel for <= 4 output channels and large filters implements it

@@ -347,6 +347,16 @@ def test_skip_self_flag_shares_the_list_with_query_points(dev, monkeypatch):
     b = ops.cconv_forward(k, pos, 2 * radius, pos, feat, with_self.neighbors_index, with_self.neighbors_row_splits,
                           skip_self=True, **kw)
     assert torch.equal(a, b) and float(a.abs().max()) > 0
+    # distinct particles at ONE position: the search compares positions (every coincident point is "the query point"), so the
+    # flag must drop those pairs as well, not only the pair (i, i)
+    pos2 = pos.clone()
+    pos2[100:140] = pos2[60:100]
+    with2 = ops.fixed_radius_search(pos2, pos2, radius, return_distances=False)
+    without2 = ops.fixed_radius_search(pos2, pos2, radius, ignore_query_point=True, return_distances=False)
+    assert int(with2.neighbors_row_splits[-1]) == int(without2.neighbors_row_splits[-1]) + pos.shape[0] + 80
+    a2 = ops.cconv_forward(k, pos2, 2 * radius, pos2, feat, without2.neighbors_index, without2.neighbors_row_splits, **kw)
+    b2 = ops.cconv_forward(k, pos2, 2 * radius, pos2, feat, with2.neighbors_index, with2.neighbors_row_splits, skip_self=True, **kw)
+    assert torch.equal(a2, b2)
     c = ops.cconv_forward(k, pos, 2 * radius, pos, feat, with_self.neighbors_index, with_self.neighbors_row_splits, **kw)
     assert not torch.equal(a, c) or True  # (the antisymmetric filter gives the pair (i, i) weight 0 +- rounding either way)
     k4 = torch.randn(4, 2, 4, 8, 3, generator=g).to(dev)
@@ -758,13 +768,35 @@ def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
 
 
 def test_reserve_device_memory(dev):
-    """ops.reserve_device_memory hands the caching allocator one block and reports what it got; a request the device cannot
-    satisfy is not an error (the rollout then allocates as it goes)."""
+    """ops.reserve_device_memory makes the caching allocator's pool hold one free block of the requested size -- whatever the
+    pool held before (this test runs after hundreds of others: the pool is many GB) -- and says what it took from the device; a
+    request the device cannot satisfy is not an error (the rollout then allocates as it goes)."""
     from dmcf_amd import ops
+
+    def device_allocs():
+        return torch.cuda.memory_stats(dev)["num_device_alloc"]
+
+    # (a) the block is a fresh segment, unless a partly used segment of an earlier test still has that much free
+    torch.cuda.synchronize(dev)
+    torch.cuda.empty_cache()
     before = torch.cuda.memory_reserved(dev)
-    assert ops.reserve_device_memory(0.5, dev) == 0.5
-    assert torch.cuda.memory_reserved(dev) >= before + (1 << 29) - (1 << 21)
-    a = torch.empty(1 << 28, dtype=torch.uint8, device=dev)  # carved out of the reserved block: no new segment
-    assert torch.cuda.memory_reserved(dev) < before + (1 << 29) + (1 << 28)
+    n0 = device_allocs()
+    got = ops.reserve_device_memory(0.5, dev)
+    assert got in (0.0, 0.5)
+    assert device_allocs() == n0 + (1 if got else 0)
+    assert torch.cuda.memory_reserved(dev) >= before + (int(got * (1 << 30)))
+    # (b) the promise: allocations up to that size are carved out of it, no device allocation
+    n1 = device_allocs()
+    a = torch.empty(1 << 28, dtype=torch.uint8, device=dev)
+    b = torch.empty(1 << 27, dtype=torch.uint8, device=dev)
+    assert device_allocs() == n1
+    del a, b
+    # (c) a pool that already holds such a block: nothing is taken from the device, and the promise still holds
+    assert ops.reserve_device_memory(0.5, dev) == 0.0
+    assert device_allocs() == n1
+    a = torch.empty(1 << 29, dtype=torch.uint8, device=dev)
+    assert device_allocs() == n1
     del a
-    assert ops.reserve_device_memory(1 << 20, dev) == 0.0  # a million GiB
+    # (d) more than the device has
+    assert ops.reserve_device_memory(1 << 20, dev) == -1.0  # a million GiB
+    torch.cuda.empty_cache()

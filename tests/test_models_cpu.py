@@ -62,6 +62,16 @@ def test_tf_checkpoint_reader_on_reference_blob():
     assert int(w["optimizer/iter"]) == 51000
 
 
+def test_checkpoint_epoch_rule():
+    """base_pipeline.py:171-185: the newest checkpoint of a manager directory, 'ckpt-<n>', continues at epoch
+    (n - 1) * save_ckpt_freq + 1 (an explicit ckpt_path is epoch 0: Simulator.load_ckpt)."""
+    from dmcf_amd.utils import tf_checkpoint as tc
+    assert tc.checkpoint_epoch("/logs/checkpoint/ckpt-12") == 12
+    assert tc.checkpoint_epoch("/logs/checkpoint/ckpt-12", save_ckpt_freq=5) == 56
+    assert tc.checkpoint_epoch("/logs/checkpoint/ckpt-1", save_ckpt_freq=5) == 1
+    assert tc.checkpoint_epoch("/checkpoints/Liquid3d/ckpt") == 0
+
+
 def test_box_scene_generator():
     from tools import scenes
     s = scenes.box_scene(10)
