@@ -248,6 +248,11 @@ bool cconv_z3_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 int cconv_z3_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
 
+// cconv_pair.hip
+bool cconv_pair_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+int cconv_pair_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+
+
 // cconv_direct.hip
 bool cconv_direct_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_direct_packed_floats(int dz, int dy, int dx, int cin);

@@ -86,7 +86,7 @@ def test_block_diagonal_tile_mask():
 
 
 def test_generated_splat_sources_are_current(tmp_path, monkeypatch):
-    """dmcf_amd/csrc/cconv_*_splat*.inc are generated (tools/gen_cls_splat.py, tools/gen_z3_splat.py) and committed: the
+    """dmcf_amd/csrc/cconv_*_splat*.inc and cconv_pair_*.inc are generated (tools/gen_cls_splat.py, tools/gen_z3_splat.py, tools/gen_pair_splat.py) and committed: the
     committed text must be what the generators write."""
     import importlib.util
     import os
@@ -102,3 +102,10 @@ def test_generated_splat_sources_are_current(tmp_path, monkeypatch):
         spec.loader.exec_module(importlib.util.module_from_spec(spec))
     for n in names:
         assert open(real_join(str(tmp_path), n)).read() == committed[n], n
+    # tools/gen_pair_splat.py (cconv_pair.hip) takes its output directory as an argument
+    spec = importlib.util.spec_from_file_location("gen_pair_splat", real_join(root, "tools", "gen_pair_splat.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.write_product(str(tmp_path))
+    for n in gen.PRODUCT_FILES:
+        assert open(real_join(str(tmp_path), n)).read() == open(real_join(csrc, n)).read(), n

@@ -1,5 +1,5 @@
 """Build-time contract of the splat kernels that keep their class tiles in FIXED registers (cconv_cls.hip: v92 .. v127,
-cconv_z3.hip: v80 .. v127): the compiler must stay below them -- that rests on how this toolchain reads
+cconv_z3.hip: v80 .. v127, cconv_pair.hip: v116 .. v255 of 256): the compiler must stay below them -- that rests on how this toolchain reads
 `amdgpu_num_vgpr` (half of the unified register file on gfx90a and later) -- and the kernel descriptors must still ask for all
 128 registers.  Cross-compiles the two files to assembly (no GPU needed) and reads it."""
 import os
@@ -44,8 +44,9 @@ def _highest_compiler_register(lines):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
-@pytest.mark.parametrize("name,first_tile,extra", [("cconv_z3", 80, ()), ("cconv_cls", 92, ("-fno-slp-vectorize",))])
-def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, extra):
+@pytest.mark.parametrize("name,first_tile,extra,total", [("cconv_z3", 80, (), 128), ("cconv_cls", 92, ("-fno-slp-vectorize",), 128),
+                                                          ("cconv_pair", 116, (), 256)])
+def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, extra, total):
     lines = _assembly(tmp_path, name, extra)
     top = {k: v for k, v in _highest_compiler_register(lines).items() if "kernel" in k and "pack" not in k}
     assert top, "no kernels found"
@@ -53,5 +54,8 @@ def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, ext
         assert 0 <= reg < first_tile, f"{kernel}: the compiler uses v{reg}, the tiles start at v{first_tile}"
     text = "\n".join(lines)
     counts = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", text)]
-    assert counts.count(128) >= len(top)  # every splat kernel owns all 128 registers (tiles included)
-    assert f"v[{first_tile}:{first_tile + (15 if name == 'cconv_z3' else 3)}]" in text
+    assert counts.count(total) >= len(top)  # every splat kernel owns all its registers (tiles included)
+    first_mfma_tile = {"cconv_z3": "v[80:95]", "cconv_cls": "v[92:95]", "cconv_pair": "v[148:151]"}[name]
+    assert first_mfma_tile in text
+    if name == "cconv_pair":  # no spills: a reload inside the batch loop would wait for every prefetched load
+        assert all(int(x) == 0 for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text))

@@ -22,7 +22,7 @@
         "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
 
 constexpr int kWaves = 8;
-constexpr int kRecF = 32 * 16;   // floats per wave: 32 groups x 8 products x 2 pairs
+constexpr int kRecF = 16 * 36;   // floats per wave: 16 groups x (8 products x 4 pairs, padded to 36) -- or 32 x 8 x 2
 constexpr int kFstF = 32 * 64;   // 32 groups x 32 channels x 2 pairs
 constexpr int kWaveF = kRecF + kFstF;
 
@@ -39,46 +39,64 @@ __device__ __forceinline__ void zero_tiles() {
         "v_mov_b32 v\\r, 0\n\t.endr" ::: "memory", PAIR_REGS);
 }
 
-// VARIANT 0: the product block; 1: no class reads / M0 updates (every pair into tile 0)
+// VARIANT 0: the product block (groups of 4 pairs); 1 .. 3: UBENCH_VARIANTS of tools/gen_pair_splat.py (b64, noreads, noclass)
+#define SPLAT_OPERANDS                                                                                                        \
+        : [s0] "=&s"(s0)                                                                                                      \
+        : [pa] "v"(pa), [pf] "v"(pf), [nb] "s"(nb), [c0] "s"(c[0]), [c1] "s"(c[1]), [c2] "s"(c[2]), [c3] "s"(c[3]),            \
+          [c4] "s"(c[4]), [c5] "s"(c[5]), [c6] "s"(c[6]), [c7] "s"(c[7]), [c8] "s"(c[8]), [c9] "s"(c[9]), [c10] "s"(c[10]),    \
+          [c11] "s"(c[11]), [c12] "s"(c[12]), [c13] "s"(c[13]), [c14] "s"(c[14]), [c15] "s"(c[15])                             \
+        : "scc", "m0", "memory", PAIR_REGS)
+
 template <int VARIANT>
-__global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))) void splat_loop(float* out, long long* clk, int iters, int npairs) {
+__global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))) void splat_loop(float* out, long long* clk, int iters, int npairs, int cshift) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int GP = VARIANT == 1 ? 2 : 4;  // pairs per staging group
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float* Rec = smem + wave * kWaveF;  // [32][8][2]
-    float* Fst = Rec + kRecF;           // [32][32][2]
-    // pair k = lane: products q = 0..7 -> value (k + 1) * 0.001 + q ; features channel c -> (c + 1) + 100 * (k % 3)
-    for (int q = 0; q < 8; ++q) Rec[(lane >> 1) * 16 + q * 2 + (lane & 1)] = (lane < npairs) ? (lane + 1) * 0.25f + q * 16.0f : 0.0f;
-    for (int c = 0; c < 32; ++c) Fst[(lane >> 1) * 64 + c * 2 + (lane & 1)] = (float)(c + 1) + 64.0f * (lane % 3);
+    float* Rec = smem + wave * kWaveF;  // [64 / GP][8][GP]
+    float* Fst = Rec + kRecF;           // [64 / GP][32][GP]
+    constexpr int RG = VARIANT == 0 ? 36 : 8 * GP;  // floats per record group (the product layout pads to 36)
+    static_assert(kFstF >= 64 * 32, "");
+    for (int q = 0; q < 8; ++q) Rec[(lane / GP) * RG + q * GP + (lane % GP)] = (lane < npairs) ? (lane + 1) * 0.25f + q * 16.0f : 0.0f;
+    for (int c = 0; c < 32; ++c) {
+        const float f = (float)(c + 1) + 64.0f * (lane % 3);
+        if (VARIANT == 0 || VARIANT == 3) Fst[lane * 32 + c] = f;  // row-major: [pair][32 channels]
+        else Fst[(lane / GP) * 32 * GP + c * GP + (lane % GP)] = f;
+    }
     __syncthreads();
-    const int cls4 = 4 * ((lane * 7) % 27);
-    const uint32_t pa = lds_addr(Rec) + 8 * (4 * (lane >> 5) + (lane & 3));
-    const uint32_t pf = lds_addr(Fst) + 8 * (lane & 31);
+    // class bytes (4 * class) of the 64 pairs, four per scalar register: the owner lanes' values, packed inside each quad with
+    // two DPP steps and read out of lanes 0, 4, 8, ...
+    const int cls4 = 4 * (((lane >> cshift) * 7) % 27);
+    int pk = cls4 | (__builtin_amdgcn_mov_dpp(cls4, 0xb1, 0xf, 0xf, true) << 8);        // quad_perm [1,0,3,2]
+    pk = pk | (__builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true) << 16);               // quad_perm [2,3,0,1]
+    uint32_t c[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) c[m] = __builtin_amdgcn_readlane(pk, 4 * m);
+    const uint32_t pa = lds_addr(Rec) + 4 * GP * (4 * (lane >> 5) + (lane & 3));
+    const uint32_t pf = lds_addr(Fst) + 4 * ((VARIANT == 0 || VARIANT == 3) ? 1 : GP) * (lane & 31);
     const int nb = (npairs + 7) >> 3;
     zero_tiles();
-    uint32_t c[16];
+    uint32_t s0;
     const long long t0 = clock64();
     for (int it = 0; it < iters; ++it) {
-        if (VARIANT == 0) {
+        if constexpr (VARIANT == 0) {
             asm volatile(
 #include "../../dmcf_amd/csrc/cconv_pair_splat.inc"
-                : [c0] "=&s"(c[0]), [c1] "=&s"(c[1]), [c2] "=&s"(c[2]), [c3] "=&s"(c[3]), [c4] "=&s"(c[4]), [c5] "=&s"(c[5]),
-                  [c6] "=&s"(c[6]), [c7] "=&s"(c[7]), [c8] "=&s"(c[8]), [c9] "=&s"(c[9]), [c10] "=&s"(c[10]), [c11] "=&s"(c[11]),
-                  [c12] "=&s"(c[12]), [c13] "=&s"(c[13]), [c14] "=&s"(c[14]), [c15] "=&s"(c[15])
-                : [pa] "v"(pa), [pf] "v"(pf), [cls] "v"(cls4), [nb] "s"(nb)
-                : "scc", "m0", "memory", PAIR_REGS);
-        } else {
-            uint32_t z = 0;
+            SPLAT_OPERANDS;
+        } else if constexpr (VARIANT == 1) {
             asm volatile(
-                "s_mov_b32 %[c0], 0\n\t"
-#include "pair_splat_noclass.inc"
-                : [c0] "=&s"(c[0])
-                : [pa] "v"(pa), [pf] "v"(pf), [cls] "v"(cls4), [nb] "s"(nb)
-                : "scc", "m0", "memory", PAIR_REGS);
-            (void)z;
+#include "pair_splat_v1.inc"
+            SPLAT_OPERANDS;
+        } else if constexpr (VARIANT == 2) {
+            asm volatile(
+#include "pair_splat_v2.inc"
+            SPLAT_OPERANDS;
+        } else {
+            asm volatile(
+#include "pair_splat_v3.inc"
+            SPLAT_OPERANDS;
         }
     }
     const long long t1 = clock64();
-    // tiles -> out[(block * 64 + lane) * 108 + r]  (workgroup 0, wave 0 only)
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory", PAIR_REGS);
     float* dump = smem;  // [108][64] per wave 0
     __syncthreads();
@@ -99,57 +117,58 @@ __global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))
     if (tid == 0) clk[blockIdx.x] = t1 - t0;
 }
 
+typedef void (*kern_t)(float*, long long*, int, int, int);
+constexpr int kNV = 4;
+static const kern_t kKernels[kNV] = {splat_loop<0>, splat_loop<1>, splat_loop<2>, splat_loop<3>};
+static const char* kNames[kNV] = {"product (products in groups of 4, features row-major)", "groups of 2, ds_read_b64", "features in groups of 4 too", "noclass"};
+
 int main(int argc, char** argv) {
     const int npairs = argc > 1 ? atoi(argv[1]) : 64;
     float* out;
     long long* clk;
-    hipMalloc(&out, 108 * 64 * 4);
-    hipMalloc(&clk, 1024 * 8);
+    (void)hipMalloc(&out, 108 * 64 * 4);
+    (void)hipMalloc(&clk, 1024 * 8);
     const size_t lds = kWaves * kWaveF * 4;
-    hipFuncSetAttribute((const void*)splat_loop<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipFuncSetAttribute((const void*)splat_loop<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    // ---- correctness: one iteration, one workgroup
-    for (int variant = 0; variant < 2; ++variant) {
-        if (variant == 0) splat_loop<0><<<1, 64 * kWaves, lds>>>(out, clk, 1, npairs);
-        else splat_loop<1><<<1, 64 * kWaves, lds>>>(out, clk, 1, npairs);
-        if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
-        std::vector<float> h(108 * 64);
-        hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
-        std::vector<double> ref(108 * 64, 0.0);
-        for (int k = 0; k < 64 && k < 8 * ((npairs + 7) / 8); ++k) {
-            const int cls = variant == 0 ? (k * 7) % 27 : 0;
-            for (int lane = 0; lane < 64; ++lane)
-                for (int i = 0; i < 4; ++i) {
-                    // D[block][i][j]: lane = 4 block + j, reg i;  A[block][i] = rec[k][4 z' + i], z' = block >> 3;  B[block][j] = f[k][lane & 31]
-                    const int q = 4 * (lane >> 5) + i;
-                    const double a = k < npairs ? (k + 1) * 0.25 + q * 16.0 : 0.0;
-                    const double f = (double)((lane & 31) + 1) + 64.0 * (k % 3);
-                    ref[(4 * cls + i) * 64 + lane] += a * f;
-                }
+    for (int v = 0; v < kNV; ++v) (void)hipFuncSetAttribute((const void*)kKernels[v], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    // ---- correctness: one iteration, one workgroup; consecutive pairs share a class in runs of 1, 2, 4, 64
+    for (int variant = 0; variant < kNV; ++variant) {
+        for (int cshift : {0, 1, 2, 6}) {
+            hipLaunchKernelGGL(kKernels[variant], dim3(1), dim3(64 * kWaves), lds, 0, out, clk, 1, npairs, cshift);
+            if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed\n"); return 1; }
+            std::vector<float> h(108 * 64);
+            (void)hipMemcpy(h.data(), out, h.size() * 4, hipMemcpyDeviceToHost);
+            std::vector<double> ref(108 * 64, 0.0);
+            for (int k = 0; k < 64 && k < 8 * ((npairs + 7) / 8); ++k) {
+                const int cls = variant == 3 ? 0 : ((k >> cshift) * 7) % 27;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int i = 0; i < 4; ++i) {
+                        // D[block][i][j]: lane = 4 block + j, register i;  A[block][i] = products[k][4 z' + i], z' = block >> 3;  B[block][j] = f[k][lane & 31]
+                        const int q = 4 * (lane >> 5) + i;
+                        const double a = k < npairs ? (k + 1) * 0.25 + q * 16.0 : 0.0;
+                        const double f = (double)((lane & 31) + 1) + 64.0 * (k % 3);
+                        ref[(4 * cls + i) * 64 + lane] += a * f;
+                    }
+            }
+            double err = 0.0, mag = 0.0;
+            for (size_t e = 0; e < ref.size(); ++e) { err = fmax(err, fabs(ref[e] - h[e])); mag = fmax(mag, fabs(ref[e])); }
+            printf("variant %d (%s), %d pairs, class runs of %d: max |err| %g (max |ref| %g)  %s\n", variant, kNames[variant], npairs,
+                   1 << cshift, err, mag, err <= 1e-6 * mag ? "OK" : "WRONG");
         }
-        double err = 0.0, mag = 0.0;
-        for (size_t e = 0; e < ref.size(); ++e) { err = fmax(err, fabs(ref[e] - h[e])); mag = fmax(mag, fabs(ref[e])); }
-        printf("variant %d, %d pairs: max |err| %g (max |ref| %g)  %s\n", variant, npairs, err, mag, err <= 1e-6 * mag ? "OK" : "WRONG");
     }
     // ---- rate: one 8-wave workgroup per CU (two waves per SIMD), all CUs
-    for (int variant = 0; variant < 2; ++variant) {
+    for (int variant = 0; variant < kNV; ++variant) {
         const int iters = 2000, grid = 256;
         hipEvent_t a, b;
-        hipEventCreate(&a); hipEventCreate(&b);
+        (void)hipEventCreate(&a); (void)hipEventCreate(&b);
         for (int rep = 0; rep < 2; ++rep) {
-            hipEventRecord(a);
-            if (variant == 0) splat_loop<0><<<grid, 64 * kWaves, lds>>>(out, clk, iters, 64);
-            else splat_loop<1><<<grid, 64 * kWaves, lds>>>(out, clk, iters, 64);
-            hipEventRecord(b);
-            hipDeviceSynchronize();
+            (void)hipEventRecord(a);
+            hipLaunchKernelGGL(kKernels[variant], dim3(grid), dim3(64 * kWaves), lds, 0, out, clk, iters, 64, 0);
+            (void)hipEventRecord(b);
+            (void)hipDeviceSynchronize();
         }
-        float ms; hipEventElapsedTime(&ms, a, b);
-        std::vector<long long> hc(grid);
-        hipMemcpy(hc.data(), clk, grid * 8, hipMemcpyDeviceToHost);
-        double cm = 0; for (auto v : hc) cm += v; cm /= grid;
-        // pairs per SIMD = 2 waves x iters x 64
-        printf("variant %d: %.3f ms for %d iterations; wave clock (s_memtime, 100 MHz) %.0f; %.2f ns per pair and SIMD = %.1f clk at 2.4 GHz\n",
-               variant, ms, iters, cm, 1e6 * ms / (2.0 * iters * 64), 1e6 * ms / (2.0 * iters * 64) * 2.4);
+        float ms; (void)hipEventElapsedTime(&ms, a, b);
+        printf("variant %d (%s): %.3f ms for %d iterations; %.2f ns per pair and SIMD = %.1f clk at 2.4 GHz\n",
+               variant, kNames[variant], ms, iters, 1e6 * ms / (2.0 * iters * 64), 1e6 * ms / (2.0 * iters * 64) * 2.4);
     }
     return 0;
 }
