@@ -41,6 +41,7 @@ class CconvArgs(ctypes.Structure):
         ("n_pairs", ctypes.c_int64),
         ("neighbors_row_count", ctypes.c_void_p),
         ("filter_tile_mask", ctypes.c_uint32),
+        ("row_length_hint", ctypes.c_int32),
     ]
 
 

@@ -177,16 +177,13 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         return min(64, (pp ? nt1 : nt0) - 64 * (t - (pp ? nbA : 0)));
     };
     auto valid = [&](int t) -> bool { return t < NB && lane < npairs(t); };
+    // (eligibility bounds n_inp -- and with it every row -- by 2^24 entries: the two rows always fit one buffer)
+    if (!near) __builtin_trap();
     auto ld_idx = [&](int t, int& j, float& nv) {
         const bool pp = t >= nbA, ok = valid(t);
         const int o = 64 * (t - (pp ? nbA : 0)) + lane;
-        j = 0;
+        j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, ok ? (uint32_t)o * 4u + (pp ? offB : 0u) : kPOob, 0, 0);
         nv = 0.0f;
-        if (near) {
-            j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, ok ? (uint32_t)o * 4u + (pp ? offB : 0u) : kPOob, 0, 0);
-        } else if (ok) {
-            j = p.idx[(pp ? rb1 : rb0) + o];
-        }
         if (nval && ok) nv = nval[(pp ? rb1 : rb0) + o];
     };
     auto ld_pos = [&](int j, float& x, float& y, float& z) {  // a scalar base + one 24-bit multiply
@@ -355,16 +352,18 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
             const bool more = t + 1 < NB;
             const int np = npairs(t), np1 = more ? npairs(t + 1) : 0;
             PairRec nxt;
+            // what this iteration requests lands in its OWN registers and moves to the loop-carried ones after the splat: a copy
+            // placed before it would wait for every load in flight (the counter is in order)
+            int jn = 0;
+            float nvn = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f;
             if (more) {
                 nxt = geom(t + 1, j1, nv1, px, py, pz);
                 push_index(t + 1, j1);
                 pfence();
                 PT(1)
                 f_issue(np1, ff);
-                ld_pos(j2, px, py, pz);
-                j1 = j2;
-                nv1 = nv2;
-                ld_idx(t + 3, j2, nv2);
+                ld_pos(j2, qx, qy, qz);
+                ld_idx(t + 3, jn, nvn);
                 PT(2)
             }
             splat((np + 7) >> 3, cc);
@@ -378,6 +377,13 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
                 PT(6)
                 push_rec(nxt);
                 pack_classes(nxt.cls4, cc);
+                j1 = j2;
+                nv1 = nv2;
+                j2 = jn;
+                nv2 = nvn;
+                px = qx;
+                py = qy;
+                pz = qz;
                 pfence();
                 PT(7)
             }
@@ -532,7 +538,9 @@ bool cconv_pair_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     // 24-bit multiplies form the byte offsets of feature and position rows; the buffers must stay below 2 GB
     if (a->n_inp >= (1 << 24) || a->n_inp * (int64_t)cin * 4 >= ((int64_t)1 << 31)) return false;
     if (e) return true;
-    return false;
+    // more than 16 channels (one walk instead of splat D's two) and rows long enough to pay for the per-point merge: the 3e8-pair
+    // layers 24 -> 8 / 24 -> 4 take 7.7 / 4.8 ms here against 8.8 / 6.9 with splat E, the 33-pair layers 3.4 - 4.5 against 2.7 - 3.7
+    return cin > 16 && a->row_length_hint == 2;
 }
 
 int cconv_pair_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {

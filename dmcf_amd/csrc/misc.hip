@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* 
 
 extern "C" {
 
-int dmcf_version(void) { return 20200; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF
+int dmcf_version(void) { return 20300; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF; 2.3.0: row_length_hint (splat F)
 
 const char* dmcf_error_string(int code) {
     switch (code) {

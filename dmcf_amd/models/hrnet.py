@@ -87,6 +87,9 @@ class HRNet(PBFNet):
                     ext = filter_extent[max(inp_scale, scale)]
                     conv_in = feats if importance == 1.0 else feats * importance
                     conv = self.convs[layer][scale][0][inp_scale]
+                    # a layer's rows: ~33 neighbours at the base radius, 8 x / 64 x that at the wider ones (the coarser point
+                    # sets keep the particles' spacing up to scale 1) -- configuration, not list contents
+                    conv.row_length_hint = 2 if max(inp_scale, scale) > 0 and self.particle_radii[max(inp_scale, scale)] > self.particle_radii[0] else 1
                     if scale == 0 and (layer, inp_scale) in stash:
                         ans_conv = stash.pop((layer, inp_scale))  # came out of the previous layer's paired launch
                     elif scale == 0 and inp_scale in cross:

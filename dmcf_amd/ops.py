@@ -418,7 +418,7 @@ def _empty(t):
 def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index, neighbors_row_splits,
                 neighbors_value, window, window_fac, inp_importance, align_corners, coordinate_mapping, interpolation,
                 normalize, symmetric, sym_axis, bias, out, accumulate, neighbors_row_count=None, filter_tile_mask=0,
-                skip_self=False):
+                skip_self=False, row_length_hint=0):
     """Validate the operands and fill a ``dmcf_cconv_args``; returns (args, keepalive tensors, out)."""
     filters = _dev_f32(filters, "filters")
     if filters.dim() != 5:
@@ -477,6 +477,7 @@ def _cconv_args(filters, out_positions, extent, inp_positions, inp_features, nei
     a.n_pairs = neighbors_index.shape[0]
     a.neighbors_row_count = None
     a.filter_tile_mask = int(filter_tile_mask) & 0xffffffff
+    a.row_length_hint = int(row_length_hint)
     if neighbors_row_count is not None:
         if neighbors_row_count.dtype != torch.int32 or neighbors_row_count.shape[0] != n_out:
             raise TypeError("neighbors_row_count must be int32 [n_out]")
@@ -636,8 +637,10 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
                   neighbors_row_splits, neighbors_value=None, window=None, window_fac=1.0, inp_importance=None,
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
                   normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False,
-                  n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False):
-    """One call of dmcf_cconv_forward.  ``skip_self``: DMCF_FLAG_SKIP_SELF (the list holds the query points, the layer ignores them; only the direct kernel).  ``name_only``: no launch, returns the name of the kernel these arguments dispatch to.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
+                  n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False,
+                  row_length_hint=0):
+    """One call of dmcf_cconv_forward.  ``row_length_hint``: 0 unknown / 1 tens / 2 hundreds of neighbours per row -- what the
+    caller knows about the LAYER from its configuration (include/dmcf_hip.h).  ``skip_self``: DMCF_FLAG_SKIP_SELF (the list holds the query points, the layer ignores them; only the direct kernel).  ``name_only``: no launch, returns the name of the kernel these arguments dispatch to.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
     """
     L = _lib.lib()
@@ -660,7 +663,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     a, keep = _cconv_args(filters, out_positions, extent, inp_positions, inp_features, neighbors_index,
                           neighbors_row_splits, neighbors_value, window, window_fac, inp_importance, align_corners,
                           coordinate_mapping, interpolation, normalize, symmetric, sym_axis, bias, out, accumulate,
-                          neighbors_row_count, filter_tile_mask, skip_self)
+                          neighbors_row_count, filter_tile_mask, skip_self, row_length_hint)
     if name_only:
         name = ctypes.create_string_buffer(96)
         _lib.check(L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96), "dmcf_cconv_kernel_name")

@@ -333,6 +333,9 @@ class ContinuousConv(torch.nn.Module):
         self._device = device
         self.nns = None
         self._direct_kernel = None  # is this layer served by cconv_direct_kernel (learnt at its first call in a step)
+        # what the MODEL knows about this layer's rows from its configuration (include/dmcf_hip.h, row_length_hint): 0 unknown,
+        # 1 = the network's base radius (tens of neighbours), 2 = a wider radius (hundreds); models/hrnet.py sets it
+        self.row_length_hint = 0
 
     # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
     def build(self, in_channels, device=None):
@@ -467,7 +470,7 @@ class ContinuousConv(torch.nn.Module):
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
             bias=self.bias if fuse_bias else None, n_pairs_ref=n_pairs_ref,
-            neighbors_row_count=row_count, skip_self=skip_self)
+            neighbors_row_count=row_count, skip_self=skip_self, row_length_hint=self.row_length_hint)
         if self._direct_kernel is None and in_step and self.radius_search_ignore_query_points:
             # (asked once per layer: the dispatch looks at the layer, never at the list)
             self._direct_kernel = ops.cconv_forward(

@@ -188,6 +188,13 @@ typedef struct dmcf_cconv_args {
                                   16 (o / 16) .. + 15 in some filter cell (c < 32, o < 64).  0 = no hint (every block is
                                   multiplied).  Kernels may skip the fetch and the products of unset blocks; results are
                                   identical for finite features (a skipped product is an exact zero). */
+    int32_t row_length_hint;   /* optional, a property of the LAYER the caller knows from its configuration (the dispatch never
+                                  looks at the neighbour list itself: the same step gives the same bits on CSR and on padded
+                                  lists): 0 = unknown, 1 = rows of tens of neighbours (a layer at the network's base radius,
+                                  models/hrnet.py:86 with inp_scale = out_scale = 0), 2 = rows of hundreds or more (any wider
+                                  radius).  With 2, layers of 17 .. 32 input channels and 4 x 4 x 4 filters take the
+                                  pair-per-instruction kernel ("cconv_pair_kernel..."), which needs long rows to pay for
+                                  its per-point merge. */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);

@@ -671,6 +671,26 @@ def test_farthest_point_sample_matches_oracle(oracle, dev, kind, n, m):
     assert np.array_equal(got, feats[ref])
 
 
+def test_row_length_hint_picks_the_kernel_for_wide_layers(oracle, dev):
+    """include/dmcf_hip.h, row_length_hint: layers of 17 .. 32 input channels take the pair-per-instruction kernel when the caller
+    says their rows are long, the plane-sorted one otherwise; both agree with the oracle (and narrower layers ignore the hint)."""
+    from dmcf_amd import ops
+    radius = 0.3
+    inp, out, feat, filt = _conv_inputs(oracle, 23, 3000, 700, 24, 8, (4, 4, 4), radius)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=False)
+    oi, orr, od = oracle.fixed_radius_search(inp, out, radius, False)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, oi, orr, oracle.window("poly6", od / np.float32(radius) ** 2), f64=True)
+    call = lambda **kw: ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                                          nns.neighbors_row_splits, window="poly6", **kw)
+    names = {h: call(row_length_hint=h, name_only=True) for h in (0, 1, 2)}
+    assert names[0].startswith("cconv_z3_kernel") and names[1].startswith("cconv_z3_kernel") and names[2].startswith("cconv_pair_kernel")
+    for h in (0, 2):
+        _close(call(row_length_hint=h).cpu().numpy(), ref)
+    f16 = _t(filt[..., :16, :], dev)
+    assert ops.cconv_forward(f16, _t(out, dev), 2 * radius, _t(inp, dev), _t(feat[:, :16].copy(), dev), nns.neighbors_index,
+                             nns.neighbors_row_splits, window="poly6", row_length_hint=2, name_only=True).startswith("cconv_cls_kernel")
+
+
 @pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("cls", 24, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
                                                 ("z3", 24, 16, (4, 4, 4)), ("pair", 24, 16, (4, 4, 4)), ("pair", 32, 40, (4, 4, 4)),
                                                 ("direct", 32, 3, (6, 6, 6)), ("lds", 4, 8, (3, 5, 2))])
