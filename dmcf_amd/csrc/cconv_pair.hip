@@ -12,10 +12,9 @@
 // channels).  The accumulator is the tile of the pair's class: 27 tiles x 4 registers hold B_i with every cell in up to 8
 // tiles, addressed relative to M0 = 4 * class (s_set_gpr_idx_on: the class is data, not control flow).  Nothing is ordered,
 // nothing is padded, the A operand needs no arithmetic in the splat: per pair one scalar bit-field extract, one M0 update,
-// one matrix instruction and 1.25 LDS reads (the products are staged pair-interleaved and read four pairs at a time, the
-// feature rows row-major, one ds_read_b32 per pair).
-// Measured (tools/ubench/pair_splat.hip): 13.4 clocks per pair and SIMD with both operands in groups of four against 10.9
-// for the bare matrix instructions.
+// one matrix instruction and half an LDS read (products and features are staged pair-interleaved and read four pairs at a
+// time).  Measured (tools/ubench/pair_splat.hip): 12.7 - 13.4 clocks per pair and SIMD against 10.9 for the bare matrix
+// instructions (17.1 with row-major features, one ds_read_b32 per pair).
 //
 // The price is registers: 108 for the tiles.  So a workgroup is 8 waves (two per SIMD, 256 registers each), one workgroup
 // per CU, and a wave owns TWO output points of the 16-point tile, one after the other as one stream of 64-pair batches (loads
@@ -28,10 +27,10 @@
 //              tests/test_fixed_registers.py)
 //   LDS:       B tile [16 points][64 cells x 16 channels] 64 KB (one 16-channel chunk at a time, as in cconv_cls.hip) +
 //              per wave the records [16 groups][8 products][4 pairs] (group stride 36 floats: conflict-free stores), the
-//              features [64 pairs][32 channels] and an index buffer: 148 KB
+//              features [16 groups][32 channels][4 pairs] and an index buffer: 148 KB
 //
-// Per batch: geometry (lane = pair), the 8 products and the class; feature rows by 16-byte loads, lane = (pair, channel quad)
-// (a pair-interleaved feature layout would halve the splat's LDS reads, but its transposition needs 4-byte loads: 34 memory
+// Per batch: geometry (lane = pair), the 8 products and the class; feature rows by 16-byte loads, lane = (pair, channel quad),
+// transposed into the pair-interleaved layout by their LDS stores (transposing with 4-byte LOADS instead costs 34 memory
 // instructions per batch instead of 10, and the texture addresser then bounds the kernel -- measured, tools/ptrace.py: 920
 // clocks per batch in the issue phase); class bytes packed inside each quad by two DPP moves and read out with 16 v_readlane
 // (a v_readlane per pair would cost the SIMD 8 clocks each).  With two waves
@@ -61,7 +60,7 @@ constexpr int PTM = 2 * kPWaves;   // output points per workgroup = rows of the 
 constexpr int kPRow = 1024;        // floats per B row: k' = (z * 4 + y) * 64 + channel * 4 + x (16 channels)
 constexpr int kPRecG = 36;         // floats per record group: 8 products x 4 pairs, padded (bank = 4 g + 4 q + t)
 constexpr int kPRec = 16 * kPRecG;
-constexpr int kPFst = 64 * 32;     // [64 pairs][32 channels]
+constexpr int kPFst = 16 * 128;    // [16 groups][32 channels (permuted)][4 pairs]
 constexpr int kPWaveF = kPRec + kPFst + 64;  // + the index buffer
 constexpr int kPMaxNT = 4;
 constexpr int kPCompilerVgprs = 58;  // (the attribute counts HALF of the unified file: v0 .. v115)
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
     const float* const imp = PLAIN ? nullptr : p.inp_imp;
     float* Bt = smem;                                    // [PTM][kPRow], 4-float groups XOR-swizzled by the row
     float* Rec = smem + PTM * kPRow + wave * kPWaveF;    // [16 groups][kPRecG]: product q of pair 4 g + t at g * kPRecG + 4 q + t
-    float* Fst = Rec + kPRec;                            // [64 pairs][32 channels]
+    float* Fst = Rec + kPRec;                            // [16 groups][32 channels (permuted)][4 pairs]
     uint32_t* Jof = (uint32_t*)(Fst + kPFst);            // [64]: byte offset of the pair's feature row (kPOob: no pair)
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
@@ -259,17 +258,29 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
             }
         }
     };
+    // ... and transposed by the stores into the pair-interleaved layout the splat reads four pairs at a time: channel c of pair
+    // 4 g + t at Fst[g * 128 + 4 c' + t] with c' = 8 (c & 3) + (((c >> 2) + 4 ((c >> 1) & 1)) & 7), a permutation of the channels
+    // under which these 4-byte stores (two ds_write2_b32 per loaded row part) AND the splat's 16-byte reads are conflict free
+    const int pg = fr >> 2, ptq = fr & 3;
+    float* const w01 = Fst + pg * 128 + 4 * fq + ptq;             // channels 4 fq, 4 fq + 1: + 0, + 32
+    float* const w23 = Fst + pg * 128 + 4 * ((fq + 4) & 7) + ptq; // channels 4 fq + 2, 4 fq + 3: + 64, + 96
     auto f_publish = [&](int np, const f32x4 (&f)[8]) {
 #ifdef PX_NOPUBLISH
         return;
 #endif
 #pragma unroll
-        for (int r = 0; r < 8; ++r)
-            if (r < 4 || np > 32) *(f32x4*)(Fst + (8 * r + fr) * 32 + 4 * fq) = f[r];
+        for (int r = 0; r < 8; ++r) {
+            if (r < 4 || np > 32) {
+                w01[256 * r] = f[r].x;
+                w01[256 * r + 32] = f[r].y;
+                w23[256 * r + 64] = f[r].z;
+                w23[256 * r + 96] = f[r].w;
+            }
+        }
     };
     // LDS byte addresses of this lane's operands of group 0: product 4 z' + (y', x') of the lane's block row, its channel
     const uint32_t a_rec = plds(Rec + 4 * (4 * half + (lane & 3)));
-    const uint32_t a_fst = plds(Fst + ch);
+    const uint32_t a_fst = plds(Fst + 4 * (8 * (ch & 3) + (((ch >> 2) + 4 * ((ch >> 1) & 1)) & 7)));
     // One batch: 64 pairs at fixed staging addresses, `nblk` blocks of 8 (tools/gen_pair_splat.py)
     auto splat = [&](int nblk, const uint32_t (&c)[16]) {
 #ifdef PX_NOSPLAT

@@ -22,10 +22,10 @@ TILE0 = 148                  # first tile register
 OPA, OPF = 116, 132          # operand buffers: 16 registers each (2 block parities x 8 pairs)
 NBLK = 8
 
-# diagnostic variants for tools/ubench/pair_splat.hip (comma separated flags): b64 = groups of 2 pairs (ds_read_b64), fgroup =
-# features staged pair-interleaved like the products (one read per group), noreads = no operand reads, noclass = no M0 updates
-# (every pair into tile 0); ubench = unpadded record groups
-UBENCH_VARIANTS = ["b64,ubench,fgroup", "fgroup,ubench", "noclass,ubench"]
+# diagnostic variants for tools/ubench/pair_splat.hip (comma separated flags): b64 = groups of 2 pairs (ds_read_b64), frow =
+# features staged row-major (one ds_read_b32 per pair), noreads = no operand reads, noclass = no M0 updates (every pair into
+# tile 0); ubench = unpadded record groups
+UBENCH_VARIANTS = ["b64,ubench", "frow,ubench", "noclass,ubench"]
 
 
 def generate(name, variant="", outdir=None):
@@ -34,10 +34,10 @@ def generate(name, variant="", outdir=None):
     # floats: the owner lanes' 4-byte stores then hit 32 different banks)
     a_bytes, f_bytes = (144 if gp == 4 and "ubench" not in variant else 8 * 4 * gp), 32 * 4 * gp
     rd = "ds_read_b64" if gp == 2 else "ds_read_b128"
-    # The product stages the FEATURES row-major ([pair][32 channels], 16-byte loads and stores, lane = (pair, channel quad):
-    # a quarter of the memory instructions of a pair-interleaved layout, whose transposition needs 4-byte loads -- and the texture
-    # addresser, not the matrix pipe, then bounds the kernel): the B operand is one ds_read_b32 per pair
-    frow = "fgroup" not in variant
+    # The product stages the features pair-interleaved too ([group][32 channels][4 pairs]: one ds_read_b128 per FOUR pairs;
+    # cconv_pair.hip transposes with its LDS stores -- the loads stay 16 bytes per lane); frow: row-major [pair][32 channels], one
+    # ds_read_b32 per pair (17.1 instead of 12.7 clocks per pair and SIMD, tools/ubench/pair_splat.hip)
+    frow = "frow" in variant
 
     def opreg(base, pair):  # register holding the operand of `pair` (two buffers of 8)
         return base + (pair & 15)

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))
     for (int q = 0; q < 8; ++q) Rec[(lane / GP) * RG + q * GP + (lane % GP)] = (lane < npairs) ? (lane + 1) * 0.25f + q * 16.0f : 0.0f;
     for (int c = 0; c < 32; ++c) {
         const float f = (float)(c + 1) + 64.0f * (lane % 3);
-        if (VARIANT == 0 || VARIANT == 3) Fst[lane * 32 + c] = f;  // row-major: [pair][32 channels]
+        if (VARIANT == 2) Fst[lane * 32 + c] = f;  // row-major: [pair][32 channels]
         else Fst[(lane / GP) * 32 * GP + c * GP + (lane % GP)] = f;
     }
     __syncthreads();
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))
 #pragma unroll
     for (int m = 0; m < 16; ++m) c[m] = __builtin_amdgcn_readlane(pk, 4 * m);
     const uint32_t pa = lds_addr(Rec) + 4 * GP * (4 * (lane >> 5) + (lane & 3));
-    const uint32_t pf = lds_addr(Fst) + 4 * ((VARIANT == 0 || VARIANT == 3) ? 1 : GP) * (lane & 31);
+    const uint32_t pf = lds_addr(Fst) + 4 * (VARIANT == 2 ? 1 : GP) * (lane & 31);
     const int nb = (npairs + 7) >> 3;
     zero_tiles();
     uint32_t s0;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64 * kWaves, 1) __attribute__((amdgpu_num_vgpr(58))
 typedef void (*kern_t)(float*, long long*, int, int, int);
 constexpr int kNV = 4;
 static const kern_t kKernels[kNV] = {splat_loop<0>, splat_loop<1>, splat_loop<2>, splat_loop<3>};
-static const char* kNames[kNV] = {"product (products in groups of 4, features row-major)", "groups of 2, ds_read_b64", "features in groups of 4 too", "noclass"};
+static const char* kNames[kNV] = {"product (products and features in groups of 4)", "groups of 2, ds_read_b64", "features row-major, ds_read_b32", "noclass"};
 
 int main(int argc, char** argv) {
     const int npairs = argc > 1 ? atoi(argv[1]) : 64;
