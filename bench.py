@@ -79,6 +79,15 @@ def cpu_baseline(side, weights, cfg):
                        f"{ref.pairs} neighbour pairs")
 
 
+def scene_snapshot(pos, vel, lo, hi):
+    """What state the scene is in (outside the timed region): fluid particles outside the boundary shell's bounding box, the
+    largest speed.  The 5 m column of config 5 is far outside what the network was trained on: from step ~10 on particles leak
+    through the 2-layer shell, rows get longer and a step costs more -- the line says so."""
+    import torch
+    out = ((pos < lo) | (pos > hi)).any(dim=1).sum()
+    return [int(out.item()), float(vel.norm(dim=1).max().item()) if pos.shape[0] else 0.0]
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -260,6 +269,18 @@ def main():
 
     for _ in range(args.warmup):
         state = step(state)
+    _pv = (lambda st: (st["pos"], st["vel"]) if isinstance(st, dict) else (st[0], st[1]))
+    shell_lo = torch.tensor(scene["box"].min(axis=0), device=dev) if scene["box"].shape[0] else None
+    shell_hi = torch.tensor(scene["box"].max(axis=0), device=dev) if scene["box"].shape[0] else None
+    if sharded:  # the shell of the WHOLE box: every rank holds a piece of it
+        big = 3.0e38
+        lohi = torch.cat([-(shell_lo if shell_lo is not None else torch.full((3,), big, device=dev)),
+                          shell_hi if shell_hi is not None else torch.full((3,), -big, device=dev)])
+        dist.all_reduce(lohi, op=dist.ReduceOp.MAX)
+        shell_lo, shell_hi = -lohi[:3], lohi[3:]
+    snap0 = scene_snapshot(*_pv(state), shell_lo, shell_hi)
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    repeated0 = 0 if sharded else sim.repeated_steps
     if os.environ.get("DMCF_BENCH_DEBUG"):
         torch.cuda.reset_peak_memory_stats(dev)
     if rank == 0 and os.environ.get("DMCF_BENCH_NOTIMER") != "1":
@@ -278,6 +299,25 @@ def main():
     elapsed = time.perf_counter() - t0
     timer, ops.timer = (ops.timer if ops.timer is not None else ops.LaunchTimer()), None
     assert torch.isfinite(state["pos"] if isinstance(state, dict) else state[0]).all()
+    from dmcf_amd.utils.convolutions import neighbor_hints
+    snap1 = scene_snapshot(*_pv(state), shell_lo, shell_hi)
+    allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
+    if sharded:
+        t2 = torch.tensor([snap0[0], snap1[0], allocs], dtype=torch.int64, device=dev)
+        dist.all_reduce(t2)
+        v2 = torch.tensor([snap0[1], snap1[1]], dtype=torch.float64, device=dev)
+        dist.all_reduce(v2, op=dist.ReduceOp.MAX)
+        snap0, snap1, allocs = [int(t2[0]), float(v2[0])], [int(t2[1]), float(v2[1])], int(t2[2])
+    extra["scene_state"] = {
+        "simulated_steps_before_window": args.warmup, "simulated_steps_at_end": args.warmup + args.steps,
+        "fluid_outside_shell_at_window_start": snap0[0], "fluid_outside_shell_at_end": snap1[0],
+        "max_speed_at_window_start": snap0[1], "max_speed_at_end": snap1[1],
+        "longest_rows_last_step": sorted({int(h) for h in neighbor_hints() if h is not None}),
+        "repeated_steps_in_window": None if sharded else sim.repeated_steps - repeated0,
+        "device_allocations_in_window": int(allocs),
+        "reserved_gib": torch.cuda.memory_stats(dev)["reserved_bytes.all.current"] / 2 ** 30,
+        "note": "config 5's 5 m column is far outside the network's training range: particles leak through the 2-layer shell "
+                "as the rollout goes on, rows lengthen and steps get slower (DESIGN.md section 4.1)"}
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

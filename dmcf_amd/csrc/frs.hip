@@ -281,6 +281,63 @@ __device__ __forceinline__ int wave_inclusive_add(int v) {
     return v;
 }
 
+// ---- what Open3D's search can SEE (DMCF_FRS_OPEN3D_CORNER_VOXELS) ----------------------------------------------------------
+// open3d 0.15.2 (FixedRadiusSearchImpl.h, restated in oracle/dmcf_oracle.c) hashes the points into voxels of edge 2 R and, for a
+// query, visits the hash bins of the 8 voxels holding the corners q +- R.  In exact arithmetic those voxels cover the search
+// sphere.  In float they need not: with q a rounding step from the middle of a voxel, floor(fl(q - R) / 2R) and floor(fl(q + R) /
+// 2R) can be TWO apart -- the voxel between them, where the query itself and most of its neighbours live, is then never visited
+// and the reference returns a nearly empty row (seen: one query in 10^6 per search of the 1M-particle rollout; the particle
+// then gets a visibly different correction, tools/diag_degraded.py).  A pair at distance R within rounding can likewise sit in
+// a voxel one step outside the corners.  With the flag set the scan reproduces that visibility: a hit counts only if the
+// point's voxel hashes into one of the query's 8 bins.  Tested where it can matter, at almost no cost elsewhere: every hit of
+// a query whose corner voxels are two apart on some axis, otherwise only hits in the outermost shell of the sphere, where
+// rounding could put the point's voxel outside [corner-, corner+].
+__device__ __forceinline__ uint64_t o3d_spatial_hash(int x, int y, int z) {
+    const uint32_t hsh = ((uint32_t)x * 73856096u) ^ ((uint32_t)y * 193649663u) ^ ((uint32_t)z * 83492791u);
+    return (uint64_t)(int64_t)(int32_t)hsh;  // (int arithmetic, converted to size_t: sign extended)
+}
+
+struct O3dView {
+    int vlo[3], vhi[3];  // voxels of the corners q - R, q + R per axis
+    float inv_voxel;
+    float r2_inner;      // hits with d^2 above this take the exact visibility test (-1: all of them)
+};
+
+__device__ __forceinline__ O3dView o3d_view(const float (&q)[3], float radius, float r2) {
+    O3dView v;
+    const float voxel = __fmul_rn(2.0f, radius);
+    v.inv_voxel = __fdiv_rn(1.0f, voxel);
+    bool gap = false;
+    float qmax = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        v.vlo[a] = (int)floorf(__fmul_rn(__fsub_rn(q[a], radius), v.inv_voxel));
+        v.vhi[a] = (int)floorf(__fmul_rn(__fadd_rn(q[a], radius), v.inv_voxel));
+        gap |= v.vhi[a] - v.vlo[a] > 1;
+        qmax = fmaxf(qmax, fabsf(q[a]));
+    }
+    // d^2 <= R^2 (1 - delta) puts every coordinate of the point inside [fl(q - R), fl(q + R)] -- whose voxels are the corners'
+    // or lie between them -- when delta / 2 exceeds the relative rounding of q +- R (6e-8 (|q| + R) / R) and of the distance
+    const float delta = 1e-6f * (qmax * __builtin_amdgcn_rcpf(radius) + 1.0f);
+    v.r2_inner = (gap || !(delta < 0.5f)) ? -1.0f : r2 * (1.0f - delta);
+    return v;
+}
+
+__device__ __noinline__ bool o3d_visible(float px, float py, float pz, const O3dView& v, int64_t n_points) {
+    const int x = (int)floorf(__fmul_rn(px, v.inv_voxel)), y = (int)floorf(__fmul_rn(py, v.inv_voxel)),
+              z = (int)floorf(__fmul_rn(pz, v.inv_voxel));
+    if ((x == v.vlo[0] || x == v.vhi[0]) && (y == v.vlo[1] || y == v.vhi[1]) && (z == v.vlo[2] || z == v.vhi[2])) return true;
+    // not one of the 8 voxels: still found if its bin is (the FixedRadiusSearch layer's table: n / 64 bins, 1 .. 2^25)
+    int64_t size = n_points / 64;
+    size = size < 1 ? 1 : (size > 33554432 ? 33554432 : size);
+    const uint64_t bin = o3d_spatial_hash(x, y, z) % (uint64_t)size;
+    for (int c = 0; c < 8; ++c) {
+        const uint64_t cb = o3d_spatial_hash((c & 1) ? v.vhi[0] : v.vlo[0], (c & 2) ? v.vhi[1] : v.vlo[1], (c & 4) ? v.vhi[2] : v.vlo[2]) % (uint64_t)size;
+        if (cb == bin) return true;
+    }
+    return false;
+}
+
 // The candidate scan of one query by one wavefront.  MODE 0: count the hits; MODE 1: write them to the CSR row at
 // out_base; MODE 2: add window(d^2 / R^2) of every hit to `wsum` (per lane; the caller reduces over the wave).
 // Returns the number of hits.  Hits come out in a fixed order (cell rows, then position in the cell-sorted array).
@@ -295,6 +352,10 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
     for (int w = 0; w < kWin; ++w) marks[w * kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
     const float q[3] = {qx, qy, qz};
     const float r2 = __fmul_rn(radius, radius);
+    const bool o3d = (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) != 0;
+    O3dView view;
+    view.r2_inner = r2;
+    if (o3d) view = o3d_view(q, radius, r2);
     int lo[3], hi[3];
     bool empty = h->ncells <= 0 || h->n_points <= 0;
 #pragma unroll
@@ -385,6 +446,12 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                     hit = d2 <= r2;
                     if (ignore && p.x == qx && p.y == qy && p.z == qz) hit = false;
                     pidx = __float_as_int(p.w);
+                }
+                if (o3d) {  // (rare: the outermost shell of the sphere, or a query whose corner voxels are two apart)
+                    const bool check = hit && d2 > view.r2_inner;
+                    if (__ballot(check) != 0ull) {
+                        if (check) hit = o3d_visible(p.x, p.y, p.z, view, h->n_points);
+                    }
                 }
                 const unsigned long long mask = __ballot(hit);
                 if (MODE == 1 && hit) {

@@ -141,6 +141,10 @@ class PBFNet(BaseModel):
 
     conv_hook = None
     ghost_prefetch = None  # set together with conv_hook by the sharded driver: see HRNet.forward
+    # The sharded driver (dmcf_amd/parallel.py: ShardedSimulator) installs itself here for the duration of a step; preprocess asks
+    # it for the three things that need other ranks -- fluid_bounds(mn, mx), begin(all_pos, pos, box), dilated_pos(base) -- and
+    # every convolution goes through apply_conv / conv_hook.  None: one rank, the reference's own code path.
+    shard = None
 
     def apply_conv(self, conv, feats, inp_pos, out_pos, extent, widest_extent=None):
         """Every ContinuousConv call of the forward pass goes through here: ``conv(feats, inp_pos, out_pos, extent, None)``
@@ -212,7 +216,12 @@ class PBFNet(BaseModel):
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in self.particle_radii]  # :328
         # boundary particles outside the fluid AABB +- 2 r_max are dropped every step (:330-336)
         pt = pos.t().contiguous()  # [3, N]: row reductions (a strided column reduction of [N, 3] is ~0.6 ms each)
-        mn, mx = torch.aminmax(pt, dim=1)  # (one pass over the positions instead of two)
+        if pos.shape[0]:
+            mn, mx = torch.aminmax(pt, dim=1)  # (one pass over the positions instead of two)
+        else:  # (a rank of a sharded step may own no fluid at all)
+            mn, mx = pos.new_full((3,), 3.0e38), pos.new_full((3,), -3.0e38)
+        if self.shard is not None:
+            mn, mx = self.shard.fluid_bounds(mn, mx)
         lo = mn - filter_extent[-1]
         hi = mx + filter_extent[-1]
         fltr = ((box >= lo) & (box <= hi)).all(dim=1)
@@ -233,6 +242,8 @@ class PBFNet(BaseModel):
             box_feats.append(bfeats)
         all_pos = torch.cat([pos, box], dim=0)  # :349
         self.all_pos = all_pos
+        if self.shard is not None:
+            self.shard.begin(all_pos, pos, box)
         dens = None
         if self.dens_feats or self.dens_norm or self.pres_feats:  # :351-365
             win = get_window_func(self.window_dens)
@@ -254,8 +265,8 @@ class PBFNet(BaseModel):
         if fused is not None:
             ans_conv, ans_obs = fused
         else:
-            ans_conv = self.fluid_convs(fluid_feats * self.part_scale, pos, all_pos, filter_extent[0], None)  # :378
-            ans_obs = self.obs_convs(box_feats * self.part_scale, box, all_pos, filter_extent[0], None)  # :382
+            ans_conv = self.apply_conv(self.fluid_convs, fluid_feats * self.part_scale, pos, all_pos, filter_extent[0])  # :378
+            ans_obs = self.apply_conv(self.obs_convs, box_feats * self.part_scale, box, all_pos, filter_extent[0])  # :382
         ans_dense = self.fluid_dense(fluid_feats)
         ans_dense_obs = self.obs_dense(box_feats)
         ans_dense = torch.cat([ans_dense, ans_dense_obs], dim=0)
@@ -270,9 +281,12 @@ class PBFNet(BaseModel):
         else:
             fluid_feats = torch.cat([ans_conv, ans_obs, ans_dense], dim=-1)  # :411
 
-        dilated_pos, _, idx = get_dilated_pos(all_pos if self.use_bnds else pos, self.strides,
-                                              voxel_size=self.voxel_size, centralize=self.centralize,
-                                              pad=self.sample_pad, hyst=self.sample_hyst)  # :413-419
+        if self.shard is not None:
+            dilated_pos, idx = self.shard.dilated_pos(all_pos if self.use_bnds else pos)
+        else:
+            dilated_pos, _, idx = get_dilated_pos(all_pos if self.use_bnds else pos, self.strides,
+                                                  voxel_size=self.voxel_size, centralize=self.centralize,
+                                                  pad=self.sample_pad, hyst=self.sample_hyst)  # :413-419
         if self.dens_norm:  # :421-431
             dens = [(dens if self.use_bnds else dens[:pos.shape[0]]).unsqueeze(-1)]
             for scale in range(1, len(self.dens_radius)):
@@ -341,8 +355,15 @@ class PBFNet(BaseModel):
         if operands is None:
             return None
         feats, kernel, bias = operands
-        out, nns = self.fused_input_conv(kernel, bias, feats, all_pos, all_pos, extent)
         n, co = fluid_feats.shape[0], self.fluid_convs.filters
+        if self.conv_hook is not None:
+            # a sharded step: through the hook like every other convolution (one ghost exchange for both feature blocks); the
+            # fluid-neighbour counts below are a training-loss weight and are not formed there
+            out = self.apply_conv(lambda f, pi, po, ext, _: self.fused_input_conv(kernel, bias, f, pi, po, ext)[0],
+                                  feats, all_pos, all_pos, extent)
+            self._fluid_counts = None
+            return out[:, :co].contiguous(), out[:, co:].contiguous()
+        out, nns = self.fused_input_conv(kernel, bias, feats, all_pos, all_pos, extent)
         # fluid neighbours per fluid particle (pbf_model.py:450-453; only the training loss reads them): counted from the
         # shared list when first asked for -- the closure keeps the list's index buffer alive until the next step
         index = nns.raw()[0]
@@ -366,7 +387,9 @@ class PBFNet(BaseModel):
         pos, vel, acc = data[:3]
         pcnt = pos.shape[0]
         # number of fluid neighbours per particle (loss weight only; pbf_model.py:450-453)
-        if self.fluid_convs.nns is None and getattr(self, "_fluid_counts", None) is not None:
+        if self.shard is not None:
+            self._num_fluid_neighbors = None  # (a sharded step is inference only)
+        elif self.fluid_convs.nns is None and getattr(self, "_fluid_counts", None) is not None:
             self._num_fluid_neighbors = None  # formed by the property below when somebody reads it
         else:
             counts = ops.neighbor_counts(self.fluid_convs.nns)
@@ -378,6 +401,7 @@ class PBFNet(BaseModel):
         elif out.shape[-1] == 2:
             out = torch.cat([out, out[:, :1]], dim=-1)
         out_scale = torch.tensor(self.out_scale, dtype=torch.float32, device=pos.device)
+        self.net_output = out
         self.pos_correction = out_scale * out[:pcnt]  # :474
         self.obs = out_scale * out[pcnt:]
         if vel_corr is not None:

@@ -13,6 +13,7 @@ All arithmetic happens in libdmcf_hip.so through its C ABI (include/dmcf_hip.h).
 fallback: calling these with CPU tensors or without the built library raises.
 """
 import collections
+import os
 import ctypes
 
 import threading
@@ -289,6 +290,18 @@ def _size_class(x):
     return (x + g - 1) // g * g
 
 
+FRS_IGNORE_QUERY_POINT, FRS_OPEN3D_CORNER_VOXELS = 1, 2
+
+
+def frs_flags(ignore_query_point):
+    """Flags of the dmcf_frs_* entry points.  By default the search reproduces what open3d 0.15.2 can SEE (the hash bins of the 8
+    corner voxels of q +- R: include/dmcf_hip.h, DMCF_FRS_OPEN3D_CORNER_VOXELS) -- the reference's neighbour set bit for bit,
+    including the ~1 query in 10^6 whose row the reference leaves nearly empty; DMCF_FRS_BRUTE_FORCE_SET=1 returns the set of
+    the distance test instead."""
+    return ((FRS_IGNORE_QUERY_POINT if ignore_query_point else 0)
+            | (0 if os.environ.get("DMCF_FRS_BRUTE_FORCE_SET") == "1" else FRS_OPEN3D_CORNER_VOXELS))
+
+
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
                         hash_table=None, capacity_hint=None, row_stride=None):
     """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
@@ -310,7 +323,7 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         hash_table = build_spatial_hash_table(points, radius, n_queries=m)
     ws = hash_table.workspace
     nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
-    flags = 1 if ignore_query_point else 0
+    flags = frs_flags(ignore_query_point)
     dev = points.device
     row_splits = torch.empty(m + 1, dtype=torch.int64, device=dev)
     if row_stride is not None:
@@ -811,7 +824,7 @@ def window_sum(points, queries, radius, window=None, ignore_query_point=False, h
         hash_table = build_spatial_hash_table(points, radius, n_queries=m)
     nbytes = L.dmcf_frs_workspace_bytes(n, hash_table.n_queries_capacity)
     out = torch.empty(m, dtype=torch.float32, device=points.device)
-    _lib.check(L.dmcf_frs_window_sum(_ptr(queries), m, n, radius, 1 if ignore_query_point else 0, WINDOWS[window],
+    _lib.check(L.dmcf_frs_window_sum(_ptr(queries), m, n, radius, frs_flags(ignore_query_point), WINDOWS[window],
                                      _ptr(hash_table.workspace), nbytes, _ptr(out), _stream()), "dmcf_frs_window_sum")
     return out
 

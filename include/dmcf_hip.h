@@ -66,6 +66,13 @@ int dmcf_last_hip_error(void); /* hipError_t of the last failed enqueue on this 
  * here it is deterministic: ascending grid cell (z, y, x), then ascending point index.
  * ---------------------------------------------------------------------------------------------- */
 #define DMCF_FRS_IGNORE_QUERY_POINT 1
+/* Reproduce what open3d 0.15.2 can SEE: it visits the hash bins of the 8 voxels (edge 2 R) holding the corners q +- R, and in
+ * float arithmetic those need not cover the sphere -- for about one query in 10^6 (q a rounding step from the middle of a
+ * voxel) the two corner voxels of an axis are TWO apart and the reference returns a nearly empty row; a pair at distance R
+ * within rounding can sit one voxel outside as well.  With this flag a hit counts only if the point's voxel hashes into one of
+ * the query's 8 bins (table of clamp(n_points / 64, 1, 2^25) bins, the layer's default): the reference's set bit for bit
+ * (tested against the restatement of its hash search in oracle/).  Without it: the set of the distance test above. */
+#define DMCF_FRS_OPEN3D_CORNER_VOXELS 2
 
 /* bytes of workspace for a search structure over n_points that will serve up to n_queries queries */
 size_t dmcf_frs_workspace_bytes(int64_t n_points, int64_t n_queries);

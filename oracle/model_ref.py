@@ -81,7 +81,7 @@ class ModelRef:
         self._alias = {}
         self.nns_cache = {}
         self.pairs = 0
-        self.record = None  # set to [] to record every CConv call (inputs + output) of the next step
+        self.record = None  # set to [] (or a callable) to record every CConv call (inputs + output) of the next step
 
     # ---- weights --------------------------------------------------------------------------------
     def _conv_weights(self, index, alias=None):
@@ -109,9 +109,13 @@ class ModelRef:
         out = conv(feats, inp_pos, out_pos, f32(extent), nns=nns)
         self.last_nns = nns
         if self.record is not None:
-            self.record.append(dict(index=index, kernel=kernel, bias=None if symmetric else bias, feats=feats,
-                                    inp_pos=inp_pos, out_pos=out_pos, extent=float(extent), window=window,
-                                    ignore=ignore, symmetric=symmetric, nns=nns, out=out))
+            rec = dict(index=index, kernel=kernel, bias=None if symmetric else bias, feats=feats,
+                       inp_pos=inp_pos, out_pos=out_pos, extent=float(extent), window=window,
+                       ignore=ignore, symmetric=symmetric, nns=nns, out=out)
+            if callable(self.record):  # (a diagnostic that replays the call right away instead of keeping 1M-particle lists)
+                self.record(rec)
+            else:
+                self.record.append(rec)
         return out
 
     # ---- stages ---------------------------------------------------------------------------------
@@ -199,6 +203,7 @@ class ModelRef:
             dilated, self.fps_idx = O.get_dilated_pos_fps(base, self.strides)  # losses.py:274-282
         dilated = [np.ascontiguousarray(d) for d in dilated]
         dilated[0] = base  # keep identity for the neighbour cache
+        self.dilated_pos = dilated  # (diagnostics: tools/diag_degraded.py compares the lattices point by point)
         self.dens = None
         if self.dens_norm:  # pbf_model.py:421-431
             self.dens = [(dens if self.use_bnds else dens[:pos.shape[0]])[:, None].astype(f32)]

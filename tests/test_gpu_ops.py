@@ -67,7 +67,7 @@ def test_frs_rows_deterministic_order(oracle, dev):
     assert torch.equal(a.neighbors_distance, b.neighbors_distance)
 
 
-def test_frs_edge_cases(oracle, dev):
+def test_frs_edge_cases(oracle, dev, monkeypatch):
     from dmcf_amd import ops
     # empty point set / empty query set
     r = ops.fixed_radius_search(torch.zeros(0, 3, device=dev), _t(_cloud(5, 0), dev), 0.3)
@@ -85,13 +85,15 @@ def test_frs_edge_cases(oracle, dev):
     a = _cloud(3000, 3, scale=0.5)
     b = _cloud(3000, 4, scale=0.5) + np.float32([4000.0, -2500.0, 900.0])
     pts = np.concatenate([a, b])
-    # at |x| ~ 4000 one float ulp is 0.5 % of R: Open3D's corner-voxel candidate set (restated by the
-    # hash oracle) drops a few pairs whose voxel lies one rounding step outside fl(q +- R); the contract
-    # of the HIP path is the distance test itself, i.e. the brute-force set, of which the hash result
-    # is a subset (documented deviation).
-    idx, rs, d = _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False, bruteforce=True)
-    ih, rh, dh = oracle.fixed_radius_search(pts, pts[::3].copy(), 0.05, False)
-    assert np.all(np.diff(rh) <= np.diff(rs)) and 0 < rs[-1] - rh[-1] < 0.01 * rs[-1]
+    # at |x| ~ 4000 one float ulp is 0.5 % of R: Open3D's corner-voxel candidate set (restated by the hash oracle) drops a few
+    # pairs whose voxel lies one rounding step outside fl(q +- R).  By default the HIP search reproduces exactly that visibility
+    # (DMCF_FRS_OPEN3D_CORNER_VOXELS: the reference's set bit for bit); DMCF_FRS_BRUTE_FORCE_SET=1 gives the set of the distance
+    # test, of which the reference's is a subset.
+    idx, rs, d = _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False)
+    monkeypatch.setenv("DMCF_FRS_BRUTE_FORCE_SET", "1")
+    ib, rb, db = _check_search(oracle, dev, pts, pts[::3].copy(), 0.05, False, bruteforce=True)
+    assert np.all(np.diff(rs) <= np.diff(rb)) and 0 < rb[-1] - rs[-1] < 0.01 * rb[-1]
+    monkeypatch.delenv("DMCF_FRS_BRUTE_FORCE_SET")
     # queries far outside the bounding box of the points
     _check_search(oracle, dev, a, b[:100].copy(), 0.2, False)
     # a bulk plus OUTLIERS with neighbours of their own: the grid covers mean +- 3 sigma of the points (frs_finish_header),
@@ -111,12 +113,46 @@ def test_frs_edge_cases(oracle, dev):
     out.append(rng.uniform(-40, 40, size=(30, 3)).astype(np.float32))
     pts = np.concatenate([bulk] + out).astype(np.float32)
     for ign in (False, True):
-        idx, rs, d = _check_search(oracle, dev, pts, pts.copy(), 0.1, ign, bruteforce=True)
+        idx, rs, d = _check_search(oracle, dev, pts, pts.copy(), 0.1, ign)
         assert int(np.diff(rs)[6000:6000 + 26 * 12].min()) >= (11 if ign else 12)  # every cluster member sees its cluster
     # all points identical
     same = np.zeros((300, 3), np.float32) + np.float32(0.25)
     _check_search(oracle, dev, same, same[:10].copy(), 0.1, False)
     _check_search(oracle, dev, same, same[:10].copy(), 0.1, True)
+
+
+def test_frs_reproduces_the_reference_at_voxel_midpoints(oracle, dev, monkeypatch):
+    """open3d visits the 8 voxels (edge 2 R) holding the corners q +- R.  For a query a rounding step from the MIDDLE of a voxel
+    the two corner voxels of that axis can be two apart: the voxel between them -- the query's own -- is never visited and the
+    reference's row is nearly empty (found by tools/diag_degraded.py: one query in 10^6 per search of the 1M-particle rollout,
+    e.g. z = 1.3 with R = 0.1).  The default search reproduces the reference's set bit for bit; DMCF_FRS_BRUTE_FORCE_SET=1
+    returns the full set of the distance test."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(3)
+    pts = rng.uniform(0.0, 2.0, size=(20000, 3)).astype(np.float32)
+    qs = rng.uniform(0.2, 1.8, size=(4000, 3)).astype(np.float32)
+    R = np.float32(0.1)
+    # queries at (k + 1/2) * 2 R -+ a few ulps on one axis: some of them hit the double rounding
+    mids = (np.arange(1, 9, dtype=np.float32) + np.float32(0.5)) * (np.float32(2) * R)
+    k = 0
+    for a in range(3):
+        for mval in mids:
+            for step in (-2, -1, 0, 1, 2):
+                v = mval
+                for _ in range(abs(step)):
+                    v = np.nextafter(v, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+                qs[k, a] = v
+                k += 1
+    idx, rs, d = _check_search(oracle, dev, pts, qs, float(R), False)   # == the hash oracle, row by row
+    ib, rb, db = oracle.fixed_radius_search(pts, qs, float(R), False, bruteforce=True)
+    assert (np.diff(rs) < np.diff(rb)).sum() >= 1, "no query of this set hits the double rounding: the test has lost its point"
+    assert np.diff(rs)[np.diff(rs) < np.diff(rb)].min() < 0.5 * np.diff(rb).mean()  # ... and it costs such a row most of its pairs
+    monkeypatch.setenv("DMCF_FRS_BRUTE_FORCE_SET", "1")
+    _check_search(oracle, dev, pts, qs, float(R), False, bruteforce=True)
+    # the density sum takes the same scan
+    monkeypatch.delenv("DMCF_FRS_BRUTE_FORCE_SET")
+    w = ops.window_sum(_t(pts, dev), _t(qs, dev), float(R), window=None).cpu().numpy()
+    np.testing.assert_array_equal(w.astype(np.int64), np.diff(rs))
 
 
 def test_frs_lattice_ties(oracle, dev):
