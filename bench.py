@@ -112,6 +112,10 @@ def parse_args(argv=None):
                     help="override Simulator(reserve_gib=...) (default: the product's own 'auto' rule, 40 KiB per particle handed "
                          "to the caching allocator before the first step; 0 = none)")
     ap.add_argument("--decomp", default="blocks", choices=["blocks", "slabs"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = side^3 particles PER GPU (one box of N side^3, the default the driver's efficiency is "
+                         "computed from); strong = ONE box of side^3 particles split over the N GPUs (BASELINE.json's '1M particles "
+                         "@1/2/4/8 GPUs' read literally)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduction logic only, on the gloo backend without a GPU (CPU test)")
     return ap.parse_args(argv)
@@ -250,16 +254,23 @@ def main():
         comm = parallel.TorchDistComm()
         grid = block_grid(world) if args.decomp == "blocks" else [world, 1, 1]
         h = 0.05
-        decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * args.side * h for g in grid], grid)
+        if args.scaling == "strong":
+            if any(args.side % g for g in grid):
+                raise SystemExit(f"--scaling strong: --side {args.side} is not divisible by the block grid {grid}")
+            sides = [args.side // g for g in grid]
+        else:
+            sides = [args.side] * 3
+        decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * sd * h for g, sd in zip(grid, sides)], grid)
         ssim = parallel.ShardedSimulator(model, comm, decomp, **sim_kw)
-        scene = scenes.box_block_scene(args.side, grid, rank)
+        parallel.stats().profile = True  # HIP events around every wait for a ghost exchange (outside of nothing: they are the step)
+        scene = scenes.box_block_scene(sides, grid, rank)
         n_fluid = scene["pos"].shape[0]
         state = parallel.shard_scene(scene, decomp, rank, dev, presharded=True)
         state["gid"] = state["gid"] + rank * n_fluid
         n_total = world * n_fluid
         step = ssim.step
-        par = (f"{grid[0]}x{grid[1]}x{grid[2]} blocks of one {grid[0] * args.side}x{grid[1] * args.side}x{grid[2] * args.side} box, "
-               "1 process per GPU, per-layer ghost all-to-all-v over RCCL")
+        par = (f"{grid[0]}x{grid[1]}x{grid[2]} blocks of one {grid[0] * sides[0]}x{grid[1] * sides[1]}x{grid[2] * sides[2]} box "
+               f"({args.scaling} scaling), 1 process per GPU, per-layer ghost all-to-all-v over RCCL")
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -295,6 +306,7 @@ def main():
             print(f"[debug] step done at {1e3 * (time.perf_counter() - t0):.1f} ms; reserved {ms['reserved_bytes.all.current'] / 2**30:.1f} GiB "
                   f"(peak {ms['reserved_bytes.all.peak'] / 2**30:.1f}), allocated peak {ms['allocated_bytes.all.peak'] / 2**30:.1f} GiB, "
                   f"device mallocs {ms['num_device_alloc']}, frees {ms['num_device_free']}, retries {ms['num_alloc_retries']}", file=sys.stderr, flush=True)
+    rank_elapsed = time.perf_counter() - t0  # (this rank's own clock, before the closing barrier)
     barrier()
     elapsed = time.perf_counter() - t0
     timer, ops.timer = (ops.timer if ops.timer is not None else ops.LaunchTimer()), None
@@ -327,6 +339,19 @@ def main():
         dist.all_reduce(cnt)
         assert int(cnt.item()) == n_total, f"particles lost in migration: {int(cnt.item())} != {n_total}"
         extra["ghost_rows_per_step_rank0"] = int(ssim.exchanged_rows / max(args.steps + args.warmup, 1))
+        # what the step costs besides its kernels, per rank (all steps incl. warm-up for the row counts; the timed steps for the
+        # waits): ghost rows received, rows migrated, device -> host reads, ms the compute stream stood still for an exchange
+        st = parallel.stats()
+        torch.cuda.synchronize(dev)
+        mine = dict(rank=rank, fluid_particles=int(state["pos"].shape[0]), boundary_particles=int(state["box"].shape[0]),
+                    ghost_rows_per_step=int(ssim.exchanged_rows / max(args.steps + args.warmup, 1)),
+                    migrated_rows_per_step=ssim.migrated_rows_total / max(args.steps + args.warmup, 1),
+                    host_syncs_per_step=st.host_syncs / max(args.steps + args.warmup, 1),
+                    exposed_exchange_wait_ms_per_step=st.exposed_wait_ms() / max(args.steps, 1),
+                    rank_seconds=rank_elapsed)
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+        extra["per_rank"] = per_rank
 
     if rank == 0:
         recs = timer.results()
@@ -342,7 +367,7 @@ def main():
         line = {
             "metric": "rollout_particle_steps_per_sec", "value": n_total * args.steps / elapsed,
             "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling if sharded else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic 3-D box (BASELINE.json config 5), {n_fluid} fluid particles per GPU + closed 2-layer "
                                    f"boundary shell ({scene['box'].shape[0]} boundary particles on rank 0), Liquid3d SymNet (18 CConv/ASCC "

@@ -48,6 +48,38 @@ from .utils.tools.losses import grid_pos
 # --------------------------------------------------------------------------------------------------
 # communicators
 # --------------------------------------------------------------------------------------------------
+class Stats:
+    """What a sharded step costs besides its kernels (bench.py --gpus N prints it per rank): device -> host reads (each one
+    drains the queue), rows sent / received as ghosts and by the migration, and -- with ``profile`` set -- HIP events around
+    every wait for an asynchronous exchange (how long the compute stream was held up by it)."""
+
+    def __init__(self):
+        self.host_syncs = 0
+        self.profile = False
+        self.wait_events = []
+
+    def exposed_wait_ms(self):
+        ms = sum(a.elapsed_time(b) for a, b in self.wait_events)
+        self.wait_events = []
+        return ms
+
+
+STATS = threading.local()
+
+
+def stats():
+    st = getattr(STATS, "v", None)
+    if st is None:
+        st = STATS.v = Stats()
+    return st
+
+
+def host(x):
+    """tensor -> Python list / number: a counted device -> host read"""
+    stats().host_syncs += 1
+    return x.tolist() if x.dim() else x.item()
+
+
 class Comm:
     rank = 0
     world = 1
@@ -104,7 +136,7 @@ class TorchDistComm(Comm):
             send_counts = torch.tensor(sc, dtype=torch.int64, device=xdev)
             rc_t = torch.empty_like(send_counts)
             dist.all_to_all_single(rc_t, send_counts, group=self.group)
-            rc = rc_t.tolist()
+            rc = host(rc_t)
         else:
             rc = [int(c) for c in recv_counts]
         inp = torch.cat([s.reshape(s.shape[0], width) for s in send], dim=0).contiguous().to(xdev)
@@ -129,7 +161,15 @@ class TorchDistComm(Comm):
         work = dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group, async_op=True)
 
         def wait():
-            work.wait()  # (the current stream waits; ``inp`` / ``out`` stay referenced by this closure until then)
+            st = stats()
+            if st.profile:  # how long does the compute stream stand still for this exchange?
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                work.wait()
+                e1.record()
+                st.wait_events.append((e0, e1))
+            else:
+                work.wait()  # (the current stream waits; ``inp`` / ``out`` stay referenced by this closure until then)
             return [p.reshape((p.shape[0],) + trailing) for p in torch.split(out, rc, dim=0)]
         return wait
 
@@ -352,7 +392,7 @@ class GhostPlan:
                 b = _bounds_tensor(decomp, peers, dev)                      # [P, 3, 2]
                 flags = torch.stack([_gap2(cpos, b[i:i + 1].expand(cpos.shape[0], 3, 2)) <= w2 for i in range(len(peers))])
                 hit = torch.nonzero(flags)                                  # rows ordered by peer, then by point
-                counts = torch.bincount(hit[:, 0], minlength=len(peers)).tolist()
+                counts = host(torch.bincount(hit[:, 0], minlength=len(peers)))
                 rows = cand[hit[:, 1]]
                 off = 0
                 for i, r in enumerate(peers):
@@ -370,7 +410,7 @@ class GhostPlan:
                 seg = torch.repeat_interleave(torch.arange(len(peers), device=dev),
                                               torch.tensor([parent.send_idx[r].shape[0] for r in peers], device=dev))
                 keep = _gap2(pos_owned[rows], _bounds_tensor(decomp, peers, dev)[seg]) <= w2
-                counts = torch.bincount(seg[keep], minlength=len(peers)).tolist()
+                counts = host(torch.bincount(seg[keep], minlength=len(peers)))
                 rows = rows[keep]
                 off = 0
                 for i, r in enumerate(peers):
@@ -383,7 +423,7 @@ class GhostPlan:
                 mine = _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2)
                 keep = _gap2(g, mine) <= w2
                 self.in_parent = torch.nonzero(keep).reshape(-1)
-                self.recv_counts = torch.bincount(src[keep], minlength=world).tolist()
+                self.recv_counts = host(torch.bincount(src[keep], minlength=world))
                 self.ghost_pos = g[self.in_parent]
             else:
                 self.in_parent = empty
@@ -440,7 +480,7 @@ class ShardedSimulator:
         self.reserve_gib = reserve_gib  # as Simulator(reserve_gib=...): one block for the caching allocator before the first step
         self.reserved_gib = None
         self.exchanged_rows = 0
-        self.host_syncs = 0
+        self.migrated_rows_total = 0
         m = model
         for key in ("translate", "scale", "grav_eqvar"):
             if key in m.transformation:
@@ -563,7 +603,7 @@ class ShardedSimulator:
             out, ok = None, 0
         flag = torch.tensor([ok], dtype=torch.int32, device=state["pos"].device)
         self.comm.all_reduce(flag, "min")
-        if int(flag.item()) == 0:
+        if int(host(flag[0])) == 0:
             with neighbor_cache(estimate=False):
                 out = self._step(state)
         return out
@@ -591,9 +631,9 @@ class ShardedSimulator:
             own = self.decomp.owner(adv)
             payload = torch.cat([pos0, vel0] + ([acc] if acc is not None else []), dim=1)
             order = torch.argsort(own, stable=True)
-            counts = torch.bincount(own, minlength=comm.world).tolist()
-            self.host_syncs += 1
+            counts = host(torch.bincount(own, minlength=comm.world))
             self.migrated_rows = int(sum(counts)) - int(counts[comm.rank])
+            self.migrated_rows_total += self.migrated_rows
             recv = comm.all_to_all(list(torch.split(payload[order], counts, dim=0)))
             rc = [int(r.shape[0]) for r in recv]
             payload = torch.cat(recv, dim=0)
@@ -648,8 +688,7 @@ class ShardedSimulator:
                                torch.tensor([float(base.shape[0])], dtype=torch.float64, device=dev)])
             acc64 = comm.all_reduce(acc64, "sum")
             center = (acc64[:3] / acc64[3]).to(torch.float32)
-            center_host = center.tolist()
-            self.host_syncs += 1
+            center_host = host(center)
         for si, stride in enumerate(m.strides):
             if stride == 1:
                 sets.append(base)
@@ -677,8 +716,7 @@ class ShardedSimulator:
                     ext = [v for k in range(3) for v in (-blo[k], blo[k] + bdims[k] - 1)]
                 else:
                     ext = [-big_i] * 6
-                ext = comm.all_reduce(torch.tensor(ext + [unknown], dtype=torch.int64, device=dev), "max").tolist()
-                self.host_syncs += 1
+                ext = host(comm.all_reduce(torch.tensor(ext + [unknown], dtype=torch.int64, device=dev), "max"))
                 if ext[0] > -big_i and ext[6] == 0:
                     ulo = [-ext[2 * k] for k in range(3)]
                     uhi = [ext[2 * k + 1] for k in range(3)]

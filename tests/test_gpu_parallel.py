@@ -167,3 +167,10 @@ def test_sharded_bench_over_rccl_world1(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and "1x1x1 blocks" in d["config"]["parallelism"] and d["value"] > 0
     assert d["roofline_groups"]["neighbour_list"]["launches"] > 0
+    # what the first real multi-GPU run will be read by: per-rank ghost / migration rows, device -> host reads, exposed waits
+    pr = d["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["fluid_particles"] == 24 ** 3
+    assert {"ghost_rows_per_step", "migrated_rows_per_step", "host_syncs_per_step", "exposed_exchange_wait_ms_per_step",
+            "rank_seconds"} <= set(pr[0])
+    assert pr[0]["exposed_exchange_wait_ms_per_step"] >= 0 and pr[0]["host_syncs_per_step"] > 0
+    assert d["scene_state"]["fluid_outside_shell_at_end"] == 0 and "weak scaling" in d["config"]["parallelism"]

@@ -152,19 +152,21 @@ def box_block_scene(side, grid, rank, h=0.05, jitter=0.1, vel_std=0.1, shell_lay
     fluid particles per GPU); each rank generates only its own part."""
     L = shell_layers
     grid = [int(g) for g in grid]
+    # ``side``: one number (cubes) or three (the block's lattice cells per axis: strong scaling splits ONE box unevenly per axis)
+    side = np.broadcast_to(np.asarray(side, dtype=np.int64), (3,))
     c = (rank // (grid[1] * grid[2]), (rank // grid[2]) % grid[1], rank % grid[2])
     rng = np.random.default_rng(seed + 2 * rank)
-    axes = [(np.arange(side * c[k], side * (c[k] + 1)) + 0.5) * h for k in range(3)]
+    axes = [(np.arange(side[k] * c[k], side[k] * (c[k] + 1)) + 0.5) * h for k in range(3)]
     pos = np.stack(np.meshgrid(*axes, indexing="ij"), -1).reshape(-1, 3)
     pos = pos + rng.uniform(-jitter * h, jitter * h, size=pos.shape)
     vel = np.random.default_rng(seed + 2 * rank + 1).normal(0.0, vel_std, size=pos.shape)
     g = []
     for k in range(3):
-        lo = side * c[k] - (L if c[k] == 0 else 0)
-        hi = side * (c[k] + 1) + (L if c[k] == grid[k] - 1 else 0)
+        lo = side[k] * c[k] - (L if c[k] == 0 else 0)
+        hi = side[k] * (c[k] + 1) + (L if c[k] == grid[k] - 1 else 0)
         g.append(np.arange(lo, hi))
     gi = np.stack(np.meshgrid(*g, indexing="ij"), -1).reshape(-1, 3)
-    total = np.array([side * grid[0], side * grid[1], side * grid[2]])
+    total = np.array([side[0] * grid[0], side[1] * grid[1], side[2] * grid[2]])
     outside_lo = gi < 0
     outside_hi = gi >= total
     is_shell = (outside_lo | outside_hi).any(axis=1)
