@@ -253,6 +253,11 @@ bool cconv_pair_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 int cconv_pair_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
 
+// cconv_p16.hip
+bool cconv_p16_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+int cconv_p16_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+
+
 // cconv_direct.hip
 bool cconv_direct_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_direct_packed_floats(int dz, int dy, int dx, int cin);

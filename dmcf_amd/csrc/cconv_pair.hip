@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
 #pragma unroll
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     constexpr int kIt = 64 / kPWaves;          // blocks of a chunk per wave: t = wave + 8 it < 16 nq
-    constexpr int kPre = NTT <= 2 ? 4 : 2;     // blocks whose filter fragments are requested together
+    constexpr int kPre = NTT <= 2 ? 8 : 4;     // blocks whose filter fragments are requested together (NTT <= 2: a whole chunk)
     auto nq_of = [&](int chunk) { return (min(16, cin - 16 * chunk) + 3) >> 2; };
     auto w_issue = [&](int chunk, int it0, f32x4 (&bw)[kPre][NTT]) {
         const int nq = nq_of(chunk);

@@ -109,3 +109,9 @@ def test_generated_splat_sources_are_current(tmp_path, monkeypatch):
     gen.write_product(str(tmp_path))
     for n in gen.PRODUCT_FILES:
         assert open(real_join(str(tmp_path), n)).read() == open(real_join(csrc, n)).read(), n
+    spec = importlib.util.spec_from_file_location("gen_p16_splat", real_join(root, "tools", "gen_p16_splat.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    gen.write_product(str(tmp_path))
+    for n in gen.PRODUCT_FILES:
+        assert open(real_join(str(tmp_path), n)).read() == open(real_join(csrc, n)).read(), n

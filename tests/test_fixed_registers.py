@@ -45,7 +45,7 @@ def _highest_compiler_register(lines):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 @pytest.mark.parametrize("name,first_tile,extra,total", [("cconv_z3", 80, (), 128), ("cconv_cls", 92, ("-fno-slp-vectorize",), 128),
-                                                          ("cconv_pair", 116, (), 256)])
+                                                          ("cconv_pair", 116, (), 256), ("cconv_p16", 76, (), 128)])
 def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, extra, total):
     lines = _assembly(tmp_path, name, extra)
     top = {k: v for k, v in _highest_compiler_register(lines).items() if "kernel" in k and "pack" not in k}
@@ -55,7 +55,7 @@ def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, ext
     text = "\n".join(lines)
     counts = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", text)]
     assert counts.count(total) >= len(top)  # every splat kernel owns all its registers (tiles included)
-    first_mfma_tile = {"cconv_z3": "v[80:95]", "cconv_cls": "v[92:95]", "cconv_pair": "v[148:151]"}[name]
+    first_mfma_tile = {"cconv_z3": "v[80:95]", "cconv_cls": "v[92:95]", "cconv_pair": "v[148:151]", "cconv_p16": "v[92:95]"}[name]
     assert first_mfma_tile in text
-    if name == "cconv_pair":  # no spills: a reload inside the batch loop would wait for every prefetched load
+    if name in ("cconv_pair", "cconv_p16"):  # no spills: a reload inside the batch loop would wait for every prefetched load
         assert all(int(x) == 0 for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text))
