@@ -40,7 +40,7 @@ static_assert(sizeof(FrsHeader) == 128, "header layout");
 struct FrsLayout {
     int64_t n, m, table;
     size_t off_header, off_cell_start, off_cell_fill, off_point_cell, off_tmp_idx, off_sorted, off_counts,
-        off_scan, scan_bytes, total;
+        off_scan, scan_bytes, off_flags, total;
 };
 
 static int64_t frs_table_size(int64_t n) {
@@ -66,6 +66,9 @@ static FrsLayout frs_layout(int64_t n, int64_t m) {
     const int64_t scan_n = (L.table + 1) > m ? (L.table + 1) : m;
     L.scan_bytes = scan_tmp_bytes(scan_n);
     L.off_scan = off;          off += L.scan_bytes;
+    // one byte per query: "this query may see a point the reference cannot" (DMCF_FRS_OPEN3D_CORNER_VOXELS, see frs_fix); written
+    // and read by the searches on this structure, so one search at a time per structure
+    L.off_flags = off;         off += align_up((size_t)(m > 0 ? m : 1), 256);
     L.total = off;
     return L;
 }
@@ -298,41 +301,64 @@ __device__ __forceinline__ uint64_t o3d_spatial_hash(int x, int y, int z) {
 }
 
 struct O3dView {
-    int vlo[3], vhi[3];  // voxels of the corners q - R, q + R per axis
-    float inv_voxel;
-    float r2_inner;      // hits with d^2 above this take the exact visibility test (-1: all of them)
+    float q[3];
+    float radius, inv_voxel;
+    float r2_inner;      // hits with d^2 above this need the exact visibility test (-1: all of them)
 };
+
+// voxels of the corners q - R, q + R per axis
+__device__ __forceinline__ void o3d_corners(const O3dView& v, int (&vlo)[3], int (&vhi)[3]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        vlo[a] = (int)floorf(__fmul_rn(__fsub_rn(v.q[a], v.radius), v.inv_voxel));
+        vhi[a] = (int)floorf(__fmul_rn(__fadd_rn(v.q[a], v.radius), v.inv_voxel));
+    }
+}
 
 __device__ __forceinline__ O3dView o3d_view(const float (&q)[3], float radius, float r2) {
     O3dView v;
     const float voxel = __fmul_rn(2.0f, radius);
     v.inv_voxel = __fdiv_rn(1.0f, voxel);
-    bool gap = false;
+    v.radius = radius;
+    // The corner voxels of an axis can only be two apart when q sits within rounding of the MIDDLE of a voxel: a cheap test
+    // (distance of q / voxel from k + 1/2 below 1e-3 -- rounding is 1e-7 of q / voxel, coordinates beyond 1000 voxels count as
+    // near) picks the one query in ~300 that gets the exact one
+    bool near = false;
     float qmax = 0.0f;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        v.vlo[a] = (int)floorf(__fmul_rn(__fsub_rn(q[a], radius), v.inv_voxel));
-        v.vhi[a] = (int)floorf(__fmul_rn(__fadd_rn(q[a], radius), v.inv_voxel));
-        gap |= v.vhi[a] - v.vlo[a] > 1;
-        qmax = fmaxf(qmax, fabsf(q[a]));
+        v.q[a] = q[a];
+        const float u = q[a] * v.inv_voxel;
+        near |= fabsf(__builtin_amdgcn_fractf(u) - 0.5f) < 1e-3f;
+        qmax = fmaxf(qmax, fabsf(u));
     }
+    near |= !(qmax < 1000.0f);
     // d^2 <= R^2 (1 - delta) puts every coordinate of the point inside [fl(q - R), fl(q + R)] -- whose voxels are the corners'
-    // or lie between them -- when delta / 2 exceeds the relative rounding of q +- R (6e-8 (|q| + R) / R) and of the distance
-    const float delta = 1e-6f * (qmax * __builtin_amdgcn_rcpf(radius) + 1.0f);
-    v.r2_inner = (gap || !(delta < 0.5f)) ? -1.0f : r2 * (1.0f - delta);
+    // or lie between them -- when delta exceeds twice the relative rounding of q +- R (6e-8 (2 q / voxel + 1)) plus that of the
+    // squared distance and of R^2 (3e-7); a quarter of margin
+    const float delta = 1.5e-7f * (2.0f * qmax + 1.0f) + 4e-7f;
+    bool all = !(delta < 0.5f);
+    if (__ballot(near) != 0ull) {  // (wave uniform: one query per wave)
+        int vlo[3], vhi[3];
+        o3d_corners(v, vlo, vhi);
+        all |= vhi[0] - vlo[0] > 1 || vhi[1] - vlo[1] > 1 || vhi[2] - vlo[2] > 1;
+    }
+    v.r2_inner = all ? -1.0f : r2 * (1.0f - delta);
     return v;
 }
 
-__device__ __noinline__ bool o3d_visible(float px, float py, float pz, const O3dView& v, int64_t n_points) {
+__device__ __forceinline__ bool o3d_visible(float px, float py, float pz, const O3dView& v, int n_points) {
+    int vlo[3], vhi[3];
+    o3d_corners(v, vlo, vhi);
     const int x = (int)floorf(__fmul_rn(px, v.inv_voxel)), y = (int)floorf(__fmul_rn(py, v.inv_voxel)),
               z = (int)floorf(__fmul_rn(pz, v.inv_voxel));
-    if ((x == v.vlo[0] || x == v.vhi[0]) && (y == v.vlo[1] || y == v.vhi[1]) && (z == v.vlo[2] || z == v.vhi[2])) return true;
+    if ((x == vlo[0] || x == vhi[0]) && (y == vlo[1] || y == vhi[1]) && (z == vlo[2] || z == vhi[2])) return true;
     // not one of the 8 voxels: still found if its bin is (the FixedRadiusSearch layer's table: n / 64 bins, 1 .. 2^25)
-    int64_t size = n_points / 64;
+    int64_t size = (int64_t)n_points / 64;
     size = size < 1 ? 1 : (size > 33554432 ? 33554432 : size);
     const uint64_t bin = o3d_spatial_hash(x, y, z) % (uint64_t)size;
     for (int c = 0; c < 8; ++c) {
-        const uint64_t cb = o3d_spatial_hash((c & 1) ? v.vhi[0] : v.vlo[0], (c & 2) ? v.vhi[1] : v.vlo[1], (c & 4) ? v.vhi[2] : v.vlo[2]) % (uint64_t)size;
+        const uint64_t cb = o3d_spatial_hash((c & 1) ? vhi[0] : vlo[0], (c & 2) ? vhi[1] : vlo[1], (c & 4) ? vhi[2] : vlo[2]) % (uint64_t)size;
         if (cb == bin) return true;
     }
     return false;
@@ -341,12 +367,17 @@ __device__ __noinline__ bool o3d_visible(float px, float py, float pz, const O3d
 // The candidate scan of one query by one wavefront.  MODE 0: count the hits; MODE 1: write them to the CSR row at
 // out_base; MODE 2: add window(d^2 / R^2) of every hit to `wsum` (per lane; the caller reduces over the wave).
 // Returns the number of hits.  Hits come out in a fixed order (cell rows, then position in the cell-sorted array).
-template <int MODE>
+// EXACT (DMCF_FRS_OPEN3D_CORNER_VOXELS only): every hit that could lie outside the reference's 8 bins takes the exact
+// visibility test -- the form of the FIXUP kernel (frs_fix), which re-scans the few queries the hot kernels flag.  !EXACT is the
+// hot form: it only NOTICES such a hit (d^2 above r2_inner: one compare per window) and reports it through `redo`.  The test
+// itself (a 64-bit modulo) stays out of the hot kernels: with it inside they needed 71 instead of 52 registers -- seven
+// instead of eight waves per SIMD for a latency-bound scan -- and the searches of a step took 15 - 20 % longer.
+template <int MODE, bool EXACT>
 __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const FrsHeader* __restrict__ h,
                                             const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
                                             float radius, int flags, int64_t out_base, int32_t* __restrict__ nbr_index,
                                             float* __restrict__ nbr_dist, int window, float inv_r2, float& wsum,
-                                            uint32_t* marks, int32_t row_cap = 0x7fffffff) {
+                                            uint32_t* marks, int32_t row_cap, bool& redo) {
     const int lane = lane_id();
     int mark_tag = 0;
     for (int w = 0; w < kWin; ++w) marks[w * kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
@@ -449,8 +480,12 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 }
                 if (o3d) {  // (rare: the outermost shell of the sphere, or a query whose corner voxels are two apart)
                     const bool check = hit && d2 > view.r2_inner;
-                    if (__ballot(check) != 0ull) {
-                        if (check) hit = o3d_visible(p.x, p.y, p.z, view, h->n_points);
+                    if (EXACT) {
+                        if (__ballot(check) != 0ull) {
+                            if (check) hit = o3d_visible(p.x, p.y, p.z, view, h->n_points);
+                        }
+                    } else {
+                        redo |= __ballot(check) != 0ull;
                     }
                 }
                 const unsigned long long mask = __ballot(hit);
@@ -487,7 +522,9 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
     return cnt;
 }
 
-// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.
+// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.  qflags (with
+// DMCF_FRS_OPEN3D_CORNER_VOXELS): the count pass marks the queries whose row may hold a point the reference cannot see, the
+// write pass leaves those rows to frs_fix.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queries, int64_t m,
                                                  const FrsHeader* __restrict__ h,
@@ -495,18 +532,24 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                                                  const float4* __restrict__ sorted, float radius, int flags,
                                                  int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
                                                  int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
-                                                 int64_t capacity) {
+                                                 int64_t capacity, uint8_t* __restrict__ qflags) {
     __shared__ uint32_t marks[4][kWin * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;  // whole wave leaves
     // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
     // row_splits[m] > capacity and repeats the search with exact buffers)
     if (WRITE && row_splits[qi + 1] > capacity) return;
+    const bool o3d = (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) != 0;
+    if (WRITE && o3d && qflags[qi]) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     float unused = 0.0f;
-    const int32_t cnt = frs_scan<WRITE ? 1 : 0>(qx, qy, qz, h, cell_start, sorted, radius, flags, WRITE ? row_splits[qi] : 0,
-                                                nbr_index, nbr_dist, 0, 0.0f, unused, marks[threadIdx.x >> 6]);
-    if (!WRITE && lane_id() == 0) counts[qi] = cnt;
+    bool redo = false;
+    const int32_t cnt = frs_scan<WRITE ? 1 : 0, false>(qx, qy, qz, h, cell_start, sorted, radius, flags, WRITE ? row_splits[qi] : 0,
+                                                       nbr_index, nbr_dist, 0, 0.0f, unused, marks[threadIdx.x >> 6], 0x7fffffff, redo);
+    if (!WRITE && lane_id() == 0) {
+        counts[qi] = cnt;
+        if (o3d) qflags[qi] = redo ? 1 : 0;
+    }
 }
 
 // Single pass into padded rows (see dmcf_frs_search_padded): row qi starts at qi * stride.
@@ -515,20 +558,24 @@ __global__ __launch_bounds__(256) void frs_query_padded(const float* __restrict_
                                                         const float4* __restrict__ sorted, float radius, int flags,
                                                         int64_t stride, int64_t* __restrict__ row_begin,
                                                         int32_t* __restrict__ row_count, int32_t* __restrict__ nbr_index,
-                                                        float* __restrict__ nbr_dist, int32_t* __restrict__ max_count) {
+                                                        float* __restrict__ nbr_dist, int32_t* __restrict__ max_count,
+                                                        uint8_t* __restrict__ qflags) {
     __shared__ uint32_t marks[4][kWin * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     float unused = 0.0f;
-    const int32_t cnt = frs_scan<1>(qx, qy, qz, h, cell_start, sorted, radius, flags, qi * stride, nbr_index, nbr_dist, 0, 0.0f,
-                                    unused, marks[threadIdx.x >> 6], (int32_t)min(stride, (int64_t)0x7fffffff));
+    bool redo = false;
+    const int32_t cnt = frs_scan<1, false>(qx, qy, qz, h, cell_start, sorted, radius, flags, qi * stride, nbr_index, nbr_dist, 0, 0.0f,
+                                           unused, marks[threadIdx.x >> 6], (int32_t)min(stride, (int64_t)0x7fffffff), redo);
     if (lane_id() == 0) {
         row_begin[qi] = qi * stride;
         if (qi == m - 1) row_begin[m] = m * stride;
         row_count[qi] = (int32_t)min((int64_t)cnt, stride);
+        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) qflags[qi] = redo ? 1 : 0;
         // same-address atomics serialise (1.1M of them cost ~3 ms per search): only rows that beat the value currently
-        // visible try; a stale read merely costs a redundant atomic
+        // visible try; a stale read merely costs a redundant atomic.  (A flagged row may shrink in frs_fix: its first count
+        // still bounds it.)
         if (cnt > __hip_atomic_load(max_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_count, cnt);
     }
 }
@@ -538,22 +585,73 @@ __global__ __launch_bounds__(256) void frs_query_padded(const float* __restrict_
 __global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ queries, int64_t m,
                                                       const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
                                                       const float4* __restrict__ sorted, float radius, int flags, int window,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, uint8_t* __restrict__ qflags) {
     __shared__ uint32_t marks[4][kWin * kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     float wsum = 0.0f;
-    frs_scan<2>(qx, qy, qz, h, cell_start, sorted, radius, flags, 0, nullptr, nullptr, window, 1.0f / (radius * radius), wsum,
-                marks[threadIdx.x >> 6]);
+    bool redo = false;
+    frs_scan<2, false>(qx, qy, qz, h, cell_start, sorted, radius, flags, 0, nullptr, nullptr, window, 1.0f / (radius * radius), wsum,
+                       marks[threadIdx.x >> 6], 0x7fffffff, redo);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
-    if (lane_id() == 0) out[qi] = wsum;
+    if (lane_id() == 0) {
+        out[qi] = wsum;
+        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) qflags[qi] = redo ? 1 : 0;
+    }
+}
+
+// The FIXUP of DMCF_FRS_OPEN3D_CORNER_VOXELS: the hot kernels above return the set of the distance test and flag the queries
+// whose row holds a hit the reference might not see (one whose voxel could lie outside the 8 corner voxels: the outermost
+// shell of the sphere, or any hit of a query whose corner voxels are two apart).  A small persistent grid walks the flags and
+// scans each flagged query again with the exact test: KIND 0 recounts (counts[q]), 1 writes the CSR row, 2 rewrites the
+// padded row and its count, 3 recomputes the window sum.
+template <int KIND>
+__global__ __launch_bounds__(256) void frs_fix(const float* __restrict__ queries, int64_t m, const FrsHeader* __restrict__ h,
+                                               const uint32_t* __restrict__ cell_start, const float4* __restrict__ sorted,
+                                               float radius, int flags, const uint8_t* __restrict__ qflags,
+                                               int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits, int64_t stride,
+                                               int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist, int64_t capacity,
+                                               int window, float* __restrict__ out) {
+    __shared__ uint32_t marks[4][kWin * kWave];
+    const int lane = lane_id();
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t base = wave * kWave; base < m; base += nwaves * kWave) {
+        const int64_t mine = base + lane;
+        unsigned long long todo = __ballot(mine < m && qflags[mine] != 0);
+        while (todo) {
+            const int k = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t qi = base + k;
+            if (KIND == 1 && row_splits[qi + 1] > capacity) continue;
+            const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
+            float wsum = 0.0f;
+            bool redo = false;
+            const int64_t ob = KIND == 1 ? row_splits[qi] : (KIND == 2 ? qi * stride : 0);
+            const int32_t cap = KIND == 2 ? (int32_t)min(stride, (int64_t)0x7fffffff) : 0x7fffffff;
+            const int32_t cnt = frs_scan<KIND == 0 ? 0 : (KIND == 3 ? 2 : 1), true>(qx, qy, qz, h, cell_start, sorted, radius, flags, ob, nbr_index,
+                                                                                   nbr_dist, window, 1.0f / (radius * radius), wsum,
+                                                                                   marks[threadIdx.x >> 6], cap, redo);
+            if (KIND == 3) {
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
+            }
+            if (lane == 0) {
+                if (KIND == 0) counts[qi] = cnt;
+                if (KIND == 2) counts[qi] = (int32_t)min((int64_t)cnt, stride);
+                if (KIND == 3) out[qi] = wsum;
+            }
+        }
+    }
 }
 
 }  // namespace dmcf
 
 using namespace dmcf;
+
+static constexpr unsigned kFixGrid = 1024;  // 4096 waves walk the query flags (frs_fix)
 
 extern "C" {
 
@@ -619,8 +717,13 @@ int dmcf_frs_count(const float* queries, int64_t m, int64_t n, float radius, int
     int32_t* counts = (int32_t*)(ws + L.off_counts);
     if (m > 0) {
         const unsigned g = (unsigned)((m + 3) / 4);
+        uint8_t* qflags = (uint8_t*)(ws + L.off_flags);
         hipLaunchKernelGGL((frs_query<false>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted,
-                           radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0);
+                           radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0, qflags);
+        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+            hipLaunchKernelGGL((frs_fix<0>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
+                               (const uint8_t*)qflags, counts, (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (float*)nullptr,
+                               (int64_t)0, 0, (float*)nullptr);
     }
     return scan_counts_to_row_splits(counts, row_splits, m, ws + L.off_scan, L.scan_bytes, stream);
 }
@@ -634,13 +737,18 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
     if (!neighbors_index || pair_capacity < 0) return DMCF_EINVAL;
     const FrsLayout L = frs_layout(n, m);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
-    const char* ws = (const char*)workspace;
+    char* ws = (char*)workspace;  // (the query flags live in it: see frs_layout)
     const FrsHeader* h = (const FrsHeader*)(ws + L.off_header);
     const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
     const float4* sorted = (const float4*)(ws + L.off_sorted);
     const unsigned g = (unsigned)((m + 3) / 4);
+    uint8_t* qflags = (uint8_t*)(ws + L.off_flags);  // (written by the count pass of this search)
     hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
-                       flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity);
+                       flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity, qflags);
+    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+        hipLaunchKernelGGL((frs_fix<1>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
+                           (const uint8_t*)qflags, (int32_t*)nullptr, row_splits, (int64_t)0, neighbors_index, neighbors_distance,
+                           pair_capacity, 0, (float*)nullptr);
     return check_launch();
 }
 
@@ -654,11 +762,18 @@ int dmcf_frs_search_padded(const float* queries, int64_t m, int64_t n, float rad
     const FrsLayout L = frs_layout(n, m);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
     if (m == 0) return hipMemsetAsync(row_begin, 0, 8, stream) == hipSuccess ? DMCF_OK : DMCF_ELAUNCH;
-    const char* ws = (const char*)workspace;
+    char* ws = (char*)workspace;  // (the query flags live in it: see frs_layout)
     const unsigned g = (unsigned)((m + 3) / 4);
-    hipLaunchKernelGGL(frs_query_padded, dim3(g), dim3(256), 0, stream, queries, m, (const FrsHeader*)(ws + L.off_header),
-                       (const uint32_t*)(ws + L.off_cell_start), (const float4*)(ws + L.off_sorted), radius, flags, row_stride,
-                       row_begin, row_count, neighbors_index, neighbors_distance, max_count);
+    uint8_t* qflags = (uint8_t*)(ws + L.off_flags);
+    const FrsHeader* h = (const FrsHeader*)(ws + L.off_header);
+    const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
+    const float4* sorted = (const float4*)(ws + L.off_sorted);
+    hipLaunchKernelGGL(frs_query_padded, dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags, row_stride,
+                       row_begin, row_count, neighbors_index, neighbors_distance, max_count, qflags);
+    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+        hipLaunchKernelGGL((frs_fix<2>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
+                           (const uint8_t*)qflags, row_count, (const int64_t*)nullptr, row_stride, neighbors_index, neighbors_distance,
+                           (int64_t)0, 0, (float*)nullptr);
     return check_launch();
 }
 
@@ -670,10 +785,17 @@ int dmcf_frs_window_sum(const float* queries, int64_t m, int64_t n, float radius
     if (m == 0) return DMCF_OK;
     const FrsLayout L = frs_layout(n, m);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
-    const char* ws = (const char*)workspace;
+    char* ws = (char*)workspace;  // (the query flags live in it: see frs_layout)
     const unsigned g = (unsigned)((m + 3) / 4);
-    hipLaunchKernelGGL(frs_window_sum, dim3(g), dim3(256), 0, stream, queries, m, (const FrsHeader*)(ws + L.off_header),
-                       (const uint32_t*)(ws + L.off_cell_start), (const float4*)(ws + L.off_sorted), radius, flags, window, out);
+    uint8_t* qflags = (uint8_t*)(ws + L.off_flags);
+    const FrsHeader* h = (const FrsHeader*)(ws + L.off_header);
+    const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
+    const float4* sorted = (const float4*)(ws + L.off_sorted);
+    hipLaunchKernelGGL(frs_window_sum, dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags, window, out, qflags);
+    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+        hipLaunchKernelGGL((frs_fix<3>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
+                           (const uint8_t*)qflags, (int32_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr,
+                           (float*)nullptr, (int64_t)0, window, out);
     return check_launch();
 }
 
