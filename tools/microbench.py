@@ -43,7 +43,8 @@ def main():
         feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
         W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
         f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
-                                      neighbors_value=nns.neighbors_distance if dist else None, window=win, symmetric=sym, sym_axis=1)
+                                      neighbors_value=nns.neighbors_distance if dist else None, window=win, symmetric=sym, sym_axis=1,
+                                      row_length_hint=2 if R > 0.1 else 1)  # (what models/hrnet.py tells the layer)
         f()
         ms = timed(f)
         P = nns.neighbors_index.shape[0]

@@ -7,7 +7,7 @@ OUT=${1:-gpurun_out/pmc_bench}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "cconv|lat_conv" --output-format csv -d $OUT/$c -o p -- \
+  timeout 900 rocprofv3 --kernel-trace --pmc $c --kernel-include-regex "cconv|lat_conv|frs_query|frs_fix" --output-format csv -d $OUT/$c -o p -- \
       python bench.py --steps 2 --warmup 1 --cpu-side 0 > $OUT/$c.log 2>&1
 done
 python - "$OUT" <<'PY'
