@@ -483,11 +483,13 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
         const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
         const int nq = (nch + 3) >> 2;
         for (int t = wave; t < 16 * nq; t += kCWaves) {
-            const int blk = (t / nq) * 4 + t % nq;
+            int tq, tr;
+                blk_divmod(t, nq, tq, tr);
+                const int blk = tq * 4 + tr;
             const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % CTM) * kCRow + ((blk * 16 + mg * 4) ^ ((mi % CTM) << 2)));
             const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
             // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
-            const int wq = 4 * chunk + t % nq;  // channel quad; the mask holds quads 0 .. 7
+            const int wq = 4 * chunk + tr;  // channel quad; the mask holds quads 0 .. 7
             const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
 #pragma unroll
             for (int n = 0; n < NTT; ++n) {

@@ -213,6 +213,15 @@ __device__ __forceinline__ void axis_weights_linear(float x, int s, int& b, floa
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// t / nq and t % nq for 0 <= t < 64 and nq in 1 .. 4 (k' blocks of the contraction: nq = channel quads of the chunk) without an
+// integer division -- a generic one is ~25 instructions, and the contraction loops form it per block and wave: 3 % of a tile of
+// the 33-pair layers.  (t * m) >> 7 with m = 128 / nq rounded up is exact below 64.
+__device__ __forceinline__ void blk_divmod(int t, int nq, int& quot, int& rem) {
+    const int m = nq == 1 ? 128 : (nq == 2 ? 64 : (nq == 3 ? 43 : 32));
+    quot = (t * m) >> 7;
+    rem = t - quot * nq;
+}
+
 
 
 // defined in cconv.hip, also used by the matrix-core path

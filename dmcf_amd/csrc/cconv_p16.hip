@@ -316,10 +316,12 @@ __global__ __launch_bounds__(kGThreads, 4) __attribute__((amdgpu_num_vgpr(kGComp
     {
         const int nq = (cin + 3) >> 2;
         for (int t = wave; t < 16 * nq; t += kGWaves) {
-            const int blk = (t / nq) * 4 + t % nq;
+            int tq, tr;
+                blk_divmod(t, nq, tq, tr);
+                const int blk = tq * 4 + tr;
             const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kGRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
             const float* wb = p.Wp + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
-            const uint32_t wm = p.wmask >> (4 * (t % nq));  // (all-zero filter blocks of a block-diagonal pair of layers: skipped)
+            const uint32_t wm = p.wmask >> (4 * (tr));  // (all-zero filter blocks of a block-diagonal pair of layers: skipped)
 #pragma unroll
             for (int n = 0; n < NTT; ++n) {
                 if (n < p.NT && ((wm >> n) & 1)) {

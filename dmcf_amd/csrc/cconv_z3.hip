@@ -366,9 +366,11 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
             const int it = it0 + q;
             if (kZWaves * it < 16 * nq) {
                 const int t = wave + kZWaves * it;
-                const int blk = (t / nq) * 4 + t % nq;
+                int tq, tr;
+                blk_divmod(t, nq, tq, tr);
+                const int blk = tq * 4 + tr;
                 const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
-                const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
+                const uint32_t wm = p.wmask >> (4 * (4 * chunk + tr));  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
                     if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
@@ -403,9 +405,11 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
                 const int it = it0 + q;
                 if (kZWaves * it < 16 * nq) {
                     const int t = wave + kZWaves * it;
-                    const int blk = (t / nq) * 4 + t % nq;
+                    int tq, tr;
+                blk_divmod(t, nq, tq, tr);
+                const int blk = tq * 4 + tr;
                     const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kZRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
-                    const uint32_t wm = p.wmask >> (4 * (4 * chunk + t % nq));
+                    const uint32_t wm = p.wmask >> (4 * (4 * chunk + tr));
 #pragma unroll
                     for (int n = 0; n < NTT; ++n) {
                         if (n < p.NT && ((wm >> n) & 1)) {
