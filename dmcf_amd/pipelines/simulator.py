@@ -34,7 +34,7 @@ def reserve_for_scene(reserve_gib, n_points, device):
     gib = reserve_gib
     if gib == "auto":
         gib = n_points * RESERVE_BYTES_PER_POINT / 2 ** 30
-        gib = min(gib, torch.cuda.get_device_properties(device).total_memory / 2 ** 30 / 4)
+        gib = min(gib, torch.cuda.mem_get_info(device)[1] / 2 ** 30 / 4)  # (total device memory)
         if gib < 0.25:
             gib = 0
     return ops.reserve_device_memory(float(gib), device) if gib else 0.0

@@ -25,6 +25,7 @@ def main():
     grid = [int(x) for x in sys.argv[2:5]] if len(sys.argv) > 4 else [2, 2, 2]
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     world = grid[0] * grid[1] * grid[2]
+    torch.cuda.init()  # (before the rank threads make their first device calls concurrently)
     dev = torch.device("cuda:0")
     h = 0.05
     decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * side * h for g in grid], grid)
