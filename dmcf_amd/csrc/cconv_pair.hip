@@ -156,8 +156,15 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         oys[pp] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, oys[pp])));
         ozs[pp] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ozs[pp])));
     }
-    const int nbA = nbs[0], NB = nbs[0] + nbs[1];
     const int nt0 = nts[0], nt1 = nts[1];
+    // ONE DENSE STREAM over the wave's two rows: positions [0, nt0) are point A's pairs, [padA, padA + nt1) point B's, padA =
+    // nt0 rounded up to a block of 8 (the splat runs in blocks of 8 pairs, and a block feeds ONE point's tiles).  Batch t =
+    // positions 64 t .. 64 t + 63; the batch that holds padA is split at that block: A's blocks, the merge of A, B's blocks.
+    // A row of 265 pairs is 4.14 batches but 5 iterations when every point starts a batch of its own; two of them are 8.3 -> 9.
+    const int padA = (nt0 + 7) & ~7;
+    const int S = padA + nt1;
+    const int NB = (S + 63) >> 6;
+    const int tb = padA >> 6, bb = (padA & 63) >> 3;  // A's tiles are complete before block bb of batch tb
     const int64_t rb0 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rbs[0] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rbs[0]);
     const int64_t rb1 = ((int64_t)__builtin_amdgcn_readfirstlane((int)(rbs[1] >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)rbs[1]);
     // ONE buffer over both rows of the wave (they are 8 rows apart in the list): offsets past a row's end are replaced by an
@@ -170,20 +177,21 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
 
     pair_zero_tiles();
 
-    // pairs of batch t of the stream (wave uniform)
-    auto npairs = [&](int t) -> int {
-        const bool pp = t >= nbA;
-        return min(64, (pp ? nt1 : nt0) - 64 * (t - (pp ? nbA : 0)));
-    };
-    auto valid = [&](int t) -> bool { return t < NB && lane < npairs(t); };
+    // stream positions of batch t that exist (wave uniform), and whether this lane's position holds a pair
+    auto npairs = [&](int t) -> int { return max(0, min(64, S - 64 * t)); };
+    auto in_a = [&](int t) -> bool { return 64 * t + lane < nt0; };
+    auto in_b = [&](int t) -> bool { return 64 * t + lane >= padA && 64 * t + lane < S; };
+    auto valid = [&](int t) -> bool { return in_a(t) || in_b(t); };
     // (eligibility bounds n_inp -- and with it every row -- by 2^24 entries: the two rows always fit one buffer)
     if (!near) __builtin_trap();
     auto ld_idx = [&](int t, int& j, float& nv) {
-        const bool pp = t >= nbA, ok = valid(t);
-        const int o = 64 * (t - (pp ? nbA : 0)) + lane;
-        j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, ok ? (uint32_t)o * 4u + (pp ? offB : 0u) : kPOob, 0, 0);
+        const bool a = in_a(t), b = in_b(t);
+        const int sp = 64 * t + lane;
+        // (row A's entry sp, or row B's entry sp - padA, which sits gapB entries behind row A's start)
+        const uint32_t off = a ? (uint32_t)sp * 4u : (b ? (uint32_t)(sp - padA) * 4u + offB : kPOob);
+        j = (int)__builtin_amdgcn_raw_buffer_load_b32(rI, off, 0, 0);
         nv = 0.0f;
-        if (nval && ok) nv = nval[(pp ? rb1 : rb0) + o];
+        if (nval && (a || b)) nv = nval[a ? rb0 + sp : rb1 + (sp - padA)];
     };
     auto ld_pos = [&](int j, float& x, float& y, float& z) {  // a scalar base + one 24-bit multiply
         const float* q = (const float*)((const char*)p.inp_pos + (size_t)__umul24((uint32_t)j, 12u));
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         c.hi = c.lo;
         return c;
 #endif
-        const bool pp = t >= nbA;
+        const bool pp = 64 * t + lane >= padA;  // (per lane: a batch may hold the end of row A and the start of row B)
         x -= pp ? oxs[1] : oxs[0];
         y -= pp ? oys[1] : oys[0];
         z -= pp ? ozs[1] : ozs[0];
@@ -231,12 +239,14 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
     };
     // The class bytes of the 64 pairs, four per scalar register: packed inside each quad with two DPP moves, read out of lanes
     // 0, 4, 8, ... (16 v_readlane per batch; the splat extracts a pair's byte with scalar instructions)
+    int pk_cur = 0;  // the packed class bytes of the staged batch (lanes 0, 4, 8, ...: four pairs each)
     auto pack_classes = [&](int cls4, uint32_t (&c)[16]) {
 #ifdef PX_NOPACK
         return;
 #endif
         int pk = cls4 | (__builtin_amdgcn_mov_dpp(cls4, 0xb1, 0xf, 0xf, true) << 8);   // quad_perm [1, 0, 3, 2]
         pk = pk | (__builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true) << 16);          // quad_perm [2, 3, 0, 1]
+        pk_cur = pk;
 #pragma unroll
         for (int m = 0; m < 16; ++m) c[m] = (uint32_t)__builtin_amdgcn_readlane(pk, 4 * m);
     };
@@ -279,10 +289,10 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         }
     };
     // LDS byte addresses of this lane's operands of group 0: product 4 z' + (y', x') of the lane's block row, its channel
-    const uint32_t a_rec = plds(Rec + 4 * (4 * half + (lane & 3)));
-    const uint32_t a_fst = plds(Fst + 4 * (8 * (ch & 3) + (((ch >> 2) + 4 * ((ch >> 1) & 1)) & 7)));
+    const uint32_t a_rec0 = plds(Rec + 4 * (4 * half + (lane & 3)));
+    const uint32_t a_fst0 = plds(Fst + 4 * (8 * (ch & 3) + (((ch >> 2) + 4 * ((ch >> 1) & 1)) & 7)));
     // One batch: 64 pairs at fixed staging addresses, `nblk` blocks of 8 (tools/gen_pair_splat.py)
-    auto splat = [&](int nblk, const uint32_t (&c)[16]) {
+    auto splat = [&](int nblk, const uint32_t (&c)[16], uint32_t a_rec, uint32_t a_fst) {
 #ifdef PX_NOSPLAT
         return;
 #endif
@@ -331,7 +341,11 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
     uint64_t plast = __builtin_readcyclecounter();
     const uint64_t pstart = plast;
 #endif
-    if (nbA == 0) merge_first();
+    bool a_done = false;
+    if (padA == 0) {
+        merge_first();
+        a_done = true;
+    }
     if (NB > 0) {
         // Stages (nothing hides a round trip at two waves per SIMD, so every load is issued a whole splat before its first
         // use): indices three batches ahead, positions two, geometry + index push + ALL feature loads of batch t + 1 before
@@ -365,22 +379,43 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
             PairRec nxt;
             // what this iteration requests lands in its OWN registers and moves to the loop-carried ones after the splat: a copy
             // placed before it would wait for every load in flight (the counter is in order)
-            int jn = 0;
-            float nvn = 0.0f, qx = 0.0f, qy = 0.0f, qz = 0.0f;
+            int jn;
+            float nvn, qx, qy, qz;
             if (more) {
                 nxt = geom(t + 1, j1, nv1, px, py, pz);
                 push_index(t + 1, j1);
                 pfence();
                 PT(1)
                 f_issue(np1, ff);
-                ld_pos(j2, qx, qy, qz);
-                ld_idx(t + 3, jn, nvn);
-                PT(2)
             }
-            splat((np + 7) >> 3, cc);
-            PT(3)
-            if (t == nbA - 1) merge_first();
+            // (unconditional -- past the stream's end the index load is out of the buffer's range and returns entry 0 -- so that
+            // the loaded registers are not merged with constants of another path: such a merge is a copy behind a full wait)
+            ld_pos(j2, qx, qy, qz);
+            ld_idx(t + 3, jn, nvn);
+            PT(2)
+            const int nblk = (np + 7) >> 3;
+            // ONE splat site: the batch that holds the point boundary runs it twice -- A's blocks, A's merge, then B's blocks
+            // with the staging addresses and the class bytes moved on by bb blocks (two groups of four pairs each)
+            int b0 = 0, b1 = (t == tb && !a_done) ? bb : nblk;
+            for (;;) {
+                if (b1 > b0) {
+                    if (b0 > 0) {  // (cc is dead after this batch: the next one packs its own)
+#pragma unroll
+                        for (int m = 0; m < 16; ++m) cc[m] = (uint32_t)__builtin_amdgcn_readlane(pk_cur, (4 * m + 8 * b0) & 63);
+                    }
+                    splat(b1 - b0, cc, a_rec0 + (uint32_t)(2 * kPRecG * 4) * (uint32_t)b0, a_fst0 + 1024u * (uint32_t)b0);
+                }
+                if (t != tb || a_done) break;
+                PT(3)
+                merge_first();
+                a_done = true;
+                b0 = bb;
+                b1 = nblk;
+            }
             PT(4)
+            // (the compiler may not move the rotation of the in-flight loads -- register copies, each behind a wait for every
+            // load issued before it -- in front of the splat: volatile asm statements keep their order)
+            asm volatile("" : "+v"(jn), "+v"(nvn), "+v"(qx), "+v"(qy), "+v"(qz));
             if (more) {
                 pfence();
                 PT(5)
@@ -401,6 +436,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         }
     }
     PT(8)
+    if (!a_done) merge_first();  // (row A ends exactly at the end of the stream's last batch and row B is empty)
     // point B: merge in place
     asm volatile(
 #include "cconv_pair_merge.inc"
