@@ -301,15 +301,7 @@ int cconv_direct_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy,
     const int64_t ntiles = (p.n_out + pts - 1) / pts;
     if (ntiles > 0x7fffffff) return DMCF_EUNSUPPORTED;
     p.ntiles = (int)ntiles;
-    static int ncu = 0;  // one persistent workgroup per CU
-    if (ncu == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
-            ncu = n;
-        else
-            ncu = 256;
-    }
+    const int ncu = device_cu_count();  // one persistent workgroup per CU
     int nwg = (ncu + 7) / 8 * 8;
     dp.nwg = nwg;
     dp.p = p;

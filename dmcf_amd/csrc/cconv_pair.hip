@@ -48,7 +48,7 @@ namespace dmcf {
 // Diagnostic build (make -C dmcf_amd/csrc pair_trace -> variants/PTRACE.so, read by tools/ptrace.py): cycle stamps at the phase
 // boundaries of the kernel, summed over every 16th tile.  Compiled out of the product library.
 #ifdef PX_TRACE
-__device__ unsigned long long g_ptrace[16];
+__device__ unsigned long long g_ptrace[24];
 #define PT(k) { const uint64_t now_ = __builtin_readcyclecounter(); pt[k] += now_ - plast; plast = now_; }
 #else
 #define PT(k)
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
     };
 
 #ifdef PX_TRACE
-    uint64_t pt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t pt[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t plast = __builtin_readcyclecounter();
     const uint64_t pstart = plast;
 #endif
@@ -491,7 +491,9 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
 #include "cconv_pair_store.inc"
                 :: [b] "v"(rowB_) : "memory", PAIR_FIXED_REGS);
         }
+        PT(16)
         __syncthreads();
+        PT(17)
         const int nq = nq_of(chunk);
 #pragma unroll
         for (int it0 = 0; it0 < kIt; it0 += kPre) {
@@ -523,7 +525,9 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
                 w_issue(chunk + 1, 0, bw);
             }
         }
+        PT(18)
         __syncthreads();
+        PT(19)
     }
 
     PT(13)
@@ -537,7 +541,9 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
             for (int r = 0; r < 4; ++r) red[((size_t)wave * 16 + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
         }
     }
+    PT(20)
     __syncthreads();
+    PT(21)
     for (int e = tid; e < PTM * cout; e += kPThreads) {
         const int ptt = e / cout, o = e % cout;
         const int64_t ii = pt0 + ptt;
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
 #ifdef PX_TRACE
     PT(14)
     if (lane == 0 && (tile & 15) == 0) {
-        for (int k = 0; k < 16; ++k)
+        for (int k = 0; k < 24; ++k)
             if (k < 10 || k > 12) atomicAdd(&g_ptrace[k], pt[k]);
         atomicAdd(&g_ptrace[10], plast - pstart);
         atomicAdd(&g_ptrace[11], 1ull);
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
 #ifdef PX_TRACE
 }
 extern "C" int dmcf_ptrace(unsigned long long* out) {
-    unsigned long long z[16] = {0};
+    unsigned long long z[24] = {0};
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmcf::g_ptrace), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(dmcf::g_ptrace), z, sizeof(z));
     return 0;

@@ -22,6 +22,18 @@ inline int check_launch() {
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// compute units of the current device (persistent kernels launch one workgroup, or a few, per CU); 256 when the query fails
+inline int device_cu_count() {
+    static thread_local int ncu[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (ncu[dev] == 0) {
+        int n = 0;
+        ncu[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    return ncu[dev];
+}
+
 // un-fused float arithmetic for everything that feeds a comparison which decides set membership
 __device__ __forceinline__ float dist2_unfused(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);

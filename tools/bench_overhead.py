@@ -19,8 +19,14 @@ for cin, cout in ((32, 32), (16, 32), (24, 16), (8, 8), (4, 8)):
     rs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     idx = torch.zeros(1, dtype=torch.int32, device=dev)
     d = torch.zeros(1, dtype=torch.float32, device=dev)
-    for k in ("blk", "mfma", "lds"):
-        os.environ["DMCF_CCONV_KERNEL"] = k
-        f = lambda: ops.cconv_forward(W, s0, 0.2, s0, feat, idx, rs, neighbors_value=d, window="poly6")
-        f()
-        print(f"{cin}->{cout} {k}: {timed(f):.2f} ms with empty neighbour lists", flush=True)
+    for k in ("", "cls", "z3", "pair"):  # "": the default dispatch of a short-row layer
+        os.environ.pop("DMCF_CCONV_KERNEL", None)
+        if k:
+            os.environ["DMCF_CCONV_KERNEL"] = k
+        f = lambda: ops.cconv_forward(W, s0, 0.2, s0, feat, idx, rs, window="poly6", row_length_hint=1)
+        try:
+            f()
+        except Exception as e:
+            print(f"{cin}->{cout} {k}: {type(e).__name__}", flush=True)
+            continue
+        print(f"{cin}->{cout} {k or 'default'}: {timed(f):.2f} ms with empty neighbour lists", flush=True)

@@ -9,14 +9,16 @@ from dmcf_amd import _lib
 from tools import microbench
 
 lib = ctypes.CDLL(os.path.join(ROOT, "dmcf_amd", "libdmcf_hip.so"))
-buf = (ctypes.c_ulonglong * 16)()
+buf = (ctypes.c_ulonglong * 24)()
 microbench.main()
 torch.cuda.synchronize()
 lib.dmcf_ptrace(buf)
 z = np.array(list(buf), dtype=np.float64)
 names = ["prologue (first batch: idx -> pos -> geometry -> features)", "geometry + push_index", "issue: features, positions, indices",
-         "splat", "merge of the first point", "wait for the loads (fence)", "publish features", "records + classes",
-         "(loop exit)", "merge of the second point + unpark", "", "", "", "stores + barriers + contraction", "reduction + epilogue"]
+         "splat of the first point's blocks (boundary batch)", "splat (+ merge of the first point)", "wait for the loads (fence)",
+         "publish features", "records + classes", "(loop exit)", "merge of the second point + unpark", "", "", "", "(chunk loop exit)",
+         "epilogue: sum over waves, bias, store", "", "chunk: tiles -> B rows", "chunk: barrier (slowest wave)",
+         "chunk: contraction (B fragments, filter fragments, matrix)", "chunk: barrier", "partial sums -> LDS", "barrier"]
 tot, waves, nb = z[10], z[11], z[12]
 print(f"waves {waves:.0f} batches {nb:.0f} cycles/wave {tot / waves:.0f} cycles/batch {tot / nb:.0f}")
 for k, n in enumerate(names):
