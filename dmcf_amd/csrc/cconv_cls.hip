@@ -131,6 +131,7 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
 #pragma unroll
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
+    float out_prev = 0.0f;
     for (int chunk = 0; chunk < p.nchunks; ++chunk) {
         const int c0 = chunk * CCH;
         const int nch = min(CCH, cin - c0);
@@ -472,6 +473,7 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
                 }
             }
         }
+        if (chunk == p.nchunks - 1) out_prev = epilogue_prefetch(p, pt0, CTM, tid);  // (its round trip: under the merge and the contraction)
         merge(wave + kCWaves);
         __syncthreads();
         if constexpr (SINGLE) {
@@ -525,7 +527,7 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
         for (int w = 0; w < kCWaves; ++w) v += red[((size_t)w * kCRows + ptt) * ncol + o];
         if (p.bias) v += p.bias[o];
         float* dst = p.out + ii * cout + o;
-        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += e == tid ? out_prev : *dst;
         *dst = v;
     }
 }

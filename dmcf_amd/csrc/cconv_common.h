@@ -245,6 +245,16 @@ bool cconv_cls_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 size_t cconv_cls_packed_floats(int cin, int cout);
 int cconv_cls_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 int cconv_cls_pack(const dmcf_cconv_args* a, float* packed, hipStream_t stream);  // enqueues the packing, returns the chunk count
+// DMCF_FLAG_ACCUMULATE: the value the epilogue adds to, requested EARLY (before the contraction): read in the epilogue itself it is
+// a dependent round trip at the very end of every tile, with nothing left to hide it -- as long as the elementwise kernel it
+// replaces.  A tile's outputs are contiguous (point-major): element e = point * cout + channel sits at out + pt0 * cout + e; this
+// is the element of the thread's first epilogue iteration (e = tid), later iterations read theirs in place.
+__device__ __forceinline__ float epilogue_prefetch(const CconvParams& p, int64_t pt0, int pts, int tid) {
+    if (!(p.flags & DMCF_FLAG_ACCUMULATE)) return 0.0f;
+    const int64_t lim = min((int64_t)pts, p.n_out - pt0) * p.cout;
+    return tid < lim ? p.out[pt0 * p.cout + tid] : 0.0f;
+}
+
 // The "plain" layer: poly6 window on squared distances re-formed from the positions, no per-point importance -- every CConv of
 // the networks here once the lists carry no distances.  Splats D and E have instantiations with these three choices compiled
 // in: the window's branch ladder, the distance / importance loads and their predicates otherwise run once per batch.

@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
             }
         }
     };
+    const float out_prev = epilogue_prefetch(p, pt0, PTM, tid);
     f32x4 bw[kPre][NTT];
     w_issue(0, 0, bw);  // the first fragments' round trip runs under the tile's first barrier
 #pragma unroll 1
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
         for (int w = 0; w < kPWaves; ++w) v += red[((size_t)w * 16 + ptt) * ncol + o];
         if (p.bias) v += p.bias[o];
         float* dst = p.out + ii * cout + o;
-        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += e == tid ? out_prev : *dst;
         *dst = v;
     }
 #ifdef PX_TRACE

@@ -377,6 +377,7 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
             }
         }
     };
+    const float out_prev = epilogue_prefetch(p, pt0, ZTM, tid);
     f32x4 bw[kBoth ? 2 : 1][kPre][NTT];
     w_issue(0, 0, bw[0]);
     if (kBoth && p.nchunks > 1) w_issue(1, 0, bw[kBoth ? 1 : 0]);
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
         for (int w = 0; w < kZWaves; ++w) v += red[((size_t)w * 16 + ptt) * ncol + o];
         if (p.bias) v += p.bias[o];
         float* dst = p.out + ii * cout + o;
-        if (p.flags & DMCF_FLAG_ACCUMULATE) v += *dst;
+        if (p.flags & DMCF_FLAG_ACCUMULATE) v += e == tid ? out_prev : *dst;
         *dst = v;
     }
 #ifdef ZX_TRACE

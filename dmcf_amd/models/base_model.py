@@ -32,6 +32,16 @@ class Dense(torch.nn.Module):
             return torch.addmm(self.bias, x, self.kernel)
         return x @ self.kernel
 
+    @torch.no_grad()
+    def product(self, x, residual=None):
+        """``x @ kernel`` (+ ``residual``, inside the GEMM: its C operand) WITHOUT the bias -- the start of a layer's sum
+        (models/hrnet.py); the bias rides on the first convolution that accumulates into the result."""
+        if self.kernel is None:
+            self.build(x.shape[-1], x.device)
+        if residual is not None:
+            return torch.addmm(residual, x, self.kernel)
+        return x @ self.kernel
+
 
 class BaseModel(torch.nn.Module):
     """models/base_model.py:10-29.  ``model(data, training=False)`` runs

@@ -4,11 +4,17 @@
 (pos[inp_scale] -> pos[scale], extent 2*r[max(inp_scale, scale)], hrnet.py:85-92), a Dense + identity
 residual on the same-scale branch (:93-99), merged by add_n (``add_merge``) or concat (:115-118).
 """
+import os
+
 import numpy as np
 import torch
 
 from .base_model import Dense
 from .pbf_model import PBFNet
+
+
+# DMCF_FUSE_EPILOGUE=0: every term of a layer's sum as its own tensor, summed by elementwise kernels (the reference's form)
+_FUSE_EPILOGUE = os.environ.get("DMCF_FUSE_EPILOGUE", "1") != "0"
 
 
 class HRNet(PBFNet):
@@ -80,10 +86,27 @@ class HRNet(PBFNet):
             for scale in order:
                 importance = self.part_scale if scale == 0 else 1.0
                 inp = []
-                for inp_scale in range(len(ans_convs[-1])):
-                    feats = relu_in[inp_scale]  # :85
+                n_inp = len(ans_convs[-1])
+
+                def feats_of(inp_scale):
+                    f = relu_in[inp_scale]  # :85
                     if self.dens_norm and dens is not None and inp_scale < len(dens):  # :87-89
-                        feats = torch.cat([feats, feats / dens[inp_scale] ** 2], dim=-1)
+                        f = torch.cat([f, f / dens[inp_scale] ** 2], dim=-1)
+                    return f
+
+                # ONE running sum per output scale instead of a tensor per term and an elementwise kernel per "+" (:93-99,
+                # :115-118): the Dense of the layer's own scale starts it -- with the residual as the GEMM's C operand --, every
+                # convolution adds its result in its epilogue (DMCF_FLAG_ACCUMULATE), the Dense bias rides on the first of
+                # them.  The same terms in a different order of additions (the parity bar of the outputs is 1e-5).
+                fuse = self.add_merge and _FUSE_EPILOGUE
+                acc, pending_bias = None, None
+                if fuse and layer < len(self.denses) and scale < n_inp:
+                    own = self.denses[layer][scale][0][scale]
+                    prev_out = ans_convs[-1][scale]
+                    acc = own.product(feats_of(scale), prev_out if own.units == prev_out.shape[-1] else None)
+                    pending_bias = own.bias
+                for inp_scale in range(n_inp):
+                    feats = feats_of(inp_scale)
                     ext = filter_extent[max(inp_scale, scale)]
                     conv_in = feats if importance == 1.0 else feats * importance
                     conv = self.convs[layer][scale][0][inp_scale]
@@ -102,7 +125,29 @@ class HRNet(PBFNet):
                     else:
                         # (the same relu(x_{inp_scale}) feeds every output scale: its widest extent is a hint for the hook)
                         widest = max(filter_extent[max(inp_scale, s)] for s in range(n_scales))
+                        if acc is not None:
+                            conv.accumulate_into, conv.extra_bias = acc, pending_bias
                         ans_conv = self.apply_conv(conv, conv_in, pos[inp_scale], pos[scale], ext, widest if conv_in is feats else None)
+                        if acc is not None:
+                            if conv.accumulate_into is None:  # (taken: the result IS the sum)
+                                pending_bias = None
+                            conv.accumulate_into = conv.extra_bias = None
+                    if fuse:
+                        if acc is None:
+                            acc = ans_conv
+                        elif ans_conv is not acc:
+                            acc = acc.add_(ans_conv)
+                        if layer < len(self.denses) and scale != inp_scale and self.voxel_size is None:  # :100-113 (FPS lists)
+                            if scale > inp_scale:
+                                for i in range(inp_scale, scale):
+                                    feats = feats[idx[i + 1][0].long()]
+                                acc = acc + self.denses[layer][scale][0][inp_scale](feats)
+                            else:
+                                ind = idx[scale + 1][0].long()
+                                for i in range(scale + 1, inp_scale):
+                                    ind = ind[idx[i + 1][0].long()]
+                                acc = acc.index_add(0, ind, self.denses[layer][scale][0][inp_scale](feats))
+                        continue
                     if layer < len(self.denses):
                         if scale == inp_scale:  # :93-99
                             ans_conv = ans_conv + self.denses[layer][scale][0][inp_scale](feats)
@@ -119,7 +164,9 @@ class HRNet(PBFNet):
                                     ind = ind[idx[i + 1][0].long()]
                                 ans_conv = ans_conv.index_add(0, ind, self.denses[layer][scale][0][inp_scale](feats))
                     inp.append(ans_conv)
-                if self.add_merge:  # :115-118
+                if fuse:
+                    ans[scale] = acc if pending_bias is None else acc.add_(pending_bias)
+                elif self.add_merge:  # :115-118
                     merged = inp[0]
                     for t in inp[1:]:
                         merged = merged + t

@@ -336,6 +336,8 @@ class ContinuousConv(torch.nn.Module):
         # what the MODEL knows about this layer's rows from its configuration (include/dmcf_hip.h, row_length_hint): 0 unknown,
         # 1 = the network's base radius (tens of neighbours), 2 = a wider radius (hundreds); models/hrnet.py sets it
         self.row_length_hint = 0
+        self.accumulate_into = None  # one-shot, see forward
+        self.extra_bias = None
 
     # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
     def build(self, in_channels, device=None):
@@ -379,6 +381,16 @@ class ContinuousConv(torch.nn.Module):
                 user_neighbors_importance=None):
         if self.kernel is None:
             self.build(inp_features.shape[-1], inp_features.device)
+        # one-shot requests of the caller (models/hrnet.py): add the result to this tensor in the kernel's epilogue
+        # (DMCF_FLAG_ACCUMULATE) instead of returning a new one, and add this vector to the layer's bias
+        acc, extra_bias = self.accumulate_into, self.extra_bias
+        self.accumulate_into = self.extra_bias = None
+        if acc is not None and (self.use_dense_layer_for_center or self.activation is not None or not acc.is_contiguous()
+                                or tuple(acc.shape) != (out_positions.shape[0], self.filters) or acc.dtype != torch.float32):
+            self.extra_bias = extra_bias  # (not expressible in the epilogue: the plain call, then the sum)
+            return acc.add_(self.forward(inp_features, inp_positions, out_positions, extents, inp_importance,
+                                         fixed_radius_search_hash_table, user_neighbors_index, user_neighbors_row_splits,
+                                         user_neighbors_importance))
         if isinstance(extents, torch.Tensor):
             if extents.dim() > 0 and extents.numel() != 1:
                 raise NotImplementedError("per-point extents (RadiusSearch, convolutions.py:366-370) are never "
@@ -406,9 +418,10 @@ class ContinuousConv(torch.nn.Module):
                     ops, self.kernel, inp_features, out_positions.shape[0], extent,
                     window=self.window_function.name, window_fac=self.window_function.fac,
                     align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
-                    interpolation=self.interpolation, bias=self.bias if fuse_bias else None)
+                    interpolation=self.interpolation, bias=self._epilogue_bias(fuse_bias, extra_bias),
+                    out=acc, accumulate=acc is not None)
                 self._conv_values, self._conv_output = None, (None if _CACHE.depth > 0 else out_features)
-                return self._finish(out_features, inp_features)
+                return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             radius = float(np.float32(0.5) * np.float32(extent))  # :353
             if fixed_radius_search_hash_table is not None:
                 self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
@@ -469,8 +482,9 @@ class ContinuousConv(torch.nn.Module):
             neighbors_value=neighbors_value, window=window, window_fac=window_fac, inp_importance=inp_importance,
             align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
-            bias=self.bias if fuse_bias else None, n_pairs_ref=n_pairs_ref,
-            neighbors_row_count=row_count, skip_self=skip_self, row_length_hint=self.row_length_hint)
+            bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=n_pairs_ref,
+            neighbors_row_count=row_count, skip_self=skip_self, row_length_hint=self.row_length_hint,
+            out=acc, accumulate=acc is not None)
         if self._direct_kernel is None and in_step and self.radius_search_ignore_query_points:
             # (asked once per layer: the dispatch looks at the layer, never at the list)
             self._direct_kernel = ops.cconv_forward(
@@ -485,7 +499,16 @@ class ContinuousConv(torch.nn.Module):
                 _CACHE.with_query_points(self.fixed_radius_search, inp_positions, out_positions,
                                          float(np.float32(0.5) * np.float32(extent)))
         self._conv_output = None if in_step else out_features
-        return self._finish(out_features, inp_features)
+        return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
+
+    def _epilogue_bias(self, fuse_bias, extra_bias):
+        """The vector the kernel's epilogue adds: the layer's bias (when the epilogue may form it) + the caller's."""
+        if self.use_dense_layer_for_center:
+            return None  # (bias and the caller's vector follow the dense term, _finish)
+        bias = self.bias if fuse_bias else None
+        if extra_bias is None:
+            return bias
+        return extra_bias if bias is None else bias + extra_bias
 
     def _shares_list(self):
         """May this layer take the list of the same search WITH the query points (see _NeighborCache.with_query_points)?  Only
@@ -494,13 +517,15 @@ class ContinuousConv(torch.nn.Module):
         return (self.radius_search_ignore_query_points and self._direct_kernel is True and self.radius_search_metric == "L2"
                 and isinstance(self.window_function, WindowFunction) and os.environ.get("DMCF_SHARE_LISTS", "1") != "0")
 
-    def _finish(self, out_features, inp_features):
+    def _finish(self, out_features, inp_features, extra_bias=None):
         if self.use_dense_layer_for_center:  # :462-464
             dense_output = inp_features @ self.dense
             self._dense_output = None if _CACHE.depth > 0 else dense_output
             out_features = out_features + dense_output
             if self.use_bias:
                 out_features = out_features + self.bias
+        if extra_bias is not None:
+            out_features = out_features + extra_bias
         if self.activation is not None:
             out_features = self.activation(out_features)
         return out_features

@@ -262,7 +262,31 @@ def test_cross_layer_paired_convs_equal_the_two_layers(dev, monkeypatch):
             launches.append(sum(1 for k, m, _ in recs if k == "cconv"))
         res[fuse] = (state[0].cpu().numpy(), state[1].cpu().numpy(), launches)
     assert res["0"][2] == [17, 17, 17] and res["1"][2] == [16, 16, 16], (res["0"][2], res["1"][2])  # 18 layers, input pair fused
-    assert _rel(res["1"][0], res["0"][0]) <= 1e-6 and _rel(res["1"][1], res["0"][1]) <= 1e-4
+    assert _rel(res["1"][0], res["0"][0]) <= 1e-6, _rel(res["1"][0], res["0"][0])
+    assert _rel(res["1"][1], res["0"][1]) <= 1e-4, _rel(res["1"][1], res["0"][1])
+
+
+def test_layer_sums_in_the_conv_epilogue_equal_the_separate_terms(dev, monkeypatch):
+    """HRNet forms a layer's sum conv_0 + conv_1 + conv_2 + dense + residual in ONE buffer (Dense.product with the residual as
+    the GEMM's C operand, every convolution adding in its epilogue, DMCF_FLAG_ACCUMULATE) instead of a tensor per term and an
+    elementwise kernel per '+': the same terms in another order -- three steps agree to rounding, with fewer launches outside
+    the library."""
+    from dmcf_amd.models import hrnet
+    from dmcf_amd.pipelines import Simulator
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(hrnet, "_FUSE_EPILOGUE", fuse)
+        sim = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+        state = scenes.model_inputs(scenes.box_scene(20, seed=9), device=dev)
+        for _ in range(3):
+            state = sim.step([state])[0]
+        convs = [c for _, c in sim.model._all_convs]
+        assert all(c.accumulate_into is None and c.extra_bias is None for c in convs)  # one-shot requests, all taken
+        res[fuse] = (state[0].cpu().numpy(), state[1].cpu().numpy())
+    assert _rel(res[True][0], res[False][0]) <= 1e-6, _rel(res[True][0], res[False][0])
+    assert _rel(res[True][1], res[False][1]) <= 1e-4, _rel(res[True][1], res[False][1])
 
 
 def test_liquid3d_momentum_conservation(dev):

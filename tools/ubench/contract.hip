@@ -17,9 +17,10 @@ constexpr int kRow = 1024;
 constexpr int NT = 2;
 
 template <int WAVES, int VAR>
-__global__ __launch_bounds__(64 * WAVES, 1) void tail(const float* __restrict__ Wp, float* __restrict__ out, int ntiles, float seed) {
+__global__ __launch_bounds__(64 * WAVES, 1) void tail(const float* __restrict__ Wp_arg, float* __restrict__ out, int ntiles, float seed) {
+    const float* Wp = Wp_arg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr bool kPersist = VAR & 1, kStationary = VAR & 2, kNoMfma = VAR & 4, kNoLds = VAR & 8, kNoEpi = VAR & 16;
+    constexpr bool kPersist = VAR & 1, kStationary = VAR & 2, kNoMfma = VAR & 4, kNoLds = VAR & 8, kNoEpi = VAR & 16, kReload = VAR & 32;
     constexpr int kIt = 64 / WAVES;  // blocks of a chunk per wave
     constexpr int PPW = 16 / WAVES;  // points per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(64 * WAVES, 1) void tail(const float* __restrict__ 
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+        if (kReload) {  // the filter pointer fetched from the argument block again, as a fresh workgroup has to
+            typedef const __attribute__((address_space(4))) uint64_t* KP;
+            KP kp = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(kp));
+            Wp = (const float*)kp[0];
+        }
         if (!kStationary) w_issue();
         const f32x4 val = {seed * tile, seed, seed + 1.0f, seed * lane};
 #pragma unroll
@@ -140,6 +147,7 @@ int main() {
            ntiles * 1024.0 * 32 / 4 / ncu / 2.4e9 * 1e3);
     run<16, 0>(W, out, ntiles, ncu, "as the product (workgroup per tile, filter per tile)");
     run<16, 1>(W, out, ntiles, ncu, "persistent");
+    run<16, 33>(W, out, ntiles, ncu, "persistent, arguments fetched again per tile");
     run<16, 2>(W, out, ntiles, ncu, "filter once per workgroup (= per tile here)");
     run<16, 3>(W, out, ntiles, ncu, "persistent + filter-stationary");
     run<16, 4>(W, out, ntiles, ncu, "no matrix instructions");
