@@ -46,12 +46,15 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def cconv_algorithmic_bytes(m):
     """SURVEY.md section 8d, no cache credit.  Neighbour-list launch: P * (4 index + 12 neighbour xyz + 4 * Cin features
     [+ 4 importance / d^2 only when the list carries that array]) + n_out * (8 row split + 12 xyz + 4 * Cout) +
-    4 * K * Cin * Cout.  Lattice launch (no list): the input volume, the per-offset matrices, the cell table, the outputs."""
+    4 * K * Cin * Cout.  Lattice launch (no list): the input volume, the per-offset matrices, the cell table, the outputs.
+    A launch that ADDS to its output (DMCF_FLAG_ACCUMULATE: the layer sums of models/hrnet.py) reads it first: + n_out * 4 * Cout,
+    the bytes of the elementwise kernel it replaces."""
+    rmw = m["n_out"] * 4 * m["cout"] if m.get("accumulate") else 0
     if m.get("lattice"):
         return (m["volume_bytes"] + m["table_bytes"] + 4 * m["n_offsets"] * m["cin"] * m["cout"]
-                + m["n_out"] * 4 * m["cout"] + 4 * m["K"] * m["cin"] * m["cout"])
+                + m["n_out"] * 4 * m["cout"] + 4 * m["K"] * m["cin"] * m["cout"] + rmw)
     per_pair = 4 + 12 + 4 * m["cin"] + (4 if m.get("pair_values", True) else 0)
-    return m["pairs"] * per_pair + m["n_out"] * (8 + 12 + 4 * m["cout"]) + 4 * m["K"] * m["cin"] * m["cout"]
+    return m["pairs"] * per_pair + m["n_out"] * (8 + 12 + 4 * m["cout"]) + 4 * m["K"] * m["cin"] * m["cout"] + rmw
 
 
 def frs_algorithmic_bytes(m):

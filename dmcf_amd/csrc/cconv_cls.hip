@@ -474,35 +474,74 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
             }
         }
         if (chunk == p.nchunks - 1) out_prev = epilogue_prefetch(p, pt0, CTM, tid);  // (its round trip: under the merge and the contraction)
+        // ---------------- contraction of this channel chunk on the matrix cores ----------------
+        // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4 for t = wave + 8 it; blocks of channels past the chunk's end
+        // are skipped.  The filter fragments of this wave's blocks are requested kPre blocks at a time, the first ones BEFORE
+        // the second point's merge and the tile's barrier: their round trip runs under those.  The loop this replaces loaded a
+        // block's fragments right before its matrix instructions -- one exposed L2 round trip per block, eight per tile
+        // (cconv_z3.hip found the same: ~1500 clocks each with every wave of the workgroup in the same phase).
+        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
+        const int nq = (nch + 3) >> 2;
+        constexpr int kIt = 64 / kCWaves;                       // blocks of a chunk per wave
+        // (fragments + accumulators must fit the compiler's registers; a multi-chunk layer's accumulators live across the walk)
+        constexpr int kPre = SINGLE ? (NTT <= 1 ? 8 : (NTT <= 2 ? 4 : 2)) : (NTT <= 1 ? 4 : (NTT <= 2 ? 2 : 1));
+        auto w_issue = [&](int it0, f32x4 (&bw)[kPre][NTT]) {
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) {
+                const int t = wave + kCWaves * (it0 + q);
+                if (t < 16 * nq) {
+                    int tq, tr;
+                    blk_divmod(t, nq, tq, tr);
+                    const int blk = tq * 4 + tr;
+                    const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+                    // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
+                    const int wq = 4 * chunk + tr;  // channel quad; the mask holds quads 0 .. 7
+                    const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
+#pragma unroll
+                    for (int n = 0; n < NTT; ++n)
+                        if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
+                }
+            }
+        };
+        f32x4 bw[kPre][NTT];
+        // (written under conditions, inside the chunk loop: without a definition here the compiler carries "the previous
+        // chunk's value" -- these registers -- across the whole walk of the list)
+#pragma unroll
+        for (int q = 0; q < kPre; ++q)
+#pragma unroll
+            for (int n = 0; n < NTT; ++n) asm volatile("" : "=v"(bw[q][n]));
+        w_issue(0, bw);
         merge(wave + kCWaves);
         __syncthreads();
         if constexpr (SINGLE) {
 #pragma unroll
             for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
         }
-        // ---------------- contraction of this channel chunk on the matrix cores ----------------
-        // 16-wide k' blocks: blk = (z * 4 + y) * 4 + channel / 4; blocks of channels past the chunk's end are skipped.
-        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
-        const int nq = (nch + 3) >> 2;
-        for (int t = wave; t < 16 * nq; t += kCWaves) {
-            int tq, tr;
-                blk_divmod(t, nq, tq, tr);
-                const int blk = tq * 4 + tr;
-            const f32x4 av = *(const f32x4*)(Bt + (size_t)(mi % CTM) * kCRow + ((blk * 16 + mg * 4) ^ ((mi % CTM) << 2)));
-            const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
-            // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
-            const int wq = 4 * chunk + tr;  // channel quad; the mask holds quads 0 .. 7
-            const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
 #pragma unroll
-            for (int n = 0; n < NTT; ++n) {
-                if (n < p.NT && ((wm >> n) & 1)) {
-                    const f32x4 bv = *(const f32x4*)(wb + n * 64);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+        for (int it0 = 0; it0 < kIt; it0 += kPre) {
+#pragma unroll
+            for (int q = 0; q < kPre; ++q) {
+                const int t = wave + kCWaves * (it0 + q);
+                if (t < 16 * nq) {
+                    int tq, tr;
+                    blk_divmod(t, nq, tq, tr);
+                    const int blk = tq * 4 + tr;
+                    const f32x4 av = *(const f32x4*)(Bt + (size_t)mi * kCRow + ((blk * 16 + mg * 4) ^ (mi << 2)));
+                    const int wq = 4 * chunk + tr;
+                    const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
+#pragma unroll
+                    for (int n = 0; n < NTT; ++n) {
+                        if (n < p.NT && ((wm >> n) & 1)) {
+                            const f32x4 bv = bw[q][n];
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[n], 0, 0, 0);
+                        }
+                    }
                 }
             }
+            if (it0 + kPre < kIt && wave + kCWaves * (it0 + kPre) < 16 * nq) w_issue(it0 + kPre, bw);
         }
         __syncthreads();
     }

@@ -628,7 +628,8 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
         timer.end("cconv", dict(pairs=0, pairs_equiv=int(no * (n_off / len(parts)) * float(fill)), n_out=no, cin=int(cin),
                                 cout=int(cout), K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False,
                                 lattice=True, kernel="lat_conv_kernel", n_offsets=int(n_off),
-                                volume_bytes=int(inp_volume.numel()) * 4, table_bytes=int(out_table.numel()) * 4), t0)
+                                volume_bytes=int(inp_volume.numel()) * 4, table_bytes=int(out_table.numel()) * 4,
+                                accumulate=bool(accumulate)), t0)
     return out
 
 
@@ -693,7 +694,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96)
         timer.end("cconv", dict(pairs=n_pairs_ref if n_pairs_ref is not None else int(a.n_pairs), n_out=n_out, cin=int(filters.shape[3]), cout=cout,
                                 K=kdims[0] * kdims[1] * kdims[2], symmetric=bool(symmetric), kernel=name.value.decode(),
-                                pair_values=bool(a.neighbors_value)), t0)
+                                pair_values=bool(a.neighbors_value), accumulate=bool(accumulate)), t0)
     return out
 
 
