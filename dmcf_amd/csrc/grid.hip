@@ -68,17 +68,23 @@ __global__ __launch_bounds__(256) void grid_sum(const float* __restrict__ pos, i
     }
 }
 
+// one wavefront: lane l sums the blocks l, l + 64, ... in rising order, the 64 partial sums meet in a fixed butterfly --
+// deterministic (a serial loop over the blocks was 54 us of dependent double adds behind dependent loads)
 __global__ void grid_center(const double* __restrict__ part, int nblocks, int64_t n, const float* __restrict__ given,
                             GridHeader* h) {
-    const int a = threadIdx.x;
-    if (a >= 3) return;
+    const int lane = lane_id();
     if (given) {
-        h->center[a] = given[a];
+        if (lane < 3) h->center[lane] = given[lane];
         return;
     }
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += part[b * 3 + a];  // fixed order: deterministic
-    h->center[a] = n > 0 ? (float)(s / (double)n) : 0.0f;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += kWave) s += part[b * 3 + a];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, kWave);
+        if (lane == 0) h->center[a] = n > 0 ? (float)(s / (double)n) : 0.0f;
+    }
 }
 
 // extrema of the scaled positions, per block
@@ -117,14 +123,28 @@ __global__ __launch_bounds__(256) void grid_extrema(const GridParams p, const Gr
 }
 
 __global__ void grid_finish_bounds(const GridParams p, const float* __restrict__ part, int nblocks, GridHeader* h) {
-    if (threadIdx.x != 0) return;
-    int64_t cells = p.n > 0 ? 1 : 0;
+    // one wavefront: the blocks' extrema by lanes, then a butterfly (min / max: any order gives the same bits)
+    const int lane = lane_id();
+    float mns[3], mxs[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
         float mn = INFINITY, mx = -INFINITY;
-        for (int b = 0; b < nblocks; ++b) {
+        for (int b = lane; b < nblocks; b += kWave) {
             mn = fminf(mn, part[b * 6 + a]);
             mx = fmaxf(mx, part[b * 6 + 3 + a]);
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, d, kWave));
+            mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
+        }
+        mns[a] = mn;
+        mxs[a] = mx;
+    }
+    if (lane != 0) return;
+    int64_t cells = p.n > 0 ? 1 : 0;
+    for (int a = 0; a < 3; ++a) {
+        const float mn = mns[a], mx = mxs[a];
         int lo = 0, d = 0;
         if (p.n > 0 && isfinite(mn) && isfinite(mx)) {
             // :167-170 -- floor is monotone: the extrema of the candidates follow from the extrema of the positions
