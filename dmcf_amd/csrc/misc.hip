@@ -128,6 +128,72 @@ int scan_counts_to_row_splits(const int32_t* counts, int64_t* row_splits, int64_
 // one wave per row for long rows would be overkill here: rows are neighbour lists (tens to a few
 // thousand entries) and the op runs once per step (models/pbf_model.py:450-453); a 16-lane group per
 // row keeps the loads coalesced inside a row.
+// Axis-aligned bounding box of [n, 3] points (dmcf_points_aabb): per-block extrema without atomics, then one wavefront over
+// the blocks.  A NaN coordinate makes both bounds of its axis NaN (what torch.aminmax / tf.reduce_min return).
+constexpr int kAabbBlocks = 1024;
+
+__global__ __launch_bounds__(256) void aabb_partial(const float* __restrict__ pts, int64_t n, float* __restrict__ part) {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    bool bad[3] = {false, false, false};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+            bad[a] |= v != v;
+        }
+    }
+    __shared__ float red[3][3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float b = bad[a] ? 1.0f : 0.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, kWave));
+            b = fmaxf(b, __shfl_xor(b, d, kWave));
+        }
+        if (lane_id() == 0) {
+            red[0][a][threadIdx.x >> 6] = mn[a];
+            red[1][a][threadIdx.x >> 6] = mx[a];
+            red[2][a][threadIdx.x >> 6] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        float* o = part + (size_t)blockIdx.x * 8;
+        const bool b = fmaxf(fmaxf(red[2][a][0], red[2][a][1]), fmaxf(red[2][a][2], red[2][a][3])) > 0.0f;
+        o[a] = b ? NAN : fminf(fminf(red[0][a][0], red[0][a][1]), fminf(red[0][a][2], red[0][a][3]));
+        o[3 + a] = b ? NAN : fmaxf(fmaxf(red[1][a][0], red[1][a][1]), fmaxf(red[1][a][2], red[1][a][3]));
+    }
+}
+
+__global__ void aabb_finish(const float* __restrict__ part, int nblocks, float* __restrict__ out) {
+    const int lane = lane_id();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = INFINITY, mx = -INFINITY, b = 0.0f;
+        for (int k = lane; k < nblocks; k += kWave) {
+            const float lo = part[(size_t)k * 8 + a], hi = part[(size_t)k * 8 + 3 + a];
+            b = fmaxf(b, lo != lo ? 1.0f : 0.0f);
+            mn = fminf(mn, lo);
+            mx = fmaxf(mx, hi);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn = fminf(mn, __shfl_xor(mn, d, kWave));
+            mx = fmaxf(mx, __shfl_xor(mx, d, kWave));
+            b = fmaxf(b, __shfl_xor(b, d, kWave));
+        }
+        if (lane == 0) {
+            out[a] = b > 0.0f ? NAN : mn;
+            out[3 + a] = b > 0.0f ? NAN : mx;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* __restrict__ values,
                                                                    const int64_t* __restrict__ row_splits,
                                                                    int64_t n_rows, float* __restrict__ out) {
@@ -150,7 +216,7 @@ __global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* 
 
 extern "C" {
 
-int dmcf_version(void) { return 20300; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF; 2.3.0: row_length_hint (splat F)
+int dmcf_version(void) { return 20400; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF; 2.3.0: row_length_hint (splat F); 2.4.0: dmcf_points_aabb
 
 const char* dmcf_error_string(int code) {
     switch (code) {
@@ -164,6 +230,19 @@ const char* dmcf_error_string(int code) {
 }
 
 int dmcf_last_hip_error(void) { return dmcf::g_last_hip_error; }
+
+size_t dmcf_points_aabb_workspace_bytes(void) { return (size_t)dmcf::kAabbBlocks * 8 * sizeof(float); }
+
+int dmcf_points_aabb(const float* points, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                     dmcf_stream_t stream) {
+    if (n < 0 || !out || (n > 0 && !points)) return DMCF_EINVAL;
+    if (!workspace || workspace_bytes < dmcf_points_aabb_workspace_bytes()) return DMCF_EWORKSPACE;
+    const int64_t want = (n + 1023) / 1024;  // >= 4 points per thread
+    const int nb = (int)(want < 1 ? 1 : (want > dmcf::kAabbBlocks ? dmcf::kAabbBlocks : want));
+    hipLaunchKernelGGL(dmcf::aabb_partial, dim3(nb), dim3(256), 0, (hipStream_t)stream, points, n, (float*)workspace);
+    hipLaunchKernelGGL(dmcf::aabb_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, (const float*)workspace, nb, out);
+    return dmcf::check_launch();
+}
 
 int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
                               dmcf_stream_t stream) {

@@ -720,6 +720,20 @@ def continuous_conv(filters, out_positions, extents, offset, inp_positions, inp_
                          coordinate_mapping=coordinate_mapping, interpolation=interpolation, normalize=normalize)
 
 
+def points_aabb(points):
+    """(min, max) over axis 0 of [n, 3] float32 points, two [3] device tensors: the fluid bounds of the boundary crop
+    (models/pbf_model.py:330-336) in two small launches (a torch reduction over the strided columns was 0.2 ms + a transpose)."""
+    L = _lib.lib()
+    points = _dev_f32(points, "points")
+    if points.dim() != 2 or points.shape[1] != 3:
+        raise ValueError("points must be [n, 3]")
+    out = torch.empty(6, dtype=torch.float32, device=points.device)
+    wsb = int(L.dmcf_points_aabb_workspace_bytes())
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=points.device)
+    _lib.check(L.dmcf_points_aabb(_ptr(points), points.shape[0], _ptr(out), _ptr(ws), wsb, _stream()), "dmcf_points_aabb")
+    return out[:3], out[3:]
+
+
 def reduce_subarrays_sum(values, row_splits):
     """Mirror of ``o3dml.ops.reduce_subarrays_sum`` (models/pbf_model.py:450-453)."""
     L = _lib.lib()

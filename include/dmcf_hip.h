@@ -14,6 +14,8 @@
  *   ml3d.ops.continuous_conv (utils/convolutions.py:414-431)     dmcf_cconv_forward
  *   ASCC: mirror :410-412 + second continuous_conv :433-458      dmcf_cconv_forward(DMCF_FLAG_SYMMETRIC)
  *   o3dml.ops.reduce_subarrays_sum (models/pbf_model.py:450-453) dmcf_reduce_subarrays_sum
+ *   tf.reduce_min / reduce_max of the positions                  dmcf_points_aabb
+ *     (models/pbf_model.py:330-336)
  *   farthest_point_sample / gather_point (utils/tools/sampling.cu) dmcf_farthest_point_sample / dmcf_gather_point
  *   grid_pos: candidate cells + tf.unique + decode               dmcf_grid_pos_bounds / _count / _write
  *     (utils/tools/losses.py:136-181, called from :266-272)
@@ -279,6 +281,15 @@ int dmcf_lattice_conv_forward_batch(const dmcf_lattice_conv_args* parts, int32_t
  * ---------------------------------------------------------------------------------------------- */
 int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
                               dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * The fluid's axis-aligned bounding box, tf.reduce_min / reduce_max(pos, axis=0) of the boundary crop every step begins with
+ * (models/pbf_model.py:330-336): out[0..2] = min x, y, z, out[3..5] = max.  n == 0: +inf / -inf.  A NaN coordinate makes both
+ * bounds of its axis NaN, as the reference's reductions do.  Workspace: dmcf_points_aabb_workspace_bytes() bytes.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dmcf_points_aabb_workspace_bytes(void);
+int dmcf_points_aabb(const float* points, int64_t n, float* out, void* workspace, size_t workspace_bytes,
+                     dmcf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * grid_pos(pos, voxel_size, centralize, pad, hyst) (utils/tools/losses.py:136-181; the coarse point sets of the

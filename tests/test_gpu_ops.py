@@ -308,6 +308,25 @@ def test_reduce_subarrays_sum(oracle, dev):
     np.testing.assert_allclose(y, oracle.reduce_subarrays_sum(v, rs), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("n", [0, 1, 255, 4097, 1_200_003])
+def test_points_aabb_equals_the_column_reductions(dev, n):
+    """dmcf_points_aabb = reduce_min / reduce_max over axis 0 (models/pbf_model.py:330-336), bit for bit, NaNs included."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(n)
+    p = (rng.normal(size=(n, 3)) * [1.0, 50.0, 1e-3] + [0.0, -7.0, 3.0]).astype(np.float32)
+    mn, mx = ops.points_aabb(_t(p, dev))
+    if n == 0:
+        assert np.all(mn.cpu().numpy() == np.inf) and np.all(mx.cpu().numpy() == -np.inf)
+        return
+    np.testing.assert_array_equal(mn.cpu().numpy(), p.min(axis=0))
+    np.testing.assert_array_equal(mx.cpu().numpy(), p.max(axis=0))
+    if n > 3:
+        p[n // 2, 1] = np.nan
+        mn, mx = ops.points_aabb(_t(p, dev))
+        assert np.isnan(mn[1].item()) and np.isnan(mx[1].item())
+        np.testing.assert_array_equal(mn.cpu().numpy()[[0, 2]], p.min(axis=0)[[0, 2]])
+
+
 def test_scale_properties_200k(oracle, dev):
     """Size-independent properties at a size the oracle would not finish quickly:
     row counts symmetric (j in N(i) <=> i in N(j)), ASCC momentum conservation, CConv linearity."""
