@@ -85,7 +85,7 @@ SYMBOLS = [
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_kernel_name",
     "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
     "dmcf_lattice_conv_batch_workspace_bytes", "dmcf_lattice_conv_forward_batch",
-    "dmcf_reduce_subarrays_sum", "dmcf_points_aabb_workspace_bytes", "dmcf_points_aabb",
+    "dmcf_reduce_subarrays_sum", "dmcf_points_aabb_workspace_bytes", "dmcf_points_aabb", "dmcf_dense_forward",
     "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
     "dmcf_grid_pos_workspace_bytes", "dmcf_grid_pos_bounds", "dmcf_grid_pos_count", "dmcf_grid_pos_write",
 ]
@@ -145,6 +145,9 @@ def lib():
     L.dmcf_lattice_conv_batch_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32]
     L.dmcf_lattice_conv_forward_batch.restype = c.c_int
     L.dmcf_lattice_conv_forward_batch.argtypes = [c.POINTER(LatticeConvArgs), c.c_int32, c.c_void_p, c.c_size_t, c.c_void_p]
+    L.dmcf_dense_forward.restype = c.c_int
+    L.dmcf_dense_forward.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p,
+                                     c.c_void_p]
     L.dmcf_points_aabb_workspace_bytes.restype = c.c_size_t
     L.dmcf_points_aabb_workspace_bytes.argtypes = []
     L.dmcf_points_aabb.restype = c.c_int

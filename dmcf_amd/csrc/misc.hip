@@ -128,6 +128,71 @@ int scan_counts_to_row_splits(const int32_t* counts, int64_t* row_splits, int64_
 // one wave per row for long rows would be overkill here: rows are neighbour lists (tens to a few
 // thousand entries) and the op runs once per step (models/pbf_model.py:450-453); a 16-lane group per
 // row keeps the loads coalesced inside a row.
+// out = x W (+ bias) (+ residual) for the networks' Dense layers (dmcf_dense_forward): n ~ 1e6 rows, k and m of a few tens --
+// 430 MB of rows for 2 GFLOP, memory bound; the library GEMMs took 120 - 240 us for these tall-skinny products.  A wavefront
+// keeps the whole filter as B fragments of v_mfma_f32_16x16x4_f32 in registers (k / 4 x NT of them) and walks tiles of 16 rows:
+// lane (r, q) loads x[row r][16 j + 4 q ..] in 16-byte pieces (64 contiguous bytes per row and instruction), the products of
+// piece (j, i) pair x[.][16 j + 4 q + i] with W[16 j + 4 q + i][.] -- any bijection of the k index serves, this one makes the
+// loads wide.  (One row per thread with the filter in scalar registers was tried first: every load instruction of a wave then
+// touches 64 cache lines for 16 bytes each, 230 us for 32 -> 32.)  Fixed order of additions: deterministic.
+typedef float dense_f32x4 __attribute__((ext_vector_type(4)));
+template <int NT>
+__global__ __launch_bounds__(256) void dense_rows(const float* __restrict__ x, int64_t n, int k, const float* __restrict__ W, int m,
+                                                  const float* __restrict__ bias, const float* __restrict__ residual,
+                                                  float* __restrict__ out, int64_t ntiles) {
+    const int lane = lane_id(), r = lane & 15, q = lane >> 4;
+    const int kj = (k + 15) >> 4;
+    float wf[4][4][NT];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int kk = 16 * j + 4 * q + i, col = 16 * t + r;
+                wf[j][i][t] = (kk < k && col < m) ? W[(size_t)kk * m + col] : 0.0f;
+            }
+    float bs[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bs[t] = (bias && 16 * t + r < m) ? bias[16 * t + r] : 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = (int64_t)gridDim.x * 4;
+    for (int64_t tile = wave; tile < ntiles; tile += nwaves) {
+        const int64_t row = tile * 16 + r;
+        dense_f32x4 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = (dense_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+            if (j < kj && row < n && 16 * j + 4 * q < k) a[j] = *(const dense_f32x4*)(x + row * k + 16 * j + 4 * q);
+        }
+        dense_f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (dense_f32x4){0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < kj) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j][i], wf[j][i][t], acc[t], 0, 0, 0);
+            }
+        }
+        // D layout: lane (r, q) holds rows 4 q + rr, column 16 t + r
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int64_t orow = tile * 16 + 4 * q + rr;
+            if (orow >= n) continue;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int col = 16 * t + r;
+                if (col >= m) continue;
+                float v = acc[t][rr] + bs[t];
+                if (residual) v += residual[orow * m + col];
+                out[orow * m + col] = v;
+            }
+        }
+    }
+}
+
 // Axis-aligned bounding box of [n, 3] points (dmcf_points_aabb): per-block extrema without atomics, then one wavefront over
 // the blocks.  A NaN coordinate makes both bounds of its axis NaN (what torch.aminmax / tf.reduce_min return).
 constexpr int kAabbBlocks = 1024;
@@ -230,6 +295,26 @@ const char* dmcf_error_string(int code) {
 }
 
 int dmcf_last_hip_error(void) { return dmcf::g_last_hip_error; }
+
+int dmcf_dense_forward(const float* x, int64_t n, int32_t k, const float* W, int32_t m, const float* bias,
+                       const float* residual, float* out, dmcf_stream_t stream) {
+    if (n < 0 || k <= 0 || m <= 0 || (n > 0 && (!x || !W || !out))) return DMCF_EINVAL;
+    if ((k & 3) || k > 64 || m > 64) return DMCF_EUNSUPPORTED;
+    if ((uintptr_t)x & 15) return DMCF_EUNSUPPORTED;
+    if (n == 0) return DMCF_OK;
+    const int64_t ntiles = (n + 15) / 16;
+    const int64_t want = (ntiles + 3) / 4;
+    const unsigned grid = (unsigned)(want < 2048 ? want : 2048);  // eight waves per SIMD of 256 CUs; each keeps the filter
+    const int nt = (m + 15) / 16;
+#define DMCF_DENSE(NTT)                                                                                                   \
+    hipLaunchKernelGGL(dmcf::dense_rows<NTT>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, n, (int)k, W, (int)m, bias,  \
+                       residual, out, ntiles)
+    if (nt <= 1) DMCF_DENSE(1);
+    else if (nt == 2) DMCF_DENSE(2);
+    else DMCF_DENSE(4);
+#undef DMCF_DENSE
+    return dmcf::check_launch();
+}
 
 size_t dmcf_points_aabb_workspace_bytes(void) { return (size_t)dmcf::kAabbBlocks * 8 * sizeof(float); }
 

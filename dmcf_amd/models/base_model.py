@@ -1,12 +1,13 @@
 """BaseModel -- mirror of the reference's ``models/base_model.py:10-107``: the five-stage ``call``."""
 import torch
 
+from .. import ops
 from ..utils.config import Config
 
 
 class Dense(torch.nn.Module):
     """tf.keras.layers.Dense(units, activation=None): lazily built ``kernel`` [in, units] (glorot
-    uniform) and ``bias`` [units] (zeros); a plain library GEMM (rocBLAS through torch)."""
+    uniform) and ``bias`` [units] (zeros); dmcf_dense_forward for the shapes it takes (a row per thread), else torch's GEMM."""
 
     def __init__(self, units, name=None, activation=None, use_bias=True):
         super().__init__()
@@ -28,6 +29,8 @@ class Dense(torch.nn.Module):
     def forward(self, x):
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
+        if ops.dense_supported(x, self.kernel):
+            return ops.dense_forward(x, self.kernel, self.bias)
         if self.bias is not None:
             return torch.addmm(self.bias, x, self.kernel)
         return x @ self.kernel
@@ -38,6 +41,8 @@ class Dense(torch.nn.Module):
         (models/hrnet.py); the bias rides on the first convolution that accumulates into the result."""
         if self.kernel is None:
             self.build(x.shape[-1], x.device)
+        if ops.dense_supported(x, self.kernel):
+            return ops.dense_forward(x, self.kernel, None, residual)
         if residual is not None:
             return torch.addmm(residual, x, self.kernel)
         return x @ self.kernel

@@ -720,6 +720,28 @@ def continuous_conv(filters, out_positions, extents, offset, inp_positions, inp_
                          coordinate_mapping=coordinate_mapping, interpolation=interpolation, normalize=normalize)
 
 
+def dense_supported(x, kernel):
+    """Does :func:`dense_forward` take this product (else the caller keeps torch's GEMM)?"""
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous() and x.shape[1] % 4 == 0
+            and 0 < x.shape[1] <= 64 and 0 < kernel.shape[1] <= 64 and x.data_ptr() % 16 == 0)
+
+
+def dense_forward(x, kernel, bias=None, residual=None):
+    """``x @ kernel (+ bias) (+ residual)``: the networks' Dense layers on a million rows (dmcf_dense_forward)."""
+    L = _lib.lib()
+    n, k = x.shape
+    m = kernel.shape[1]
+    kernel = _dev_f32(kernel, "kernel")
+    out = torch.empty(n, m, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        residual = _dev_f32(residual, "residual")
+        if tuple(residual.shape) != (n, m):
+            raise ValueError("residual must be [n, m]")
+    _lib.check(L.dmcf_dense_forward(_ptr(x), n, k, _ptr(kernel), m, _ptr(bias) if bias is not None else None,
+                                    _ptr(residual) if residual is not None else None, _ptr(out), _stream()), "dmcf_dense_forward")
+    return out
+
+
 def points_aabb(points):
     """(min, max) over axis 0 of [n, 3] float32 points, two [3] device tensors: the fluid bounds of the boundary crop
     (models/pbf_model.py:330-336) in two small launches (a torch reduction over the strided columns was 0.2 ms + a transpose)."""

@@ -14,6 +14,8 @@
  *   ml3d.ops.continuous_conv (utils/convolutions.py:414-431)     dmcf_cconv_forward
  *   ASCC: mirror :410-412 + second continuous_conv :433-458      dmcf_cconv_forward(DMCF_FLAG_SYMMETRIC)
  *   o3dml.ops.reduce_subarrays_sum (models/pbf_model.py:450-453) dmcf_reduce_subarrays_sum
+ *   tf.keras.layers.Dense (models/hrnet.py:49,93-99;             dmcf_dense_forward
+ *     models/pbf_model.py:134-152)
  *   tf.reduce_min / reduce_max of the positions                  dmcf_points_aabb
  *     (models/pbf_model.py:330-336)
  *   farthest_point_sample / gather_point (utils/tools/sampling.cu) dmcf_farthest_point_sample / dmcf_gather_point
@@ -281,6 +283,16 @@ int dmcf_lattice_conv_forward_batch(const dmcf_lattice_conv_args* parts, int32_t
  * ---------------------------------------------------------------------------------------------- */
 int dmcf_reduce_subarrays_sum(const float* values, const int64_t* row_splits, int64_t n_rows, float* out,
                               dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * tf.keras.layers.Dense of the networks (models/pbf_model.py:134-152 fluid_dense / obs_dense, models/hrnet.py:49 the
+ * same-scale branch :93-99, models/cconv.py:44):  out[n, m] = x[n, k] W[k, m] (+ bias[m]) (+ residual[n, m]) -- a million rows,
+ * a few tens of columns: a wavefront keeps the filter as matrix-instruction fragments and walks 16-row tiles.  k a multiple of 4
+ * up to 64, m up to 64, x 16-byte aligned; anything else: DMCF_EUNSUPPORTED (the caller keeps its library GEMM).  out may not
+ * alias x; it may be the residual.
+ * ---------------------------------------------------------------------------------------------- */
+int dmcf_dense_forward(const float* x, int64_t n, int32_t k, const float* W, int32_t m, const float* bias,
+                       const float* residual, float* out, dmcf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * The fluid's axis-aligned bounding box, tf.reduce_min / reduce_max(pos, axis=0) of the boundary crop every step begins with

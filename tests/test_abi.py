@@ -45,6 +45,7 @@ def test_workspace_queries_and_host_validation(hip_lib):
     assert hip_lib.dmcf_frs_build(None, 10, 0.1, None, 0, None) == -1  # null workspace -> DMCF_EINVAL
     assert hip_lib.dmcf_reduce_subarrays_sum(None, None, -1, None, None) == -1
     assert hip_lib.dmcf_points_aabb_workspace_bytes() >= 6 * 4
+    assert hip_lib.dmcf_dense_forward(None, 10, 8, None, 16, None, None, None, None) == -1  # null operands -> DMCF_EINVAL
     assert hip_lib.dmcf_points_aabb(None, 10, None, None, 0, None) == -1  # no output -> DMCF_EINVAL
     from dmcf_amd._lib import CconvArgs
     a = CconvArgs()

@@ -308,6 +308,30 @@ def test_reduce_subarrays_sum(oracle, dev):
     np.testing.assert_allclose(y, oracle.reduce_subarrays_sum(v, rs), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("k,m", [(4, 8), (8, 16), (16, 32), (24, 16), (32, 32), (64, 64), (12, 4), (32, 3), (20, 40)])
+def test_dense_forward_against_float64(dev, k, m):
+    """dmcf_dense_forward = x W + bias + residual (tf.keras.layers.Dense + the identity branch, models/hrnet.py:93-99), a fixed
+    order of additions: within float32 rounding of the float64 product; rows 0, 1 and a ragged last block."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(k * 100 + m)
+    for n in (0, 1, 1000, 70001):
+        x = rng.normal(size=(n, k)).astype(np.float32)
+        W = rng.normal(size=(k, m)).astype(np.float32)
+        b = rng.normal(size=(m,)).astype(np.float32)
+        r = rng.normal(size=(n, m)).astype(np.float32)
+        assert ops.dense_supported(_t(x, dev), _t(W, dev))
+        ref = x.astype(np.float64) @ W.astype(np.float64)
+        y = ops.dense_forward(_t(x, dev), _t(W, dev)).cpu().numpy()
+        yb = ops.dense_forward(_t(x, dev), _t(W, dev), _t(b, dev), _t(r, dev)).cpu().numpy()
+        assert y.shape == (n, m)
+        if n:
+            scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64)
+            assert (np.abs(y - ref) <= 4e-7 * scale + 1e-30).all()
+            assert (np.abs(yb - (ref + b + r)) <= 4e-7 * (scale + np.abs(b) + np.abs(r)) + 1e-30).all()
+    assert not ops.dense_supported(_t(np.zeros((5, 6), np.float32), dev), _t(np.zeros((6, 8), np.float32), dev))
+    assert not ops.dense_supported(_t(np.zeros((5, 8), np.float32), dev), _t(np.zeros((8, 80), np.float32), dev))
+
+
 @pytest.mark.parametrize("n", [0, 1, 255, 4097, 1_200_003])
 def test_points_aabb_equals_the_column_reductions(dev, n):
     """dmcf_points_aabb = reduce_min / reduce_max over axis 0 (models/pbf_model.py:330-336), bit for bit, NaNs included."""
