@@ -218,7 +218,7 @@ __device__ __forceinline__ int cell_coord(float x, float origin, float inv, int 
 __global__ __launch_bounds__(256) void frs_count_cells(const float* __restrict__ pts, int64_t n,
                                                        const FrsHeader* __restrict__ h,
                                                        int32_t* __restrict__ point_cell,
-                                                       uint32_t* __restrict__ cell_count) {
+                                                       uint32_t* __restrict__ cell_count, uint32_t* __restrict__ slot_of) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     int c[3];
@@ -229,17 +229,16 @@ __global__ __launch_bounds__(256) void frs_count_cells(const float* __restrict__
     }
     const int32_t cell = (c[2] * h->dims[1] + c[1]) * h->dims[0] + c[0];
     point_cell[i] = cell;
-    atomicAdd(&cell_count[cell], 1u);
+    // (the counter's old value is the point's place among its cell's members: the scatter needs no second round of atomics)
+    slot_of[i] = atomicAdd(&cell_count[cell], 1u);
 }
 
 __global__ __launch_bounds__(256) void frs_scatter(int64_t n, const int32_t* __restrict__ point_cell,
                                                    const uint32_t* __restrict__ cell_start,
-                                                   uint32_t* __restrict__ cell_fill, int32_t* __restrict__ tmp_idx) {
+                                                   const uint32_t* __restrict__ slot_of, int32_t* __restrict__ tmp_idx) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int32_t cell = point_cell[i];
-    const uint32_t slot = cell_start[cell] + atomicAdd(&cell_fill[cell], 1u);
-    tmp_idx[slot] = (int32_t)i;
+    tmp_idx[cell_start[point_cell[i]] + slot_of[i]] = (int32_t)i;
 }
 
 // the atomic scatter leaves each cell's members in arbitrary order; rank every point inside its cell
@@ -682,11 +681,12 @@ int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace
         hipLaunchKernelGGL(frs_bbox, dim3(g < 512u ? g : 512u), dim3(256), 0, stream, points, n, h);
     }
     hipLaunchKernelGGL(frs_finish_header, dim3(1), dim3(64), 0, stream, h, L.table);
-    // cell_fill doubles as the histogram: count -> scan into cell_start -> clear -> scatter cursors
+    // cell_fill is the histogram: count (each point keeps the counter's old value) -> scan into cell_start -> scatter
     if (hipMemsetAsync(cell_fill, 0, (size_t)(L.table + 1) * 4, stream) != hipSuccess) return DMCF_ELAUNCH;
     if (n > 0) {
         const unsigned g = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(frs_count_cells, dim3(g), dim3(256), 0, stream, points, n, h, point_cell, cell_fill);
+        // (the places inside the cells wait in the sorted array's memory, which is written last)
+        hipLaunchKernelGGL(frs_count_cells, dim3(g), dim3(256), 0, stream, points, n, h, point_cell, cell_fill, (uint32_t*)sorted);
     }
     // the scan scratch sits after the (query-count dependent) counts array; during the build nothing
     // else lives there, so use the tail of the workspace the caller actually gave us
@@ -694,10 +694,9 @@ int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace
     if (workspace_bytes < L.off_counts + scan_need) return DMCF_EWORKSPACE;
     int rc = scan_exclusive_u32(cell_fill, cell_start, L.table + 1, ws + workspace_bytes - scan_need, scan_need, stream);
     if (rc != DMCF_OK) return rc;
-    if (hipMemsetAsync(cell_fill, 0, (size_t)(L.table + 1) * 4, stream) != hipSuccess) return DMCF_ELAUNCH;
     if (n > 0) {
         const unsigned g = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(frs_scatter, dim3(g), dim3(256), 0, stream, n, point_cell, cell_start, cell_fill, tmp_idx);
+        hipLaunchKernelGGL(frs_scatter, dim3(g), dim3(256), 0, stream, n, point_cell, cell_start, (const uint32_t*)sorted, tmp_idx);
         hipLaunchKernelGGL(frs_rank_and_place, dim3(g), dim3(256), 0, stream, points, n, point_cell, cell_start,
                            tmp_idx, sorted);
     }
