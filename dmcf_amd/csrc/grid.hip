@@ -183,17 +183,25 @@ __global__ __launch_bounds__(256) void grid_pass(const GridParams p, const GridH
                                                  const int64_t* __restrict__ row_off, float* __restrict__ out,
                                                  int64_t out_capacity, int64_t table_cells) {
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (row >= 2 * p.n) return;
+    const bool live = row < 2 * p.n;
     const bool second = row >= p.n;
-    const int64_t i = second ? row - p.n : row;
-    int c0[3], c1[3];
-    const bool diff = grid_bases(p, h, i, c0, c1);
-    if (second && !diff) {
-        if (MODE == 1) counts[row] = 0;
-        return;
-    }
+    const int64_t i = live ? (second ? row - p.n : row) : 0;
+    int c0[3] = {0, 0, 0}, c1[3] = {0, 0, 0};
+    const bool diff = p.n > 0 && grid_bases(p, h, i, c0, c1);
     const int* c = second ? c1 : c0;
     const int64_t d0 = h->dims[0], d01 = d0 * h->dims[1];
+    const bool active = live && (!second || diff);
+    if (MODE == 0) {
+        // A row whose base cell equals that of the row in the lane below proposes the same cells with larger ranks: it can win
+        // none of them.  Particles mostly arrive in spatial order (neighbours in the array share a voxel), so this removes
+        // about half of the atomics -- the same-address ones, which serialise in L2.
+        const int64_t key = active ? c[0] + c[1] * d0 + c[2] * d01 : -1 - (int64_t)(threadIdx.x & 63);
+        const int64_t below = __shfl_up(key, 1, 64);
+        if (!active || ((threadIdx.x & 63) != 0 && below == key)) return;
+    } else if (!active) {
+        if (MODE == 1 && live) counts[row] = 0;
+        return;
+    }
     const int noff = p.len[0] * p.len[1] * p.len[2];
     const uint32_t k0 = (uint32_t)row * (uint32_t)noff;
     int cnt = 0;
