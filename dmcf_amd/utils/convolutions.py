@@ -35,10 +35,13 @@ class _NeighborCache:
 
     def __init__(self):
         self.depth = 0
-        # pair-count estimates from the previous step, by position in the step's sequence of distinct searches:
-        # with them a step enqueues all its searches without a single host round trip (see search())
-        self.hints = []
-        self.caps = {}  # slot -> entries of the padded buffers of the previous step (kept while they still fit)
+        # longest-row estimates from the previous step, by WHAT the search is (radius, size class of both point sets, its
+        # flags -- _hint_key): with them a step enqueues all its searches without a single host round trip (see search()).
+        # (Keyed by the position in the step's sequence of searches through round 3: when a layer between two lattices fell
+        # back to a neighbour list in the middle of a rollout, every later search took its neighbour's estimate -- a 35-entry
+        # stride for a 286-entry list -- and the step was repeated.)
+        self.hints = {}
+        self.caps = {}  # same keys -> entries of the padded buffers of the previous step (kept while they still fit)
         # consumers per list: learnt in one step, used in the next to hand a list's buffers back to the allocator as soon
         # as its last consumer has enqueued its kernel (12 lists of 2.4 - 3.4 GB each at 1M particles; all of them alive
         # until the end of the step was 160 GB at 4M particles and sent the caching allocator into free / malloc cycles)
@@ -62,7 +65,7 @@ class _NeighborCache:
         self.states[self.key] = (self.hints, self.caps, self.expect)
         while len(self.states) > 16:  # a handful of (model, scene) rollouts at a time
             self.states.pop(next(iter(self.states)))
-        self.hints, self.caps, self.expect = self.states.pop(key, ([], {}, {}))
+        self.hints, self.caps, self.expect = self.states.pop(key, ({}, {}, {}))
         self.key = key
 
     def __enter__(self):
@@ -98,12 +101,12 @@ class _NeighborCache:
                     return torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(())
                 maxima = torch.stack([longest(r) for _, r in pending]).tolist()
                 bad = False
-                for (slot, r), mx in zip(pending, maxima):
+                fresh = {}
+                for (hkey, r), mx in zip(pending, maxima):
                     if isinstance(r, ops.PaddedNeighborList):
                         bad |= r.overflowed(mx)
-                    while len(self.hints) <= slot:
-                        self.hints.append(None)
-                    self.hints[slot] = int(mx)
+                    fresh[hkey] = max(fresh.get(hkey, 0), int(mx))  # (searches of one class share the longest of their rows)
+                self.hints.update(fresh)
                 if bad:
                     raise ops.NeighborCapacityExceeded("a neighbour row outgrew its estimated capacity; repeat the step")
         return False
@@ -166,16 +169,17 @@ class _NeighborCache:
             table = ops.build_spatial_hash_table(points, radius, n_queries=max(points.shape[0], queries.shape[0]))
             self.tables[tkey] = table
         slot, self.order = self.order, self.order + 1
-        hint = self.hints[slot] if (self.use_hints and slot < len(self.hints)) else None
+        hkey = _hint_key(frs, points, queries, radius)
+        hint = self.hints.get(hkey) if self.use_hints else None
         if hint is not None:
-            # Padded rows of (longest row of the previous step) * 1.25 + 8 entries: ONE candidate scan per query, no
+            # Padded rows of row_stride(longest row of the previous step) entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
             # stride is detected at the end of the step (one sync) and the step is repeated with the exact search.
-            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(slot))
-            self.caps[slot] = getattr(res, "capacity", None)
+            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(hkey))
+            self.caps[hkey] = getattr(res, "capacity", None)
         else:
             res = frs(points, queries, radius, hash_table=table)
-        self.pending.append((slot, res))
+        self.pending.append((hkey, res))
         self.lists[key] = res
         self.slot_of[key] = slot
         self._consumer(key, res)
@@ -245,15 +249,43 @@ def neighbor_cache(estimate=False, key=None):
     return _CacheScope(estimate, key)
 
 
+def _hint_key(frs, points, queries, radius):
+    """What a search is, for the estimates carried from one step to the next: radius, the size class of both point sets
+    (half powers of two: particle counts drift by a few per cent per step, the lattices' with them) and the search's flags."""
+    def size_class(n):
+        return int(round(2.0 * math.log2(max(int(n), 1))))
+    return (float(radius), size_class(points.shape[0]), size_class(queries.shape[0]), bool(frs.ignore_query_point),
+            bool(frs.return_distances))
+
+
+class _HintView:
+    """The longest-row estimates as a sequence of numbers (tests / diagnostics); ``clear()`` forgets them."""
+
+    def __init__(self, hints):
+        self._hints = hints
+
+    def __iter__(self):
+        return iter(list(self._hints.values()))
+
+    def __len__(self):
+        return len(self._hints)
+
+    def clear(self):
+        self._hints.clear()
+
+
 def neighbor_hints():
-    """The per-slot pair-count estimates of the process-wide cache (tests / diagnostics)."""
-    return _CACHE.hints
+    """The longest-row estimates of the process-wide cache (tests / diagnostics)."""
+    return _HintView(_CACHE.hints)
 
 
 def row_stride(longest):
-    """Row capacity for the padded single-pass search from the longest row of the previous step: 1/4 slack, rounded up
-    to 1/8 of the enclosing power of two (a handful of distinct buffer sizes for the caching allocator)."""
-    x = int(longest) + int(longest) // 4 + 8
+    """Row capacity for the padded single-pass search from the longest row of the previous step: half as much again, and at
+    least 4 x up to 384 entries of slack -- the short-row lists are the cheap ones (a million rows of 200 entries are 0.8 GB)
+    and the ones a stray cluster of particles multiplies from one step to the next (seen in the 1M bench scene: 35 -> 105 and
+    60 -> 257 in one step, each a repeated step) --, rounded up to 1/8 of the enclosing power of two (a handful of distinct
+    buffer sizes for the caching allocator).  Neither the search nor the convolutions touch the unused part of a row."""
+    x = int(longest) + max(int(longest) // 2, min(4 * int(longest), 384)) + 8
     g = max(8, 1 << max(x.bit_length() - 4, 0))  # 1/8 of the enclosing power of two
     return (x + g - 1) // g * g
 
