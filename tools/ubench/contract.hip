@@ -16,9 +16,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int kRow = 1024;
 constexpr int NT = 2;
 
+// bit 6: the kernel reads its arguments from a module-scope device variable (cached memory, address in the code) instead of
+// the kernarg segment
+struct TailArgs {
+    const float* W;
+    float* out;
+    int ntiles;
+    float seed;
+};
+__device__ TailArgs g_args;
+
 template <int WAVES, int VAR>
-__global__ __launch_bounds__(64 * WAVES, 1) void tail(const float* __restrict__ Wp_arg, float* __restrict__ out, int ntiles, float seed) {
-    const float* Wp = Wp_arg;
+__global__ __launch_bounds__(64 * WAVES, 1) void tail(const float* __restrict__ Wp_arg, float* __restrict__ out_arg, int ntiles_arg, float seed_arg) {
+    const float* Wp = (VAR & 64) ? g_args.W : Wp_arg;
+    float* out = (VAR & 64) ? g_args.out : out_arg;
+    const int ntiles = (VAR & 64) ? g_args.ntiles : ntiles_arg;
+    const float seed = (VAR & 64) ? g_args.seed : seed_arg;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool kPersist = VAR & 1, kStationary = VAR & 2, kNoMfma = VAR & 4, kNoLds = VAR & 8, kNoEpi = VAR & 16, kReload = VAR & 32;
     constexpr int kIt = 64 / WAVES;  // blocks of a chunk per wave
@@ -130,6 +143,27 @@ static void run(const float* W, float* out, int ntiles, int ncu, const char* wha
     }
     printf("%2d waves  var %2d  %-60s %6.3f ms  (%5.0f clocks per tile and CU at 2.4 GHz)\n", WAVES, VAR, what, best,
            best * 1e-3 * 2.4e9 / (ntiles / (double)ncu));
+    if (VAR == 0) {  // the same launch as a one-node graph (where do a graph's kernel arguments live?)
+        hipStream_t st;
+        hipStreamCreate(&st);
+        hipGraph_t graph;
+        hipGraphExec_t exec;
+        hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+        hipLaunchKernelGGL((tail<WAVES, VAR>), dim3(grid), dim3(64 * WAVES), lds, st, W, out, ntiles, 0.0f);
+        hipStreamEndCapture(st, &graph);
+        hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        float gbest = 1e9f;
+        for (int rep = 0; rep < 4; ++rep) {
+            hipEventRecord(a, st);
+            hipGraphLaunch(exec, st);
+            hipEventRecord(b, st);
+            hipEventSynchronize(b);
+            float ms;
+            hipEventElapsedTime(&ms, a, b);
+            if (rep && ms < gbest) gbest = ms;
+        }
+        printf("%2d waves  var %2d  %-60s %6.3f ms\n", WAVES, VAR, "  ... launched as a graph node", gbest);
+    }
 }
 
 int main() {
@@ -146,6 +180,12 @@ int main() {
     printf("%d CUs, %d tiles of 16 points, K = 2048, 32 output channels; matrix floor %.3f ms\n", ncu, ntiles,
            ntiles * 1024.0 * 32 / 4 / ncu / 2.4e9 * 1e3);
     run<16, 0>(W, out, ntiles, ncu, "as the product (workgroup per tile, filter per tile)");
+    {
+        TailArgs ha = {W, out, ntiles, 0.0f};
+        hipMemcpyToSymbol(HIP_SYMBOL(g_args), &ha, sizeof(ha));
+    }
+    run<16, 64>(W, out, ntiles, ncu, "workgroup per tile, arguments from a device variable");
+    run<8, 64>(W, out, ntiles, ncu, "8 waves: workgroup per tile, arguments from a device variable");
     run<16, 1>(W, out, ntiles, ncu, "persistent");
     run<16, 33>(W, out, ntiles, ncu, "persistent, arguments fetched again per tile");
     run<16, 2>(W, out, ntiles, ncu, "filter once per workgroup (= per tile here)");
