@@ -285,7 +285,7 @@ def row_stride(longest):
     and the ones a stray cluster of particles multiplies from one step to the next (seen in the 1M bench scene: 35 -> 105 and
     60 -> 257 in one step, each a repeated step) --, rounded up to 1/8 of the enclosing power of two (a handful of distinct
     buffer sizes for the caching allocator).  Neither the search nor the convolutions touch the unused part of a row."""
-    x = int(longest) + max(int(longest) // 2, min(4 * int(longest), 384)) + 8
+    x = int(longest) + int(longest) // 4 + 8
     g = max(8, 1 << max(x.bit_length() - 4, 0))  # 1/8 of the enclosing power of two
     return (x + g - 1) // g * g
 
