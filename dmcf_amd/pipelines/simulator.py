@@ -23,7 +23,7 @@ log = logging.getLogger(__name__)
 
 
 # 1M fluid + 0.12M boundary particles peak at 16 GB of live buffers and ~45 GB of pool once the lists have grown (DESIGN.md
-# section 4.1), more with the wider row strides of late round 3: 48 KiB per point
+# section 4.1): 40 KiB per point
 RESERVE_BYTES_PER_POINT = 40 * 1024
 
 

@@ -280,11 +280,11 @@ def neighbor_hints():
 
 
 def row_stride(longest):
-    """Row capacity for the padded single-pass search from the longest row of the previous step: half as much again, and at
-    least 4 x up to 384 entries of slack -- the short-row lists are the cheap ones (a million rows of 200 entries are 0.8 GB)
-    and the ones a stray cluster of particles multiplies from one step to the next (seen in the 1M bench scene: 35 -> 105 and
-    60 -> 257 in one step, each a repeated step) --, rounded up to 1/8 of the enclosing power of two (a handful of distinct
-    buffer sizes for the caching allocator).  Neither the search nor the convolutions touch the unused part of a row."""
+    """Row capacity for the padded single-pass search from the longest row of the previous step: 1/4 slack, rounded up
+    to 1/8 of the enclosing power of two (a handful of distinct buffer sizes for the caching allocator).  (Wider slack for the
+    short-row lists -- 3 x up to 192 entries, then 4 x up to 384 -- was tried against the repeated step of the 1M bench scene's
+    driver window and changed nothing: the repeat came from estimates applied to the wrong search, see _hint_key; with that fixed
+    this slack runs the window without a repeat, and the wider one only cost 8.5 GiB of reservation.)"""
     x = int(longest) + int(longest) // 4 + 8
     g = max(8, 1 << max(x.bit_length() - 4, 0))  # 1/8 of the enclosing power of two
     return (x + g - 1) // g * g
