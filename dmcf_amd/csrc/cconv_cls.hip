@@ -480,11 +480,15 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
         // the second point's merge and the tile's barrier: their round trip runs under those.  The loop this replaces loaded a
         // block's fragments right before its matrix instructions -- one exposed L2 round trip per block, eight per tile
         // (cconv_z3.hip found the same: ~1500 clocks each with every wave of the workgroup in the same phase).
-        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
         const int nq = (nch + 3) >> 2;
         constexpr int kIt = 64 / kCWaves;                       // blocks of a chunk per wave
         // (fragments + accumulators must fit the compiler's registers; a multi-chunk layer's accumulators live across the walk)
         constexpr int kPre = SINGLE ? (NTT <= 1 ? 8 : (NTT <= 2 ? 4 : 2)) : (NTT <= 1 ? 4 : (NTT <= 2 ? 2 : 1));
+        // (through a buffer resource over the packed filter: the lane's part of a fragment's address is formed once, the block's
+        // and the column tile's part is a scalar offset -- cconv_pair.hip)
+        const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)p.Wp, 0, (int)((uint32_t)p.nchunks * 64u * (uint32_t)p.NT * 1024u), 0x00020000);
+        const uint32_t w_lane = ((uint32_t)mg * (uint32_t)p.NT * 16u + (uint32_t)mi) * 16u;
         auto w_issue = [&](int it0, f32x4 (&bw)[kPre][NTT]) {
 #pragma unroll
             for (int q = 0; q < kPre; ++q) {
@@ -493,13 +497,14 @@ __global__ __launch_bounds__(kCThreads, 4) __attribute__((amdgpu_num_vgpr(kClsCo
                     int tq, tr;
                     blk_divmod(t, nq, tq, tr);
                     const int blk = tq * 4 + tr;
-                    const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+                    const uint32_t w_blk = (uint32_t)(chunk * 64 + blk) * (uint32_t)p.NT * 1024u;
                     // (all-zero filter blocks of a block-diagonal pair of layers: neither fetched nor multiplied)
                     const int wq = 4 * chunk + tr;  // channel quad; the mask holds quads 0 .. 7
                     const uint32_t wm = wq < 8 ? p.wmask >> (4 * wq) : 0xfu;
 #pragma unroll
                     for (int n = 0; n < NTT; ++n)
-                        if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
+                        if (n < p.NT && ((wm >> n) & 1))
+                            bw[q][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, w_lane, w_blk + 256u * (uint32_t)n, 0));
                 }
             }
         };

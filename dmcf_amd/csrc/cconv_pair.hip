@@ -456,9 +456,14 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
     constexpr int kIt = 64 / kPWaves;          // blocks of a chunk per wave: t = wave + 8 it < 16 nq
     constexpr int kPre = NTT <= 2 ? 8 : 4;     // blocks whose filter fragments are requested together (NTT <= 2: a whole chunk)
     auto nq_of = [&](int chunk) { return (min(16, cin - 16 * chunk) + 3) >> 2; };
+    // The fragments come through a buffer resource over the packed filter: the lane's part of the address (its row of the
+    // fragment) is formed once, a block's and a column tile's part is a SCALAR offset -- one memory instruction and two scalar
+    // ones per fragment instead of a 64-bit multiply-add chain per lane (the paired 24 -> 64 layer requests ~36 per tile).
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wp, 0, (int)((uint32_t)p.nchunks * 64u * (uint32_t)p.NT * 1024u), 0x00020000);
+    const uint32_t w_lane = ((uint32_t)mg * (uint32_t)p.NT * 16u + (uint32_t)mi) * 16u;
     auto w_issue = [&](int chunk, int it0, f32x4 (&bw)[kPre][NTT]) {
         const int nq = nq_of(chunk);
-        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const int it = it0 + q;
@@ -467,11 +472,12 @@ __global__ __launch_bounds__(kPThreads, 1) __attribute__((amdgpu_num_vgpr(kPComp
                 int tq, tr;
                 blk_divmod(t, nq, tq, tr);
                 const int blk = tq * 4 + tr;
-                const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+                const uint32_t w_blk = (uint32_t)(chunk * 64 + blk) * (uint32_t)p.NT * 1024u;
                 const uint32_t wm = p.wmask >> (4 * (4 * chunk + tr));  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
-                    if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
+                    if (n < p.NT && ((wm >> n) & 1))
+                        bw[q][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, w_lane, w_blk + 256u * (uint32_t)n, 0));
             }
         }
     };

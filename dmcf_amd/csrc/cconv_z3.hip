@@ -358,9 +358,13 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
     constexpr int kPre = NTT <= 2 ? kIt : 2;   // blocks whose fragments are requested together
     constexpr bool kBoth = NTT <= 2;           // registers for the fragments of both chunks
     auto nq_of = [&](int chunk) { return (min(16, cin - 16 * chunk) + 3) >> 2; };
+    // (through a buffer resource over the packed filter: the lane's part of a fragment's address is formed once, the block's and
+    // the column tile's part is a scalar offset -- cconv_pair.hip)
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.Wp, 0, (int)((uint32_t)p.nchunks * 64u * (uint32_t)p.NT * 1024u), 0x00020000);
+    const uint32_t w_lane = ((uint32_t)mg * (uint32_t)p.NT * 16u + (uint32_t)mi) * 16u;
     auto w_issue = [&](int chunk, int it0, f32x4 (&bw)[kPre][NTT]) {
         const int nq = nq_of(chunk);
-        const float* Wc = p.Wp + (size_t)chunk * 64 * (4 * p.NT * 16 * 4);
 #pragma unroll
         for (int q = 0; q < kPre; ++q) {
             const int it = it0 + q;
@@ -369,11 +373,12 @@ __global__ __launch_bounds__(kZThreads, 1) __attribute__((amdgpu_num_vgpr(kZ3Com
                 int tq, tr;
                 blk_divmod(t, nq, tq, tr);
                 const int blk = tq * 4 + tr;
-                const float* wb = Wc + ((size_t)(blk * 4 + mg) * p.NT * 16 + mi) * 4;
+                const uint32_t w_blk = (uint32_t)(chunk * 64 + blk) * (uint32_t)p.NT * 1024u;
                 const uint32_t wm = p.wmask >> (4 * (4 * chunk + tr));  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
 #pragma unroll
                 for (int n = 0; n < NTT; ++n)
-                    if (n < p.NT && ((wm >> n) & 1)) bw[q][n] = *(const f32x4*)(wb + n * 64);
+                    if (n < p.NT && ((wm >> n) & 1))
+                        bw[q][n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, w_lane, w_blk + 256u * (uint32_t)n, 0));
             }
         }
     };
