@@ -64,7 +64,7 @@ def pmc(src, tag, P):
             if ": pairs" in l:
                 name = l.split()[0]
                 mb[name] = (float(l.split("pairs")[1].split("M")[0]) * 1e6, float(l.split("M")[1].split("ms")[0]))
-    case_of = dict(pair_L4="L4", pair_L3="L3", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC")
+    case_of = dict(pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC")
     lines = [f"# SQ counters of every kernel above 3 % of the 1M step ({tag})\n",
              "`tools/pmc_kernel.sh`: three separate `rocprofv3 --kernel-trace --pmc` passes per kernel (no other trace domain), on the micro-benchmark "
              "case that exercises the kernel (`tools/microbench.py`, 1 + 5 launches; the search: 4 steps of `bench.py`).  Derived per launch: "

@@ -33,7 +33,9 @@ def main():
              ("L7   4->32 s1->s0 R0.2", s1, s0, 0.2, 4, 32, (4, 4, 4), "poly6", False),
              ("LP  12->64 s2->s0 R0.4", grid_pos(s0, np.float32([0.1] * 3), centralize=True), s0, 0.4, 12, 64, (4, 4, 4), "poly6", False),
              ("L4  24->4  s0->s2 R0.4", s0, grid_pos(s0, np.float32([0.1] * 3), centralize=True), 0.4, 24, 4, (4, 4, 4), "poly6", False),
-             ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True)]
+             ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True),
+             # conv200_1 + conv300_1 of Liquid3d as ONE block-diagonal launch (models/hrnet.py, _paired_convs): 8 + 16 channels
+             ("LQ  24->64 s1->s0 R0.2", s1, s0, 0.2, 24, 64, (4, 4, 4), "poly6", False)]
     for name, inp, out, R, cin, cout, ks, win, sym in cases:
         if os.environ.get('ONLY') and not any(name.startswith(o) for o in os.environ['ONLY'].split(',')): continue
         # lists without distances, as the networks use them (the window is evaluated on distances re-formed from the positions: the
@@ -42,9 +44,11 @@ def main():
         nns = ops.fixed_radius_search(inp, out, R, ignore_query_point=sym, return_distances=dist)
         feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
         W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
+        mask = ops.block_diagonal_tile_mask([(0, 8, 0, 32), (8, 24, 32, 64)]) if name.startswith("LQ") else 0
         f = lambda: ops.cconv_forward(W, out, 2 * R, inp, feat, nns.neighbors_index, nns.neighbors_row_splits,
                                       neighbors_value=nns.neighbors_distance if dist else None, window=win, symmetric=sym, sym_axis=1,
-                                      row_length_hint=2 if R > 0.1 else 1)  # (what models/hrnet.py tells the layer)
+                                      row_length_hint=2 if R > 0.1 else 1,  # (what models/hrnet.py tells the layer)
+                                      filter_tile_mask=mask)
         f()
         ms = timed(f)
         P = nns.neighbors_index.shape[0]

@@ -17,6 +17,7 @@ rm -rf $OUT/pmc_traffic/FETCH_SIZE $OUT/pmc_traffic/WRITE_SIZE
 P=$OUT/pmc
 bash tools/pmc_kernel.sh $P pair_L4 cconv_pair -- env DMCF_CCONV_KERNEL=pair ONLY=L4 python tools/microbench.py > $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P pair_L3 cconv_pair -- env DMCF_CCONV_KERNEL=pair ONLY=L3 python tools/microbench.py >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P pair4_LQ cconv_pair -- env ONLY=LQ python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P cls1_L8 cconv_cls -- env ONLY=L8 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P cls2_L5 cconv_cls -- env ONLY=L5 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P cls2n_L6 cconv_cls -- env ONLY=L6 python tools/microbench.py >> $OUT/pmc.txt 2>&1
