@@ -222,3 +222,30 @@ def test_run_pipeline_arguments_and_dataset_group(tmp_path):
         DatasetGroup(name="x", dataset_path=GOLDEN, split="train")
     with pytest.raises(NotImplementedError):
         run_pipeline.main(["-c", str(yml), "--split", "train"])
+
+
+def test_neighbour_list_estimates_are_keyed_by_what_a_search_is():
+    """utils/convolutions.py: the longest-row estimates a step hands to the next belong to a search's CLASS (radius, size class of
+    both point sets, flags), not to its position in the step -- a layer that falls back from the lattice form adds a search
+    in the middle of the sequence and must not shift every later estimate."""
+    import torch
+    from dmcf_amd.utils import convolutions as cv
+
+    class Frs:
+        def __init__(self, ignore=False, dist=True):
+            self.ignore_query_point, self.return_distances = ignore, dist
+
+    def key(n_points, n_queries, radius, **kw):
+        return cv._hint_key(Frs(**kw), torch.empty(n_points, 3), torch.empty(n_queries, 3), radius)
+
+    assert key(1_124_864, 1_157_625, 0.2) == key(1_130_000, 1_150_000, 0.2)  # particle counts drift by a few per cent per step
+    assert key(1_124_864, 1_157_625, 0.2) != key(1_124_864, 1_157_625, 0.4)
+    assert key(1_124_864, 151_686, 0.4) != key(151_686, 1_124_864, 0.4)       # s0 -> s2 is not s2 -> s0
+    assert key(1000, 1000, 0.1, ignore=True) != key(1000, 1000, 0.1) != key(1000, 1000, 0.1, dist=False)
+    assert key(0, 0, 0.1) == key(1, 1, 0.1)                                   # (empty sets have a class too)
+    view = cv._HintView({key(1000, 1000, 0.1): 35, key(1000, 2000, 0.2): 286})
+    assert sorted(view) == [35, 286] and len(view) == 2
+    view.clear()
+    assert list(view) == [] and len(view) == 0
+    assert cv.row_stride(35) >= 35 + 8 and cv.row_stride(35) % 8 == 0 and cv.row_stride(2964) >= 2964 * 5 // 4
+
