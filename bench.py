@@ -24,8 +24,8 @@ Extra objects on the JSON line:
   roofline_groups   the same fraction for (a) all neighbour-list kernels together, (b) the lattice-form launches --
                     charged the bytes THEY move (input volume + per-offset matrices + table + outputs), not the pair
                     bytes of a list they never read --, and per kernel instantiation
-  cpu_baseline      the CPU oracle (numpy + C restatement, OpenMP on all host cores) timed on a bounded sample of the
-                    same workload (a smaller box from the same generator, ~config 4's 100k particles), rank 0, N = 1
+  cpu_baseline      the CPU oracle (numpy + C restatement, OpenMP on all host cores) timed on ONE step of the bench's own
+                    scene ("same inputs"; ~1 minute at 1M particles; --cpu-side bounds it), rank 0, N = 1
 """
 import argparse
 import json
@@ -63,8 +63,9 @@ def frs_algorithmic_bytes(m):
             + 8 * m["n_queries"])
 
 
-def cpu_baseline(side, weights, cfg):
-    """Time ONE step of the CPU oracle (the restated reference path) on a side^3 box from the bench's scene generator."""
+def cpu_baseline(side, weights, cfg, same=False):
+    """Time ONE step of the CPU oracle (the restated reference path) on a side^3 box from the bench's scene generator --
+    ``same``: the very scene the GPU steps (its state before the first step)."""
     import oracle  # noqa: F401  (builds the C library if needed)
     from oracle.model_ref import ModelRef
     from tools import scenes
@@ -77,9 +78,9 @@ def cpu_baseline(side, weights, cfg):
     n = scene["pos"].shape[0]
     return dict(value=n / dt, unit="particle-steps/s", cores=len(os.sched_getaffinity(0)), kind="port",
                 sample=f"1 step of the CPU oracle (oracle/model_ref.py: numpy + OpenMP C restatement of the Open3D CPU "
-                       f"algorithms; not TensorFlow/Open3D) on a {side}^3 = {n}-particle box (+ {scene['box'].shape[0]} "
-                       f"boundary) from the bench's own scene generator, same density and network; {dt:.1f} s, "
-                       f"{ref.pairs} neighbour pairs")
+                       f"algorithms; not TensorFlow/Open3D) on " + ("the bench's own scene, the state before its first step: the " if same else "a bounded sample: a ")
+                       + f"{side}^3 = {n}-particle box (+ {scene['box'].shape[0]} boundary) from the bench's scene generator, same density "
+                       f"and network; {dt:.1f} s, {ref.pairs} neighbour pairs")
 
 
 def scene_snapshot(pos, vel, lo, hi):
@@ -109,7 +110,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)  # the caching allocator reaches its steady state after ~3 steps
     ap.add_argument("--side", type=int, default=100, help="fluid cube edge in particles per GPU (100 -> 1M particles)")
-    ap.add_argument("--cpu-side", type=int, default=46, help="edge of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-side", type=int, default=None,
+                    help="edge of the CPU-baseline box (default: --side, i.e. ONE step of the CPU oracle on the bench's own scene -- "
+                         "about a minute of the host's cores at 1M particles; smaller = a bounded sample from the same generator; 0 = skip)")
     ap.add_argument("--layers-json", default=None, help="write the per-launch table here")
     ap.add_argument("--reserve-gib", type=float, default=None,
                     help="override Simulator(reserve_gib=...) (default: the product's own 'auto' rule, 40 KiB per particle handed "
@@ -386,8 +389,9 @@ def main():
             "kernel_ms_per_step": {k: v / args.steps for k, v in other.items()},
         }
         line.update(extra)
-        if world == 1 and args.cpu_side > 0:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_side, weights, cfg)
+        cpu_side = args.side if args.cpu_side is None else args.cpu_side
+        if world == 1 and cpu_side > 0:
+            line["cpu_baseline"] = cpu_baseline(cpu_side, weights, cfg, same=cpu_side == args.side)
         if args.layers_json:
             json.dump([dict(kind=k, ms=ms, **m) for k, m, ms in recs], open(args.layers_json, "w"))
         print(json.dumps(line), flush=True)

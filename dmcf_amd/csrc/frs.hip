@@ -66,8 +66,8 @@ static FrsLayout frs_layout(int64_t n, int64_t m) {
     const int64_t scan_n = (L.table + 1) > m ? (L.table + 1) : m;
     L.scan_bytes = scan_tmp_bytes(scan_n);
     L.off_scan = off;          off += L.scan_bytes;
-    // one byte per query: "this query may see a point the reference cannot" (DMCF_FRS_OPEN3D_CORNER_VOXELS, see frs_fix); written
-    // and read by the searches on this structure, so one search at a time per structure
+    // one byte per query: "this query may see a point the reference cannot" (open3d visibility flags, see frs_fix); every entry
+    // point writes the bytes it then reads inside ONE call, so searches on a shared structure only need stream order
     L.off_flags = off;         off += align_up((size_t)(m > 0 ? m : 1), 256);
     L.total = off;
     return L;
@@ -283,17 +283,20 @@ __device__ __forceinline__ int wave_inclusive_add(int v) {
     return v;
 }
 
-// ---- what Open3D's search can SEE (DMCF_FRS_OPEN3D_CORNER_VOXELS) ----------------------------------------------------------
+// ---- what Open3D's search can SEE (DMCF_FRS_OPEN3D_VOXEL_WALK, DMCF_FRS_OPEN3D_CORNER_VOXELS) -- opt-in emulations ------------
 // open3d 0.15.2 (FixedRadiusSearchImpl.h, restated in oracle/dmcf_oracle.c) hashes the points into voxels of edge 2 R and, for a
-// query, visits the hash bins of the 8 voxels holding the corners q +- R.  In exact arithmetic those voxels cover the search
-// sphere.  In float they need not: with q a rounding step from the middle of a voxel, floor(fl(q - R) / 2R) and floor(fl(q + R) /
-// 2R) can be TWO apart -- the voxel between them, where the query itself and most of its neighbours live, is then never visited
-// and the reference returns a nearly empty row (seen: one query in 10^6 per search of the 1M-particle rollout; the particle
-// then gets a visibly different correction, tools/diag_degraded.py).  A pair at distance R within rounding can likewise sit in
-// a voxel one step outside the corners.  With the flag set the scan reproduces that visibility: a hit counts only if the
-// point's voxel hashes into one of the query's 8 bins.  Tested where it can matter, at almost no cost elsewhere: every hit of
-// a query whose corner voxels are two apart on some axis, otherwise only hits in the outermost shell of the sphere, where
-// rounding could put the point's voxel outside [corner-, corner+].
+// query, visits the hash bins of its own voxel and of the 8 voxels holding the corners q +- R (round 3
+// read it as the 8 corner voxels alone -- DMCF_FRS_OPEN3D_CORNER_VOXELS keeps that reading).  In exact arithmetic those voxels
+// cover the search sphere, and the DEFAULT search (neither flag) returns exactly that: the set of the distance test.  In float
+// they need not: with q a rounding step from the middle of a voxel, floor(fl(q - R) / 2R) and floor(fl(q + R) / 2R) can be TWO
+// apart -- the voxel between them, where the query itself and most of its neighbours live, is visited only as the query's own
+// voxel (VOXEL_WALK: the row keeps what lies in that one voxel and loses the rest, typically a third of it) or not at all
+// (CORNER_VOXELS: a nearly empty row); one query in ~10^6 per search of the 1M-particle rollout.  A pair at distance R within
+// rounding can likewise sit in a voxel one step outside the corners.  With a flag set the scan reproduces that visibility: a
+// hit counts only if the point's voxel hashes into one of the query's bins.  Tested where it can matter, at almost no cost
+// elsewhere: every hit of a query whose corner voxels are two apart on some axis, otherwise only hits in the outermost shell
+// of the sphere, where rounding could put the point's voxel outside [corner-, corner+].
+constexpr int kO3dFlags = DMCF_FRS_OPEN3D_CORNER_VOXELS | DMCF_FRS_OPEN3D_VOXEL_WALK;
 __device__ __forceinline__ uint64_t o3d_spatial_hash(int x, int y, int z) {
     const uint32_t hsh = ((uint32_t)x * 73856096u) ^ ((uint32_t)y * 193649663u) ^ ((uint32_t)z * 83492791u);
     return (uint64_t)(int64_t)(int32_t)hsh;  // (int arithmetic, converted to size_t: sign extended)
@@ -303,6 +306,7 @@ struct O3dView {
     float q[3];
     float radius, inv_voxel;
     float r2_inner;      // hits with d^2 above this need the exact visibility test (-1: all of them)
+    bool own;            // the query's own voxel is visited too (DMCF_FRS_OPEN3D_VOXEL_WALK)
 };
 
 // voxels of the corners q - R, q + R per axis
@@ -314,8 +318,9 @@ __device__ __forceinline__ void o3d_corners(const O3dView& v, int (&vlo)[3], int
     }
 }
 
-__device__ __forceinline__ O3dView o3d_view(const float (&q)[3], float radius, float r2) {
+__device__ __forceinline__ O3dView o3d_view(const float (&q)[3], float radius, float r2, int flags) {
     O3dView v;
+    v.own = (flags & DMCF_FRS_OPEN3D_VOXEL_WALK) != 0;
     const float voxel = __fmul_rn(2.0f, radius);
     v.inv_voxel = __fdiv_rn(1.0f, voxel);
     v.radius = radius;
@@ -352,10 +357,14 @@ __device__ __forceinline__ bool o3d_visible(float px, float py, float pz, const 
     const int x = (int)floorf(__fmul_rn(px, v.inv_voxel)), y = (int)floorf(__fmul_rn(py, v.inv_voxel)),
               z = (int)floorf(__fmul_rn(pz, v.inv_voxel));
     if ((x == vlo[0] || x == vhi[0]) && (y == vlo[1] || y == vhi[1]) && (z == vlo[2] || z == vhi[2])) return true;
-    // not one of the 8 voxels: still found if its bin is (the FixedRadiusSearch layer's table: n / 64 bins, 1 .. 2^25)
+    const int ox = (int)floorf(__fmul_rn(v.q[0], v.inv_voxel)), oy = (int)floorf(__fmul_rn(v.q[1], v.inv_voxel)),
+              oz = (int)floorf(__fmul_rn(v.q[2], v.inv_voxel));
+    if (v.own && x == ox && y == oy && z == oz) return true;
+    // not one of the visited voxels: still found if its bin is (the FixedRadiusSearch layer's table: n / 64 bins, 1 .. 2^25)
     int64_t size = (int64_t)n_points / 64;
     size = size < 1 ? 1 : (size > 33554432 ? 33554432 : size);
     const uint64_t bin = o3d_spatial_hash(x, y, z) % (uint64_t)size;
+    if (v.own && o3d_spatial_hash(ox, oy, oz) % (uint64_t)size == bin) return true;
     for (int c = 0; c < 8; ++c) {
         const uint64_t cb = o3d_spatial_hash((c & 1) ? vhi[0] : vlo[0], (c & 2) ? vhi[1] : vlo[1], (c & 4) ? vhi[2] : vlo[2]) % (uint64_t)size;
         if (cb == bin) return true;
@@ -366,7 +375,7 @@ __device__ __forceinline__ bool o3d_visible(float px, float py, float pz, const 
 // The candidate scan of one query by one wavefront.  MODE 0: count the hits; MODE 1: write them to the CSR row at
 // out_base; MODE 2: add window(d^2 / R^2) of every hit to `wsum` (per lane; the caller reduces over the wave).
 // Returns the number of hits.  Hits come out in a fixed order (cell rows, then position in the cell-sorted array).
-// EXACT (DMCF_FRS_OPEN3D_CORNER_VOXELS only): every hit that could lie outside the reference's 8 bins takes the exact
+// EXACT (open3d visibility flags only): every hit that could lie outside the reference's 8 bins takes the exact
 // visibility test -- the form of the FIXUP kernel (frs_fix), which re-scans the few queries the hot kernels flag.  !EXACT is the
 // hot form: it only NOTICES such a hit (d^2 above r2_inner: one compare per window) and reports it through `redo`.  The test
 // itself (a 64-bit modulo) stays out of the hot kernels: with it inside they needed 71 instead of 52 registers -- seven
@@ -382,10 +391,11 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
     for (int w = 0; w < kWin; ++w) marks[w * kWave + lane] = 0;  // LDS is not cleared between workgroups: stale tags of an earlier wave must not match ours
     const float q[3] = {qx, qy, qz};
     const float r2 = __fmul_rn(radius, radius);
-    const bool o3d = (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) != 0;
+    const bool o3d = (flags & kO3dFlags) != 0;
     O3dView view;
     view.r2_inner = r2;
-    if (o3d) view = o3d_view(q, radius, r2);
+    view.own = false;
+    if (o3d) view = o3d_view(q, radius, r2, flags);
     int lo[3], hi[3];
     bool empty = h->ncells <= 0 || h->n_points <= 0;
 #pragma unroll
@@ -521,9 +531,10 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
     return cnt;
 }
 
-// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.  qflags (with
-// DMCF_FRS_OPEN3D_CORNER_VOXELS): the count pass marks the queries whose row may hold a point the reference cannot see, the
-// write pass leaves those rows to frs_fix.
+// One wavefront per query.  WRITE=false: counts[q] = number of hits.  WRITE=true: fill the CSR row.  qflags (with an
+// open3d visibility flag): EACH pass marks the queries whose row may hold a point the reference cannot see and leaves them to
+// the frs_fix launch behind it -- the write pass does not rely on the count pass's marks (another search on the same
+// structure may have run in between); it never writes beyond the row's exact length, which the count pass put in row_splits.
 template <bool WRITE>
 __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queries, int64_t m,
                                                  const FrsHeader* __restrict__ h,
@@ -538,15 +549,17 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
     // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
     // row_splits[m] > capacity and repeats the search with exact buffers)
     if (WRITE && row_splits[qi + 1] > capacity) return;
-    const bool o3d = (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) != 0;
-    if (WRITE && o3d && qflags[qi]) return;
+    const bool o3d = (flags & kO3dFlags) != 0;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
     float unused = 0.0f;
     bool redo = false;
+    // (a row the reference sees less of than the distance test holds fewer entries than this scan finds: capped here, rewritten
+    // by frs_fix)
+    const int32_t cap = WRITE && o3d ? (int32_t)(row_splits[qi + 1] - row_splits[qi]) : 0x7fffffff;
     const int32_t cnt = frs_scan<WRITE ? 1 : 0, false>(qx, qy, qz, h, cell_start, sorted, radius, flags, WRITE ? row_splits[qi] : 0,
-                                                       nbr_index, nbr_dist, 0, 0.0f, unused, marks[threadIdx.x >> 6], 0x7fffffff, redo);
-    if (!WRITE && lane_id() == 0) {
-        counts[qi] = cnt;
+                                                       nbr_index, nbr_dist, 0, 0.0f, unused, marks[threadIdx.x >> 6], cap, redo);
+    if (lane_id() == 0) {
+        if (!WRITE) counts[qi] = cnt;
         if (o3d) qflags[qi] = redo ? 1 : 0;
     }
 }
@@ -571,7 +584,7 @@ __global__ __launch_bounds__(256) void frs_query_padded(const float* __restrict_
         row_begin[qi] = qi * stride;
         if (qi == m - 1) row_begin[m] = m * stride;
         row_count[qi] = (int32_t)min((int64_t)cnt, stride);
-        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) qflags[qi] = redo ? 1 : 0;
+        if (flags & kO3dFlags) qflags[qi] = redo ? 1 : 0;
         // same-address atomics serialise (1.1M of them cost ~3 ms per search): only rows that beat the value currently
         // visible try; a stale read merely costs a redundant atomic.  (A flagged row may shrink in frs_fix: its first count
         // still bounds it.)
@@ -597,11 +610,11 @@ __global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ 
     for (int d = 32; d >= 1; d >>= 1) wsum += __shfl_xor(wsum, d, kWave);
     if (lane_id() == 0) {
         out[qi] = wsum;
-        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS) qflags[qi] = redo ? 1 : 0;
+        if (flags & kO3dFlags) qflags[qi] = redo ? 1 : 0;
     }
 }
 
-// The FIXUP of DMCF_FRS_OPEN3D_CORNER_VOXELS: the hot kernels above return the set of the distance test and flag the queries
+// The FIXUP of the open3d visibility flags: the hot kernels above return the set of the distance test and flag the queries
 // whose row holds a hit the reference might not see (one whose voxel could lie outside the 8 corner voxels: the outermost
 // shell of the sphere, or any hit of a query whose corner voxels are two apart).  A small persistent grid walks the flags and
 // scans each flagged query again with the exact test: KIND 0 recounts (counts[q]), 1 writes the CSR row, 2 rewrites the
@@ -649,6 +662,10 @@ __global__ __launch_bounds__(256) void frs_fix(const float* __restrict__ queries
 }  // namespace dmcf
 
 using namespace dmcf;
+
+static bool frs_flags_ok(int flags) {  // known bits, and at most one reading of the reference's walk
+    return (flags & ~(DMCF_FRS_IGNORE_QUERY_POINT | kO3dFlags)) == 0 && (flags & kO3dFlags) != kO3dFlags;
+}
 
 static constexpr unsigned kFixGrid = 1024;  // 4096 waves walk the query flags (frs_fix)
 
@@ -706,6 +723,7 @@ int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace
 int dmcf_frs_count(const float* queries, int64_t m, int64_t n, float radius, int flags, void* workspace,
                    size_t workspace_bytes, int64_t* row_splits, dmcf_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!frs_flags_ok(flags)) return DMCF_EINVAL;
     if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_splits || (m > 0 && !queries)) return DMCF_EINVAL;
     const FrsLayout L = frs_layout(n, m);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
@@ -719,7 +737,7 @@ int dmcf_frs_count(const float* queries, int64_t m, int64_t n, float radius, int
         uint8_t* qflags = (uint8_t*)(ws + L.off_flags);
         hipLaunchKernelGGL((frs_query<false>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted,
                            radius, flags, counts, (const int64_t*)nullptr, (int32_t*)nullptr, (float*)nullptr, (int64_t)0, qflags);
-        if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+        if (flags & kO3dFlags)
             hipLaunchKernelGGL((frs_fix<0>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
                                (const uint8_t*)qflags, counts, (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr, (float*)nullptr,
                                (int64_t)0, 0, (float*)nullptr);
@@ -731,6 +749,7 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
                    size_t workspace_bytes, const int64_t* row_splits, int32_t* neighbors_index,
                    float* neighbors_distance, int64_t pair_capacity, dmcf_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!frs_flags_ok(flags)) return DMCF_EINVAL;
     if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_splits || (m > 0 && !queries)) return DMCF_EINVAL;
     if (m == 0) return DMCF_OK;
     if (!neighbors_index || pair_capacity < 0) return DMCF_EINVAL;
@@ -744,7 +763,7 @@ int dmcf_frs_write(const float* queries, int64_t m, int64_t n, float radius, int
     uint8_t* qflags = (uint8_t*)(ws + L.off_flags);  // (written by the count pass of this search)
     hipLaunchKernelGGL((frs_query<true>), dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius,
                        flags, (int32_t*)nullptr, row_splits, neighbors_index, neighbors_distance, pair_capacity, qflags);
-    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+    if (flags & kO3dFlags)
         hipLaunchKernelGGL((frs_fix<1>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
                            (const uint8_t*)qflags, (int32_t*)nullptr, row_splits, (int64_t)0, neighbors_index, neighbors_distance,
                            pair_capacity, 0, (float*)nullptr);
@@ -755,6 +774,7 @@ int dmcf_frs_search_padded(const float* queries, int64_t m, int64_t n, float rad
                            size_t workspace_bytes, int64_t row_stride, int64_t* row_begin, int32_t* row_count,
                            int32_t* neighbors_index, float* neighbors_distance, int32_t* max_count, dmcf_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!frs_flags_ok(flags)) return DMCF_EINVAL;
     if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || !row_begin || !max_count || (m > 0 && (!queries || !row_count)))
         return DMCF_EINVAL;
     if (row_stride < 0 || (m > 0 && row_stride > 0 && !neighbors_index)) return DMCF_EINVAL;
@@ -769,7 +789,7 @@ int dmcf_frs_search_padded(const float* queries, int64_t m, int64_t n, float rad
     const float4* sorted = (const float4*)(ws + L.off_sorted);
     hipLaunchKernelGGL(frs_query_padded, dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags, row_stride,
                        row_begin, row_count, neighbors_index, neighbors_distance, max_count, qflags);
-    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+    if (flags & kO3dFlags)
         hipLaunchKernelGGL((frs_fix<2>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
                            (const uint8_t*)qflags, row_count, (const int64_t*)nullptr, row_stride, neighbors_index, neighbors_distance,
                            (int64_t)0, 0, (float*)nullptr);
@@ -779,6 +799,7 @@ int dmcf_frs_search_padded(const float* queries, int64_t m, int64_t n, float rad
 int dmcf_frs_window_sum(const float* queries, int64_t m, int64_t n, float radius, int flags, int window,
                         const void* workspace, size_t workspace_bytes, float* out, dmcf_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (!frs_flags_ok(flags)) return DMCF_EINVAL;
     if (m < 0 || n < 0 || !workspace || !(radius > 0.0f) || (m > 0 && (!queries || !out))) return DMCF_EINVAL;
     if (window < DMCF_WINDOW_NONE || window > DMCF_WINDOW_CUBIC_GRAD) return DMCF_EINVAL;
     if (m == 0) return DMCF_OK;
@@ -791,7 +812,7 @@ int dmcf_frs_window_sum(const float* queries, int64_t m, int64_t n, float radius
     const uint32_t* cell_start = (const uint32_t*)(ws + L.off_cell_start);
     const float4* sorted = (const float4*)(ws + L.off_sorted);
     hipLaunchKernelGGL(frs_window_sum, dim3(g), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags, window, out, qflags);
-    if (flags & DMCF_FRS_OPEN3D_CORNER_VOXELS)
+    if (flags & kO3dFlags)
         hipLaunchKernelGGL((frs_fix<3>), dim3(kFixGrid), dim3(256), 0, stream, queries, m, h, cell_start, sorted, radius, flags,
                            (const uint8_t*)qflags, (int32_t*)nullptr, (const int64_t*)nullptr, (int64_t)0, (int32_t*)nullptr,
                            (float*)nullptr, (int64_t)0, window, out);

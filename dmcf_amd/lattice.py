@@ -150,7 +150,11 @@ def lookup(t):
 
 
 def enabled():
-    return os.environ.get("DMCF_LATTICE_CONV", "1") != "0"
+    """The stencil form takes every lattice point within the radius -- the neighbour set of the default search.  Under an
+    emulation of open3d's float walk (ops.search_set() != "distance") the layers keep their neighbour lists, so that a step
+    follows ONE reading of the reference end to end."""
+    from . import ops
+    return os.environ.get("DMCF_LATTICE_CONV", "1") != "0" and ops.search_set() == "distance"
 
 
 class LatticePair:

@@ -309,6 +309,10 @@ class PBFNet(BaseModel):
         # the ghost plans behind the two forms are different collectives)
         if os.environ.get("DMCF_FUSE_INPUT_CONVS", "1") == "0" or _convs._CACHE.depth == 0 or not fluid_feats.is_cuda:
             return None
+        if ops.search_set() != "distance":
+            # an emulation of open3d's hash walk: what a query sees depends on the TABLE of the point set searched (n / 64
+            # bins), so the fluid -> all and boundary -> all lists are not the two halves of the all -> all list
+            return None
         wa, wb = a.window_function, b.window_function
         if a.kernel is None or b.kernel is None:
             return None  # first call: the layers build their weights from the input widths

@@ -290,16 +290,33 @@ def _size_class(x):
     return (x + g - 1) // g * g
 
 
-FRS_IGNORE_QUERY_POINT, FRS_OPEN3D_CORNER_VOXELS = 1, 2
+FRS_IGNORE_QUERY_POINT, FRS_OPEN3D_CORNER_VOXELS, FRS_OPEN3D_VOXEL_WALK = 1, 2, 4
+
+# Which neighbour SET the searches return (include/dmcf_hip.h, DMCF_FRS_*):
+#   "distance"        every point with d^2 <= R^2 -- what open3d's walk over the query's own voxel and the 8 corner voxels of
+#                     q +- R covers in exact arithmetic.  Symmetric lists: the ASCC head conserves
+#                     momentum (models/sym_net.py:42-53).  THE DEFAULT.
+#   "open3d"          that walk as float arithmetic executes it: about one query in 10^6 (a rounding step from the middle of
+#                     a voxel) keeps only what lies in its own voxel; bit-exact against oracle.fixed_radius_search(bins=
+#                     "own+corners"), the oracle's default.
+#   "open3d_corners"  round 3's reading of the library (the 8 corner voxels alone: such a query's row is nearly empty);
+#                     bit-exact against bins="corners".
+# The two emulations exist so that a capture of the real library (tools/capture_golden.py) can be matched bit for bit
+# whichever way it falls; they cost a fixup pass per search and break the lists' symmetry exactly where the library does.
+SEARCH_SETS = {"distance": 0, "open3d": FRS_OPEN3D_VOXEL_WALK, "open3d_corners": FRS_OPEN3D_CORNER_VOXELS}
+
+
+def search_set():
+    """The neighbour set in force: environment variable DMCF_FRS_SET (see SEARCH_SETS), "distance" when unset."""
+    name = os.environ.get("DMCF_FRS_SET", "distance")
+    if name not in SEARCH_SETS:
+        raise ValueError(f"DMCF_FRS_SET={name!r}: expected one of {sorted(SEARCH_SETS)}")
+    return name
 
 
 def frs_flags(ignore_query_point):
-    """Flags of the dmcf_frs_* entry points.  By default the search reproduces what open3d 0.15.2 can SEE (the hash bins of the 8
-    corner voxels of q +- R: include/dmcf_hip.h, DMCF_FRS_OPEN3D_CORNER_VOXELS) -- the reference's neighbour set bit for bit,
-    including the ~1 query in 10^6 whose row the reference leaves nearly empty; DMCF_FRS_BRUTE_FORCE_SET=1 returns the set of
-    the distance test instead."""
-    return ((FRS_IGNORE_QUERY_POINT if ignore_query_point else 0)
-            | (0 if os.environ.get("DMCF_FRS_BRUTE_FORCE_SET") == "1" else FRS_OPEN3D_CORNER_VOXELS))
+    """Flags of the dmcf_frs_* entry points for the neighbour set in force (search_set)."""
+    return (FRS_IGNORE_QUERY_POINT if ignore_query_point else 0) | SEARCH_SETS[search_set()]
 
 
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,

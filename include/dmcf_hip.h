@@ -70,13 +70,21 @@ int dmcf_last_hip_error(void); /* hipError_t of the last failed enqueue on this 
  * here it is deterministic: ascending grid cell (z, y, x), then ascending point index.
  * ---------------------------------------------------------------------------------------------- */
 #define DMCF_FRS_IGNORE_QUERY_POINT 1
-/* Reproduce what open3d 0.15.2 can SEE: it visits the hash bins of the 8 voxels (edge 2 R) holding the corners q +- R, and in
- * float arithmetic those need not cover the sphere -- for about one query in 10^6 (q a rounding step from the middle of a
- * voxel) the two corner voxels of an axis are TWO apart and the reference returns a nearly empty row; a pair at distance R
- * within rounding can sit one voxel outside as well.  With this flag a hit counts only if the point's voxel hashes into one of
- * the query's 8 bins (table of clamp(n_points / 64, 1, 2^25) bins, the layer's default): the reference's set bit for bit
- * (tested against the restatement of its hash search in oracle/).  Without it: the set of the distance test above. */
+/* Opt-in emulations of what open3d 0.15.2's hash walk can SEE in float arithmetic.  The library hashes the points into voxels
+ * of edge 2 R and visits, for a query, the bins of its own voxel and of the 8 voxels holding the corners q +- R (SURVEY.md
+ * section 8 row a1).  In exact arithmetic those voxels cover the search sphere: the set above, which is what the search returns
+ * WITHOUT either flag -- symmetric lists, on which the ASCC layer's momentum conservation rests (models/sym_net.py:42-53).  In
+ * float, for about one query in 10^6 (q a rounding step from the middle of a voxel) the corner voxels of an axis are TWO
+ * apart and the walk misses part of the sphere; a pair at distance R within rounding can sit one voxel outside as well.
+ *   DMCF_FRS_OPEN3D_VOXEL_WALK     a hit counts only if the point's voxel hashes into the bin of the query's own voxel or of
+ *                                  one of the 8 corner voxels (table of clamp(n_points / 64, 1, 2^25) bins, the layer's
+ *                                  default) -- such a query keeps what lies in its own voxel;
+ *   DMCF_FRS_OPEN3D_CORNER_VOXELS  the same with the 8 corner voxels alone (round 3's reading of the library: such a query's
+ *                                  row comes out nearly empty).
+ * Each is bit-exact against the restatement of that walk in oracle/ (dmcf_ref_fixed_radius_search, bin_set); which of the two
+ * the library implements is one of the questions tools/capture_golden.py settles.  At most one of them may be set. */
 #define DMCF_FRS_OPEN3D_CORNER_VOXELS 2
+#define DMCF_FRS_OPEN3D_VOXEL_WALK 4
 
 /* bytes of workspace for a search structure over n_points that will serve up to n_queries queries */
 size_t dmcf_frs_workspace_bytes(int64_t n_points, int64_t n_queries);

@@ -94,8 +94,25 @@ static inline float dist2(const float a[3], const float b[3]) {
     return (dx * dx + dy * dy) + dz * dz;
 }
 
-/* EXT _FixedRadiusSearchCPU: for every query, the bins of the 8 voxels containing the corners
- * q +- radius (deduplicated, visited in ascending bin id), test dist <= threshold with
+/* Which hash bins a query visits.  Two readings of EXT _FixedRadiusSearchCPU exist in this project (neither can be
+ * checked against the library here; tools/capture_golden.py holds the inputs that tell them apart):
+ *   DMCF_REF_BINS_OWN_AND_CORNERS (the DEFAULT): a std::set of bins that first receives the bin
+ *       of the query's OWN voxel, floor(q / 2R), and then the bins of the 8 voxels holding the corners q +- R;
+ *   DMCF_REF_BINS_CORNERS (round 3's reading): the 8 corner voxels only.
+ * In exact arithmetic both are the same set of voxels (the own voxel is one of the corners') and cover the search sphere.
+ * In float they differ from each other and from the sphere for a query a rounding step from the MIDDLE of a voxel on some
+ * axis: floor(fl(q - R) / 2R) and floor(fl(q + R) / 2R) are then two apart.  CORNERS never visits the voxel between them
+ * (the row comes out nearly empty); OWN_AND_CORNERS visits it, but still not the voxels that share the own voxel's
+ * coordinate on that axis and a corner's coordinate on the others (the row loses whatever lies there). */
+#define DMCF_REF_BINS_CORNERS 0
+#define DMCF_REF_BINS_OWN_AND_CORNERS 1
+/* NOT a reading of the library: all 27 voxels around the query's own one, which cover the sphere whatever the rounding --
+ * the set of the distance test (== dmcf_ref_bruteforce_search) at the cost of a hash search.  What the product's default
+ * search returns is checked against this at sizes the O(n m) loop cannot reach. */
+#define DMCF_REF_BINS_ALL_27 2
+
+/* EXT _FixedRadiusSearchCPU: for every query, the bins chosen by `bin_set` (above; deduplicated, visited in ascending
+ * bin id), test dist <= threshold with
  * threshold = radius*radius (L2, inclusive), optional skip of points whose coordinates equal
  * the query's.  Two passes: nbr_index == NULL -> only counts are written to row_splits
  * (as an exclusive prefix sum, int64, length m+1); otherwise indices (+ squared distances).
@@ -103,8 +120,9 @@ static inline float dist2(const float a[3], const float b[3]) {
 int64_t dmcf_ref_fixed_radius_search(const float* points, int64_t n, const float* queries, int64_t m,
                                      float radius, int ignore_query_point, int64_t hash_table_size,
                                      const uint32_t* cell_splits, const uint32_t* index,
-                                     int64_t* row_splits, int32_t* nbr_index, float* nbr_dist) {
+                                     int64_t* row_splits, int32_t* nbr_index, float* nbr_dist, int bin_set) {
     if (n < 0 || m < 0 || hash_table_size < 1 || !(radius > 0.0f)) return DMCF_REF_EINVAL;
+    if (bin_set < DMCF_REF_BINS_CORNERS || bin_set > DMCF_REF_BINS_ALL_27) return DMCF_REF_EINVAL;
     const float voxel_size = 2 * radius;
     const float inv_voxel_size = 1 / voxel_size;
     const float threshold = radius * radius;
@@ -113,9 +131,23 @@ int64_t dmcf_ref_fixed_radius_search(const float* points, int64_t n, const float
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t qi = 0; qi < m; ++qi) {
         const float* q = queries + 3 * qi;
-        uint64_t bins[8];
+        uint64_t bins[27];
         int nbins = 0;
-        for (int dz = -1; dz <= 1; dz += 2)
+        if (bin_set != DMCF_REF_BINS_CORNERS) {
+            int32_t v[3];
+            voxel_index(q, inv_voxel_size, v);
+            bins[nbins++] = spatial_hash(v[0], v[1], v[2]) % (uint64_t)hash_table_size;
+            if (bin_set == DMCF_REF_BINS_ALL_27)
+                for (int dz = -1; dz <= 1; ++dz)
+                    for (int dy = -1; dy <= 1; ++dy)
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            uint64_t h = spatial_hash(v[0] + dx, v[1] + dy, v[2] + dz) % (uint64_t)hash_table_size;
+                            int k = 0;
+                            while (k < nbins && bins[k] != h) ++k;
+                            if (k == nbins) bins[nbins++] = h;
+                        }
+        }
+        for (int dz = -1; dz <= 1 && bin_set != DMCF_REF_BINS_ALL_27; dz += 2)
             for (int dy = -1; dy <= 1; dy += 2)
                 for (int dx = -1; dx <= 1; dx += 2) {
                     float p[3] = {q[0] + radius * (float)dx, q[1] + radius * (float)dy,

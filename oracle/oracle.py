@@ -40,7 +40,7 @@ def lib():
         L.dmcf_ref_fixed_radius_search.restype = c.c_int64
         L.dmcf_ref_fixed_radius_search.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_float,
                                                    c.c_int, c.c_int64, c.c_void_p, c.c_void_p,
-                                                   c.c_void_p, c.c_void_p, c.c_void_p]
+                                                   c.c_void_p, c.c_void_p, c.c_void_p, c.c_int]
         L.dmcf_ref_bruteforce_search.restype = c.c_int64
         L.dmcf_ref_bruteforce_search.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_float,
                                                  c.c_int, c.c_void_p, c.c_void_p, c.c_void_p]
@@ -71,15 +71,43 @@ def _ptr(a):
 # neighbour search -- utils/convolutions.py:207-210 (ctor), :354-358 (call);
 #                     utils/tools/losses.py:296-298 (tuple-unpacked result)
 # ---------------------------------------------------------------------------------------------
+# Which hash bins a query visits (dmcf_oracle.c, DMCF_REF_BINS_*): "own+corners" = the query's own voxel and the 8 corner
+# voxels of q +- R (the default), "corners" = the 8 corner voxels only (round 3's reading),
+# "all" = the 27 voxels around the query: the set of the distance test, not a reading of the library.
+BINS = {"corners": 0, "own+corners": 1, "all": 2}
+_default_bins = "own+corners"
+
+
+class search_bins:
+    """``with oracle.search_bins("corners"): ...`` -- every search of the block (the model restatement's too) walks that
+    bin set."""
+
+    def __init__(self, bins):
+        if bins not in BINS:
+            raise ValueError(f"bins must be one of {sorted(BINS)}")
+        self.bins = bins
+
+    def __enter__(self):
+        global _default_bins
+        self.saved, _default_bins = _default_bins, self.bins
+        return self
+
+    def __exit__(self, *exc):
+        global _default_bins
+        _default_bins = self.saved
+        return False
+
+
 def fixed_radius_search(points, queries, radius, ignore_query_point=False,
-                        hash_table_size_factor=1 / 64, bruteforce=False):
+                        hash_table_size_factor=1 / 64, bruteforce=False, bins=None):
     """-> (neighbors_index int32 [P], neighbors_row_splits int64 [m+1], neighbors_distance f32 [P])
 
     Restates ml3d.layers.FixedRadiusSearch(metric='L2', ignore_query_point, return_distances=True)
     (points, queries, radius): build_spatial_hash_table + fixed_radius_search of Open3D 0.15.2.
     Rows are in the oracle's order (ascending hash bin, then ascending point id); compare rows as
-    sorted sets.  distances are squared L2.
+    sorted sets.  distances are squared L2.  ``bins``: see BINS (None = the current default).
     """
+    bin_set = BINS[_default_bins if bins is None else bins]
     L = lib()
     points = _f32(points).reshape(-1, 3)
     queries = _f32(queries).reshape(-1, 3)
@@ -102,12 +130,12 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False,
     assert err == 0, err
     total = L.dmcf_ref_fixed_radius_search(_ptr(points), n, _ptr(queries), m, radius,
                                            int(ignore_query_point), size, _ptr(splits), _ptr(table),
-                                           _ptr(rs), None, None)
+                                           _ptr(rs), None, None, bin_set)
     assert total >= 0, total
     idx = np.empty(total, dtype=np.int32)
     dist = np.empty(total, dtype=np.float32)
     L.dmcf_ref_fixed_radius_search(_ptr(points), n, _ptr(queries), m, radius, int(ignore_query_point),
-                                   size, _ptr(splits), _ptr(table), _ptr(rs), _ptr(idx), _ptr(dist))
+                                   size, _ptr(splits), _ptr(table), _ptr(rs), _ptr(idx), _ptr(dist), bin_set)
     return idx, rs, dist
 
 

@@ -226,13 +226,177 @@ def test_grid_pos_properties(oracle):
     assert len(g2) < len(g)
 
 
+def _edge_search(oracle, g, case, bins):
+    pre = f"edge_{case}_"
+    return oracle.fixed_radius_search(g[pre + "points"], g[pre + "queries"], float(g[pre + "radius"]), bool(g[pre + "ignore"]),
+                                      hash_table_size_factor=float(g[pre + "factor"]), bins=bins)
+
+
+def _edge_conv(oracle, g, case):
+    pre = f"edge_{case}_"
+    rel, filt = g[pre + "rel"], g[pre + "filt"]
+    n = len(rel)
+    return oracle.continuous_conv(filt, np.zeros((n, 3), np.float32), float(g[pre + "extent"]), rel, np.ones((n, 1), np.float32),
+                                  np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int64), np.ones(n, np.float32))
+
+
+def test_disputed_inputs_discriminate(oracle, tmp_path):
+    """tools/capture_golden.py's disputed inputs (the ones an off-box run on TF 2.5 + Open3D 0.15.2 turns into golden
+    vectors), run through the oracle HERE: every case separates the readings it is meant to separate, so one capture settles
+    them; and the committed manifest is the script's."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tools", "capture_golden.py")
+    man = json.loads(subprocess.run([sys.executable, script, "--manifest"], capture_output=True, text=True, check=True).stdout)
+    with open(os.path.join(root, "tests", "golden", "open3d_golden.manifest.json")) as f:
+        assert json.load(f) == man, "regenerate tests/golden/open3d_golden.manifest.json (tools/capture_golden.py --manifest)"
+    path = str(tmp_path / "inputs.npz")
+    subprocess.run([sys.executable, script, "--inputs-only", path], check=True)
+    g = np.load(path)
+    cases = sorted({k[len("edge_"):].rsplit("_", 1)[0] for k in g.files if k.endswith("_radius") or k.endswith("_rel")})
+    assert all(f"edge_{c}_*" in man["keys"] for c in cases) and len(cases) >= 14
+
+    def rows(case, bins=None, brute=False):
+        pre = f"edge_{case}_"
+        if brute:
+            return np.diff(oracle.fixed_radius_search(g[pre + "points"], g[pre + "queries"], float(g[pre + "radius"]),
+                                                      bool(g[pre + "ignore"]), bruteforce=True)[1])
+        return np.diff(_edge_search(oracle, g, case, bins)[1])
+
+    # (a) voxel midpoints: the two readings of the walk differ from each other and from the sphere, on the same queries
+    for case in ("frs_midpoint", "frs_midpoint_ignore"):
+        full, own, corners = rows(case, brute=True), rows(case, "own+corners"), rows(case, "corners")
+        assert np.array_equal(rows(case, "all"), full)
+        hit, hit_c = own < full, corners < full
+        assert hit.sum() >= 5 and not (hit & ~hit_c).any() and (corners <= own).all() and (corners[hit_c] < own[hit_c]).any()
+    assert rows("frs_midpoint", "own+corners")[120] < rows("frs_midpoint", brute=True)[120]  # z = 1.3, R = 0.1 itself
+    # (b) the radius' edge far from the origin: both walks drop pairs of the sphere, the same ones
+    full, own, corners = rows("frs_radius_edge_far", brute=True), rows("frs_radius_edge_far", "own+corners"), rows("frs_radius_edge_far", "corners")
+    assert 0 < full.sum() - own.sum() < 0.01 * full.sum() and np.all(own <= full)
+    # (c) one bin: nothing can hide; two bins and more: the midpoint rows shrink again
+    for n in (10, 63, 64, 65, 127):
+        assert oracle.lib().dmcf_ref_hash_table_size(n, 1 / 64) == 1
+        for bins in ("own+corners", "corners"):
+            assert np.array_equal(rows(f"frs_table_n{n}", bins), rows(f"frs_table_n{n}", brute=True)), (n, bins)
+    assert oracle.lib().dmcf_ref_hash_table_size(128, 1 / 64) == 2 and oracle.lib().dmcf_ref_hash_table_size(200, 1 / 64) == 3
+    # (with 2 - 3 bins the 8 corner voxels still reach every bin: these cases pin the clamp and the modulo, not the walk)
+    assert rows("frs_table_n200", brute=True).sum() > 300
+    # (d) the cap
+    assert oracle.lib().dmcf_ref_hash_table_size(5000, 1.0e4) == 32 * 2 ** 20
+    assert (rows("frs_table_cap", "own+corners") < rows("frs_table_cap", brute=True)).any()
+    # (e) the map: both branches of both case distinctions are taken, the early-out and the border are reached
+    rel = g["edge_map_444_rel"].astype(np.float64)
+    cone = 1.25 * rel[:, 2] ** 2 - (rel[:, 0] ** 2 + rel[:, 1] ** 2)
+    assert (cone > 0).sum() > 50 and (cone < 0).sum() > 50 and (np.abs(cone) < 1e-7).sum() > 20
+    wedge = np.abs(rel[:, 1]) - np.abs(rel[:, 0])
+    assert (wedge > 0).sum() > 50 and (wedge < 0).sum() > 50
+    sq = (rel ** 2).sum(1)
+    assert ((sq < 1e-12) & (sq > 0)).sum() >= 4 and (sq == 0).sum() >= 1 and ((sq > 1e-12) & (sq < 1e-9)).sum() >= 4
+    coords = oracle.filter_coordinates(g["edge_map_444_rel"], float(g["edge_map_444_extent"]), (4, 4, 4))
+    assert coords.min() < 0.0 and coords.max() > 3.0  # (unclamped coordinates:) the clamp at the filter's border acts on both sides
+    for case in ("map_444", "map_188", "map_666"):
+        y = _edge_conv(oracle, g, case)
+        assert np.isfinite(y).all() and np.abs(y).max() > 0.1
+
+
 def test_against_open3d_golden(oracle):
-    """Pins the oracle to the real library once tools/capture_golden.py has been run off-box."""
+    """Pins the oracle to the real library once tools/capture_golden.py has been run off-box.  EVERY key of the capture is
+    consumed (a key nobody looked at fails the test), every mismatch fails loudly; for the disputed inputs the failure
+    message says which reading of the library the capture supports."""
     import os
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "open3d_golden.npz")
     if not os.path.exists(path):
         pytest.skip("tests/golden/open3d_golden.npz not captured yet (parity unpinned, see DESIGN.md section 2)")
-    g = np.load(path)
+    _check_golden(oracle, path)
+
+
+def _self_made_capture(oracle, path, bins="own+corners", with_cuda=True):
+    """A file with the keys tools/capture_golden.py writes (without --reference), the ORACLE standing in for the library."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inputs = path + ".inputs.npz"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "capture_golden.py"), "--inputs-only", inputs], check=True)
+    out = dict(np.load(inputs))
+    g = dict(out)
+    for case in sorted({k[len("edge_"):].rsplit("_", 1)[0] for k in g if k.endswith("_radius") or k.endswith("_rel")}):
+        for tag in ("cpu", "cuda") if with_cuda else ("cpu",):
+            if case.startswith("map_"):
+                out[f"edge_{case}_out_{tag}"] = _edge_conv(oracle, g, case)
+            else:
+                idx, rs, d = _edge_search(oracle, g, case, bins if tag == "cpu" else "corners")
+                out[f"edge_{case}_index_{tag}"], out[f"edge_{case}_row_splits_{tag}"], out[f"edge_{case}_distance_{tag}"] = idx, rs, d
+    rng = np.random.default_rng(0)
+    for name, dim, ks, radius, n, m in (("3d", 3, (4, 4, 4), 0.3, 800, 500), ("2d", 2, (1, 8, 8), 0.12, 900, 600), ("1d", 1, (1, 8, 1), 0.2, 300, 300)):
+        pts = rng.uniform(-1, 1, size=(n, 3)).astype(np.float32)
+        qs = rng.uniform(-1, 1, size=(m, 3)).astype(np.float32)
+        if dim <= 2:
+            pts[:, 2] = 0
+            qs[:, 2] = 0
+        if dim == 1:
+            pts[:, 0] = 0
+            qs[:, 0] = 0
+        for ign in (0, 1):
+            q = pts[:m] if ign else qs
+            idx, rs, d = oracle.fixed_radius_search(pts, q, radius, bool(ign))
+            tag = f"{name}_ign{ign}"
+            out[f"frs_{tag}_points"], out[f"frs_{tag}_queries"], out[f"frs_{tag}_radius"] = pts, q, np.float32(radius)
+            out[f"frs_{tag}_index"], out[f"frs_{tag}_row_splits"], out[f"frs_{tag}_distance"] = idx, rs, d
+        feat = rng.normal(size=(n, 6)).astype(np.float32)
+        filt = rng.uniform(-1, 1, size=(*ks, 6, 5)).astype(np.float32)
+        idx, rs, d = oracle.fixed_radius_search(pts, qs, radius)
+        imp = oracle.window("poly6", d / np.float32(radius) ** 2)
+        for mapping in ("ball_to_cube_volume_preserving", "ball_to_cube_radial", "identity"):
+            out[f"cconv_{name}_{mapping}"] = oracle.continuous_conv(filt, qs, 2 * radius, pts, feat, idx, rs, imp, coordinate_mapping=mapping)
+        out[f"cconv_{name}_feat"], out[f"cconv_{name}_filt"] = feat, filt
+        out[f"cconv_{name}_index"], out[f"cconv_{name}_row_splits"], out[f"cconv_{name}_importance"] = idx, rs, imp
+    v = rng.normal(size=100).astype(np.float32)
+    rs = np.array([0, 10, 10, 55, 100], dtype=np.int64)
+    out["rss_values"], out["rss_row_splits"], out["rss_out"] = v, rs, oracle.reduce_subarrays_sum(v, rs)
+    np.savez(path, **out)
+    return out
+
+
+def test_golden_consumer_on_a_self_made_capture(oracle, tmp_path):
+    """The consumer of the off-box capture, exercised NOW on a file with the capture's keys in which the oracle stands in for
+    the library: it accepts its own reading, it reads every key, it FAILS (not skips) on a capture of the other reading and on
+    a key it does not know -- so the day the real file arrives the test means something."""
+    path = str(tmp_path / "capture.npz")
+    out = _self_made_capture(oracle, path)
+    _check_golden(oracle, path)
+    np.savez(path, **out, edge_surprise_extra=np.zeros(3))
+    with pytest.raises(AssertionError, match="no test consumed"):
+        _check_golden(oracle, path)
+    _self_made_capture(oracle, path, bins="corners", with_cuda=False)  # "the library walks the 8 corner voxels only"
+    with pytest.raises(AssertionError, match="contradicts the oracle's reading"):
+        _check_golden(oracle, path)
+    out = _self_made_capture(oracle, path)
+    out["edge_map_444_out_cpu"] = out["edge_map_444_out_cpu"].copy()
+    out["edge_map_444_out_cpu"][7] *= np.float32(1.001)
+    np.savez(path, **out)
+    with pytest.raises(AssertionError, match="continuous_conv differs"):
+        _check_golden(oracle, path)
+
+
+def _check_golden(oracle, path):
+    import os
+    npz = np.load(path)
+    seen = set()
+
+    class Tracked:
+        files = npz.files
+
+        def __getitem__(self, k):
+            seen.add(k)
+            return npz[k]
+
+        def __contains__(self, k):
+            return k in npz.files
+    g = Tracked()
     for name in ("3d", "2d", "1d"):
         for ign in (0, 1):
             tag = f"{name}_ign{ign}"
@@ -251,6 +415,42 @@ def test_against_open3d_golden(oracle):
             ref = g[f"cconv_{name}_{mapping}"]
             assert np.abs(y - ref).max() <= 1e-5 * np.abs(ref).max()
     np.testing.assert_allclose(oracle.reduce_subarrays_sum(g["rss_values"], g["rss_row_splits"]), g["rss_out"], rtol=1e-6)
+    # ---- the disputed inputs
+    cases = sorted({k[len("edge_"):].rsplit("_", 1)[0] for k in g.files
+                    if k.startswith("edge_") and (k.endswith("_radius") or k.endswith("_rel"))})
+    verdicts = []
+    for case in cases:
+        pre = f"edge_{case}_"
+        for tag in ("cpu", "cuda"):
+            if "rel" in case or case.startswith("map_"):
+                if pre + "out_" + tag not in g:
+                    continue
+                y, ref = _edge_conv(oracle, g, case), g[pre + "out_" + tag]
+                assert y.shape == ref.shape
+                err = np.abs(y - ref).max() / np.abs(ref).max()
+                assert err <= 1e-5, f"{case} [{tag}]: continuous_conv differs from the library by {err:.2e} (row {int(np.abs(y - ref).max(1).argmax())})"
+                continue
+            if pre + "row_splits_" + tag not in g:
+                continue
+            ref = (g[pre + "index_" + tag], g[pre + "row_splits_" + tag], g[pre + "distance_" + tag])
+            match = {}
+            for bins in ("own+corners", "corners", "all"):
+                idx, rs, d = _edge_search(oracle, g, case, bins)
+                ok = np.array_equal(rs, ref[1])
+                if ok:
+                    a, da = oracle.canonical_rows(idx, rs, d)
+                    b, db = oracle.canonical_rows(*ref)
+                    ok = np.array_equal(a, b) and np.array_equal(da, db)
+                match[bins] = ok
+            verdicts.append((case, tag, match))
+    # the CPU path is the contract (BASELINE.json north_star): the oracle's DEFAULT reading must reproduce every CPU capture;
+    # a CUDA capture must be reproduced by one of the readings (its 8-slot bin list is a different program)
+    lines = [f"{c} [{t}]: " + ", ".join(f"{b}={'ok' if ok else 'DIFFERS'}" for b, ok in m.items()) for c, t, m in verdicts]
+    bad = [line for (c, t, m), line in zip(verdicts, lines) if not (m["own+corners"] if t == "cpu" else any(m.values()))]
+    assert not bad, "the capture contradicts the oracle's reading of open3d's search:\n" + "\n".join(lines)
+    for k in g.files:  # inputs of the edge cases were read through _edge_search / _edge_conv
+        if k.startswith("edge_") and k.rsplit("_", 1)[1] in ("points", "queries", "radius", "ignore", "factor", "rel", "extent", "filt"):
+            seen.add(k)
     if "ascc_out" in g:  # captured with --reference: the reference's own ASCC layer, grid_pos and a 10-step rollout
         conv = oracle.ContinuousConvRef(g["ascc_kernel"], window_function="peak", ignore_query_points=True, symmetric=True,
                                         sym_axis=1)
@@ -268,6 +468,9 @@ def test_against_open3d_golden(oracle):
             pos, vel = ref.step(state)
             assert np.abs(pos - g["rollout_pos"][t]).max() <= 1e-5 * np.abs(g["rollout_pos"][t]).max(), f"rollout step {t}"
             state = [g["rollout_pos"][t], vel] + state[2:]  # per-step parity from the reference's own states
+        seen.update(("rollout_vel_last", "rollout_seconds_per_step"))  # (informational: the reference's own wall time)
+    left = sorted(set(g.files) - seen)
+    assert not left, f"keys of the capture no test consumed: {left}"
 
 
 def test_column_fixture_from_the_reference_generator(oracle):

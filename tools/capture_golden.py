@@ -17,7 +17,16 @@ code (imported from that checkout, never copied):
 ``tests/test_oracle.py::test_against_open3d_golden`` and ``tests/test_gpu_model.py::test_against_reference_rollout_golden``
 consume whatever the file holds.
 
-Nothing in this script can run in the build container or on the GPU box (neither package exists for
+The DISPUTED INPUTS (``edge_inputs``; listed by ``--manifest``, committed as tests/golden/open3d_golden.manifest.json) are
+built so that ONE run settles every constant the oracle recalls from the library (oracle/dmcf_oracle.c, "EXT" tags): which
+hash bins a query visits (own voxel + 8 corners, or the 8 corners alone), what happens a rounding step from a voxel's middle
+and at the radius' edge far from the origin, the clamps of the table size, both branches of the sphere -> cylinder map, the
+``sq_norm < 1e-12`` early-out and the clamp at the filter's border -- each on the CPU device and, when the machine has one, on
+a CUDA device (keys ``..._cpu`` / ``..._cuda``).  ``--inputs-only`` writes the inputs without the libraries: the build container
+runs the oracle on them (tests/test_oracle.py::test_disputed_inputs_discriminate) to show that the cases DO separate the
+readings.
+
+Nothing else in this script can run in the build container or on the GPU box (neither package exists for
 ROCm 7 / Python 3.10); it is provided so the gap can be closed off-box.
 """
 import argparse
@@ -26,6 +35,149 @@ import sys
 import time
 
 import numpy as np
+
+
+def _midpoint_queries(rng, radius, m, lo=0.2, hi=1.8):
+    """m queries in [lo, hi]^3 of which the first ones sit at (k + 1/2) * 2R -+ {0, 1, 2} ulps on one axis (every such middle
+    inside the range, on every axis): some of them hit the double rounding of floor(fl(q -+ R) / 2R) (e.g. z = 1.3 with
+    R = 0.1: the corner voxels of that axis come out two apart)."""
+    R = np.float32(radius)
+    qs = rng.uniform(lo, hi, size=(m, 3)).astype(np.float32)
+    mids = (np.arange(0, 64, dtype=np.float32) + np.float32(0.5)) * (np.float32(2) * R)
+    mids = mids[(mids > lo) & (mids < hi)]
+    k = 0
+    for a in range(3):
+        for mval in mids:
+            for step in (-2, -1, 0, 1, 2):
+                v = mval
+                for _ in range(abs(step)):
+                    v = np.nextafter(v, np.float32(np.inf if step > 0 else -np.inf), dtype=np.float32)
+                qs[k, a] = v
+                k += 1
+    assert k <= m
+    return qs
+
+
+def edge_inputs():
+    """The disputed inputs, as numpy arrays only (no TensorFlow / Open3D needed): {case: dict}.  Search cases hold ``points``,
+    ``queries``, ``radius``, ``ignore``, ``factor`` (hash_table_size_factor of the call; the layer's default is 1/64); mapping
+    cases hold ``rel`` (neighbour - query, one neighbour per query), ``extent``, ``filt``."""
+    rng = np.random.default_rng(2024)
+    cases = {}
+    R = 0.1
+    pts = rng.uniform(0.0, 2.0, size=(20000, 3)).astype(np.float32)
+    # (a) a query a rounding step from the MIDDLE of a hash voxel (z = 1.3, R = 0.1 and its relatives on every axis)
+    qs = _midpoint_queries(rng, R, 600)
+    qs[120] = np.float32([0.77, 0.93, 1.3])  # the query the 1M-particle rollout found (DESIGN.md section 2)
+    cases["frs_midpoint"] = dict(points=pts, queries=qs, radius=np.float32(R), ignore=False, factor=1 / 64)
+    cases["frs_midpoint_ignore"] = dict(points=np.concatenate([qs, pts]), queries=qs, radius=np.float32(R), ignore=True, factor=1 / 64)
+    # (b) pairs at distance R within rounding, 4000 away from the origin (one ulp of a coordinate is 0.5 % of R)
+    a = rng.uniform(-0.5, 0.5, size=(3000, 3)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, size=(3000, 3)).astype(np.float32) + np.float32([4000.0, -2500.0, 900.0])
+    far = np.concatenate([a, b])
+    cases["frs_radius_edge_far"] = dict(points=far, queries=far[::3].copy(), radius=np.float32(0.05), ignore=False, factor=1 / 64)
+    # (c) the table-size clamp from below: n * factor < 1 -> ONE bin, every query visits every point (no voxel can hide);
+    #     n = 63 / 64 / 65 / 127 / 128 straddle the first two sizes.  The midpoint queries ride along: with one bin their rows
+    #     must be complete, with two bins they may not be.
+    for n in (10, 63, 64, 65, 127, 128, 200):
+        p = rng.uniform(1.0, 1.6, size=(n, 3)).astype(np.float32)  # (a small cube: a handful of neighbours per row even at n = 200)
+        q = _midpoint_queries(rng, R, 150, 1.05, 1.55)
+        cases[f"frs_table_n{n}"] = dict(points=p, queries=q, radius=np.float32(R), ignore=False, factor=1 / 64)
+    # (d) ... and from above: factor * n > 32 * 2^20 clamps to 2^25 bins (134 MB of uint32 row splits)
+    p = rng.uniform(0.0, 2.0, size=(5000, 3)).astype(np.float32)
+    cases["frs_table_cap"] = dict(points=p, queries=_midpoint_queries(rng, R, 300), radius=np.float32(R), ignore=False, factor=1.0e4)
+    # (e) the ball -> cube map, one neighbour per query, feature 1, importance 1: out row = trilinear lookup of the filter.
+    #     Both sides of the cone 5/4 z^2 = x^2 + y^2 (sphere -> cylinder), both sides of |y| = |x| (cylinder -> cube), the
+    #     sq_norm < 1e-12 early-out (|rel| < 1e-6), the axes, and |rel| = extent / 2 exactly (clamp at the filter's border).
+    extent = np.float32(0.5)
+    rel = []
+    for rho in (0.05, 0.2, 0.2499):
+        for phi in np.linspace(0.0, 2.0 * np.pi, 16, endpoint=False) + 0.013:
+            for sign in (1.0, -1.0):
+                for eps in (-1e-3, -1e-6, 0.0, 1e-6, 1e-3):
+                    # on the cone: z^2 = 4/5 (x^2 + y^2)  <=>  tan(theta) = sqrt(5) / 2
+                    t = np.arctan(np.sqrt(5.0) / 2.0) + eps
+                    rel.append([rho * np.sin(t) * np.cos(phi), rho * np.sin(t) * np.sin(phi), sign * rho * np.cos(t)])
+    for rho in (0.1, 0.25):
+        for z in (-0.3, 0.0, 0.6):
+            for quad in range(4):
+                for eps in (-1e-6, 0.0, 1e-6):
+                    ang = np.pi / 4 + quad * np.pi / 2 + eps  # |y| = |x|
+                    c = np.sqrt(max(1.0 - z * z, 0.0))
+                    rel.append([rho * c * np.cos(ang), rho * c * np.sin(ang), rho * z])
+    for mag in (0.0, 1e-8, 9e-7, 1.1e-6, 1e-5):  # around sqrt(1e-12)
+        for axis in range(3):
+            v = [0.0, 0.0, 0.0]
+            v[axis] = mag
+            rel.append(v)
+        rel.append([mag / np.sqrt(3.0)] * 3)
+    for axis in range(3):  # exactly on the ball's surface and a step beyond / inside, per axis and on the diagonal
+        for mag in (np.float32(0.25), np.nextafter(np.float32(0.25), np.float32(1)), np.nextafter(np.float32(0.25), np.float32(0))):
+            for sign in (1.0, -1.0):
+                v = [0.0, 0.0, 0.0]
+                v[axis] = sign * float(mag)
+                rel.append(v)
+    d = 0.25 / np.sqrt(3.0)
+    rel += [[d, d, d], [-d, d, -d], [d * 1.0001, d * 1.0001, d * 1.0001]]
+    rel = np.asarray(rel, np.float32)
+    for name, ks in (("map_444", (4, 4, 4)), ("map_188", (1, 8, 8)), ("map_666", (6, 6, 6))):
+        filt = rng.uniform(-1, 1, size=(*ks, 1, 8)).astype(np.float32)
+        r = rel.copy()
+        if ks[0] == 1:
+            r[:, 2] = 0
+        cases[name] = dict(rel=r, extent=extent, filt=filt)
+    return cases
+
+
+# what the capture holds and which test consumes it (tests/golden/open3d_golden.manifest.json is generated from this)
+def manifest():
+    m = {}
+    for name, dim in (("3d", 3), ("2d", 2), ("1d", 1)):
+        for ign in (0, 1):
+            m[f"frs_{name}_ign{ign}_*"] = f"FixedRadiusSearch on a seeded {dim}-D cloud, ignore_query_point={bool(ign)}"
+        m[f"cconv_{name}_*"] = "continuous_conv with DMCF's flags, three coordinate mappings"
+    m["rss_*"] = "reduce_subarrays_sum"
+    for case, c in edge_inputs().items():
+        if "rel" in c:
+            m[f"edge_{case}_*"] = ("continuous_conv on single-neighbour rows: both sides of the sphere->cylinder cone and of |y|=|x|, "
+                                   "sq_norm < 1e-12, the ball's surface (clamp at the filter border); filter %s" % (c["filt"].shape[:3],))
+        else:
+            m[f"edge_{case}_*"] = ("FixedRadiusSearch, %d points, %d queries, R=%g, ignore=%s, hash_table_size_factor=%g; outputs per "
+                                   "device (_cpu, _cuda)" % (len(c["points"]), len(c["queries"]), float(c["radius"]), c["ignore"], c["factor"]))
+    m["ascc_* / gridpos_* / rollout_*"] = "--reference: the reference's ASCC layer, grid_pos and a 10-step Liquid3d rollout"
+    return {"consumers": ["tests/test_oracle.py::test_against_open3d_golden", "tests/test_gpu_model.py::test_against_reference_rollout_golden",
+                          "tests/test_gpu_ops.py::test_against_open3d_golden_hip"], "keys": m}
+
+
+def capture_edges(out):
+    """Run the disputed inputs through the library on every device it has."""
+    import open3d.ml.tf as ml3d
+    import tensorflow as tf
+    devices = [("cpu", "/CPU:0")] + ([("cuda", "/GPU:0")] if tf.config.list_physical_devices("GPU") else [])
+    for case, c in edge_inputs().items():
+        for k, v in c.items():
+            out[f"edge_{case}_{k}"] = np.asarray(v)
+        for tag, dev in devices:
+            with tf.device(dev):
+                if "rel" in c:
+                    rel, filt = c["rel"], c["filt"]
+                    n = len(rel)
+                    y = ml3d.ops.continuous_conv(filters=filt, out_positions=np.zeros((n, 3), np.float32),
+                                                 extents=tf.constant([[float(c["extent"])]], tf.float32), offset=tf.zeros((3,)),
+                                                 inp_positions=rel, inp_features=np.ones((n, 1), np.float32),
+                                                 inp_importance=tf.ones((0,), tf.float32),
+                                                 neighbors_index=np.arange(n, dtype=np.int32),
+                                                 neighbors_row_splits=np.arange(n + 1, dtype=np.int64),
+                                                 neighbors_importance=tf.ones((n,), tf.float32), align_corners=True,
+                                                 coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
+                                                 normalize=False)
+                    out[f"edge_{case}_out_{tag}"] = y.numpy()
+                else:
+                    frs = ml3d.layers.FixedRadiusSearch(metric="L2", ignore_query_point=bool(c["ignore"]), return_distances=True)
+                    res = frs(c["points"], c["queries"], float(c["radius"]), hash_table_size_factor=float(c["factor"]))
+                    out[f"edge_{case}_index_{tag}"] = res.neighbors_index.numpy()
+                    out[f"edge_{case}_row_splits_{tag}"] = res.neighbors_row_splits.numpy()
+                    out[f"edge_{case}_distance_{tag}"] = res.neighbors_distance.numpy()
 
 
 def capture_reference(ref_path, out, rng):
@@ -83,7 +235,16 @@ def capture_reference(ref_path, out, rng):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default=None, help="path to a tum-pbs/DMCF checkout: also capture ASCC / grid_pos / a rollout")
+    ap.add_argument("--manifest", action="store_true", help="print what a capture holds (JSON) and exit; needs numpy only")
+    ap.add_argument("--inputs-only", default=None, metavar="NPZ", help="write the disputed inputs (no outputs) and exit; numpy only")
     args = ap.parse_args()
+    if args.manifest:
+        import json
+        print(json.dumps(manifest(), indent=1))
+        return
+    if args.inputs_only:
+        np.savez_compressed(args.inputs_only, **{f"edge_{case}_{k}": np.asarray(v) for case, c in edge_inputs().items() for k, v in c.items()})
+        return
     import open3d.ml.tf as ml3d
     import tensorflow as tf
 
@@ -130,6 +291,7 @@ def main():
     rs = np.array([0, 10, 10, 55, 100], dtype=np.int64)
     out["rss_values"], out["rss_row_splits"] = v, rs
     out["rss_out"] = ml3d.ops.reduce_subarrays_sum(v, rs).numpy()
+    capture_edges(out)
     if args.reference:
         capture_reference(os.path.abspath(args.reference), out, np.random.default_rng(1))
     dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "open3d_golden.npz")
