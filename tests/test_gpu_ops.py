@@ -184,7 +184,7 @@ def test_frs_at_voxel_midpoints(oracle, dev):
     hit = own < full
     assert hit.sum() >= 1, "no query of this set hits the double rounding: the test has lost its point"
     assert np.array_equal(hit, corners < full) and np.all(corners <= own)
-    assert corners[hit].max() < 0.1 * full[hit].mean()      # the corner voxels alone: such a row is all but empty
+    assert corners[hit].sum() < 0.1 * full[hit].sum()       # the corner voxels alone: such rows are all but empty (a hash collision aside)
     assert 0 < own[hit].min() and (own[hit] < full[hit]).all()  # with the own voxel: it keeps what lies in that voxel
     # the density sum takes the same scan, under every set
     for name, rows in (("distance", full), ("open3d", own), ("open3d_corners", corners)):
