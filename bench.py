@@ -41,6 +41,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense f32-input MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32), same guide
+
+
+def lattice_algorithmic_flops(m):
+    """The lattice form (dmcf_amd/csrc/cconv_lat.hip) is a 3-D convolution: one [Cin x Cout] matrix per stencil offset and
+    output point, 2 * n_out * offsets * Cin * Cout flops per launch (the offsets of all parts of a batched launch are summed
+    in ``n_offsets``, each part covering its share of the outputs: n_out * n_offsets / parts = n_out_part * offsets summed)."""
+    return 2.0 * m["n_out"] * m["n_offsets"] / max(m.get("parts", 1), 1) * m["cin"] * m["cout"]
 
 
 def cconv_algorithmic_bytes(m):
@@ -145,18 +153,26 @@ def summarise(recs, steps):
     for kind, m, ms in recs:
         if kind != "cconv":
             continue
-        g = groups.setdefault(m.get("kernel", "cconv"), dict(launches=0, ms=0.0, bytes=0, lattice=bool(m.get("lattice"))))
+        g = groups.setdefault(m.get("kernel", "cconv"), dict(launches=0, ms=0.0, bytes=0, flops=0.0, lattice=bool(m.get("lattice"))))
         g["launches"] += 1
         g["ms"] += ms
         g["bytes"] += cconv_algorithmic_bytes(m)
+        if m.get("lattice"):
+            g["flops"] += lattice_algorithmic_flops(m)
 
     def frac(gs):
         ms = sum(g["ms"] for g in gs)
         by = sum(g["bytes"] for g in gs)
         n = sum(g["launches"] for g in gs)
         gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        return dict(launches=n, ms_per_step=ms / steps, avg_launch_ms=ms / max(n, 1), algorithmic_bytes_per_launch=by / max(n, 1),
-                    achieved=gbs, frac=gbs / HBM_PEAK_GBS)
+        d = dict(launches=n, ms_per_step=ms / steps, avg_launch_ms=ms / max(n, 1), algorithmic_bytes_per_launch=by / max(n, 1),
+                 achieved=gbs, frac=gbs / HBM_PEAK_GBS)
+        fl = sum(g["flops"] for g in gs)
+        if fl > 0:  # the lattice form: a dense 3-D convolution on the f32 matrix cores -- its own roofline next to the byte one
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            d.update(bound="mfma_f32", algorithmic_flops_per_launch=fl / max(n, 1), achieved_tflops=tf, peak_tflops=MFMA_F32_PEAK_TFLOPS,
+                     frac_mfma_f32=tf / MFMA_F32_PEAK_TFLOPS)
+        return d
     nl = [g for g in groups.values() if not g["lattice"]]
     lat = [g for g in groups.values() if g["lattice"]]
     table = dict(neighbour_list=frac(nl), lattice=frac(lat), by_kernel={k: frac([g]) for k, g in sorted(groups.items())})
@@ -304,7 +320,10 @@ def main():
         ops.timer = ops.LaunchTimer()
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
+        if ops.timer is not None:
+            step_marks.append(len(ops.timer.records))
         state = step(state)
         if os.environ.get("DMCF_BENCH_DEBUG"):
             torch.cuda.synchronize(dev)
@@ -362,6 +381,18 @@ def main():
     if rank == 0:
         recs = timer.results()
         table, dominant = summarise(recs, args.steps)
+        # the lattice launches over the window: the dense volumes cover the bounding box of the lattices, which grows with every
+        # particle that leaves the shell -- first and last timed step side by side
+        def lattice_step(i):
+            lo, hi = step_marks[i], (step_marks[i + 1] if i + 1 < len(step_marks) else len(recs))
+            ls = [(m, ms) for k, m, ms in recs[lo:hi] if k == "cconv" and m.get("lattice")]
+            return dict(launches=len(ls), ms=sum(ms for _, ms in ls), volume_mb=sum(m["volume_bytes"] for m, _ in ls) / 1e6,
+                        table_mb=sum(m["table_bytes"] for m, _ in ls) / 1e6, outputs=sum(m["n_out"] for m, _ in ls),
+                        tflops=(sum(lattice_algorithmic_flops(m) for m, _ in ls) / (sum(ms for _, ms in ls) * 1e-3) / 1e12
+                                if ls else 0.0))
+        if step_marks:
+            table["lattice"]["first_timed_step"] = lattice_step(0)
+            table["lattice"]["last_timed_step"] = lattice_step(len(step_marks) - 1)
         dom = table["by_kernel"].get(dominant, dict(achieved=0.0, frac=0.0, launches=0, avg_launch_ms=0.0, algorithmic_bytes_per_launch=0.0))
         traffic, traffic_source = cited_traffic(dominant)
         other = {}

@@ -644,7 +644,7 @@ def lattice_conv(filters, inp_volume, inp_min, out_table, out_min, n_out, voxel,
         no = int(n_out if n_out_launch is None else n_out_launch)
         timer.end("cconv", dict(pairs=0, pairs_equiv=int(no * (n_off / len(parts)) * float(fill)), n_out=no, cin=int(cin),
                                 cout=int(cout), K=int(filters.shape[0] * filters.shape[1] * filters.shape[2]), symmetric=False,
-                                lattice=True, kernel="lat_conv_kernel", n_offsets=int(n_off),
+                                lattice=True, kernel="lat_conv_kernel", n_offsets=int(n_off), parts=len(parts),
                                 volume_bytes=int(inp_volume.numel()) * 4, table_bytes=int(out_table.numel()) * 4,
                                 accumulate=bool(accumulate)), t0)
     return out

@@ -402,33 +402,86 @@ class GhostPlan:
             self.recv_counts = [int(r.shape[0]) for r in recv]
             self.ghost_pos = torch.cat(recv, dim=0)
         else:
-            assert parent.n_owned == self.n_owned and self.width <= parent.width
-            # sender side: the rows of the wide lists that are within the narrower width of the peer's block
-            peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
-            if peers:
-                rows = torch.cat([parent.send_idx[r] for r in peers])
-                seg = torch.repeat_interleave(torch.arange(len(peers), device=dev),
-                                              torch.tensor([parent.send_idx[r].shape[0] for r in peers], device=dev))
-                keep = _gap2(pos_owned[rows], _bounds_tensor(decomp, peers, dev)[seg]) <= w2
-                counts = host(torch.bincount(seg[keep], minlength=len(peers)))
-                rows = rows[keep]
-                off = 0
-                for i, r in enumerate(peers):
-                    self.send_idx[r] = rows[off:off + counts[i]]
-                    off += counts[i]
-            # receiver side: the same test on the received copies
-            g = parent.ghost_pos
-            if g.shape[0]:
-                src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
-                mine = _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2)
-                keep = _gap2(g, mine) <= w2
-                self.in_parent = torch.nonzero(keep).reshape(-1)
-                self.recv_counts = host(torch.bincount(src[keep], minlength=world))
-                self.ghost_pos = g[self.in_parent]
-            else:
-                self.in_parent = empty
-                self.ghost_pos = g
-        self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous() if world > 1 else pos_owned
+            counts = self._derive_begin(pos_owned)
+            self._derive_finish(host(torch.cat(counts)) if counts else [])
+        if parent is None or world == 1:
+            self._finish_ext(pos_owned)
+
+    def _finish_ext(self, pos_owned):
+        self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous() if self.comm.world > 1 else pos_owned
+
+    # A NARROW plan in two halves, so that the plans of a whole step can share ONE host round trip (derive_batch): everything
+    # that runs on the device first, then -- with the per-peer row counts on the host -- the slicing into per-peer lists.
+    def _derive_begin(self, pos_owned):
+        parent, decomp, comm = self.parent, self.decomp, self.comm
+        dev = pos_owned.device
+        world, rank = comm.world, comm.rank
+        assert parent.parent is None and parent.n_owned == self.n_owned and self.width <= parent.width
+        w2 = self.width * self.width
+        self._pos_owned = pos_owned
+        counts = []
+        # sender side: the rows of the wide lists that are within the narrower width of the peer's block
+        self._peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
+        if self._peers:
+            rows = torch.cat([parent.send_idx[r] for r in self._peers])
+            seg = torch.repeat_interleave(torch.arange(len(self._peers), device=dev),
+                                          torch.tensor([parent.send_idx[r].shape[0] for r in self._peers], device=dev))
+            keep = _gap2(pos_owned[rows], _bounds_tensor(decomp, self._peers, dev)[seg]) <= w2
+            counts.append(torch.bincount(seg[keep], minlength=len(self._peers)))
+            self._rows = rows[keep]
+        # receiver side: the same test on the received copies
+        g = parent.ghost_pos
+        self._recv = g.shape[0] > 0
+        if self._recv:
+            src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
+            mine = _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2)
+            keep = _gap2(g, mine) <= w2
+            self.in_parent = torch.nonzero(keep).reshape(-1)
+            counts.append(torch.bincount(src[keep], minlength=world))
+            self.ghost_pos = g[self.in_parent]
+        else:
+            self.in_parent = torch.zeros(0, dtype=torch.int64, device=dev)
+            self.ghost_pos = g
+        return counts
+
+    def _derive_finish(self, counts):
+        """``counts``: the host copy of what _derive_begin returned, concatenated."""
+        counts = [int(c) for c in counts]
+        off = 0
+        if self._peers:
+            c, counts = counts[:len(self._peers)], counts[len(self._peers):]
+            for i, r in enumerate(self._peers):
+                self.send_idx[r] = self._rows[off:off + c[i]]
+                off += c[i]
+            del self._rows
+        if self._recv:
+            self.recv_counts = counts[:self.comm.world]
+        self._finish_ext(self._pos_owned)
+        del self._pos_owned
+
+    @staticmethod
+    def derive_batch(requests):
+        """[(wide plan, its owned positions, width), ...] -> the narrow plans, with ONE device -> host read for all of them
+        (each plan alone costs one: a step of the Liquid3d net derives ~10)."""
+        plans, pending, sizes = [], [], []
+        for wide, pos_owned, width in requests:
+            p = GhostPlan.__new__(GhostPlan)
+            p.comm, p.decomp, p.parent = wide.comm, wide.decomp, wide
+            p.width = float(width) * (1.0 + 1e-5) + 1e-6
+            p.n_owned = pos_owned.shape[0]
+            empty = torch.zeros(0, dtype=torch.int64, device=pos_owned.device)
+            p.send_idx = [empty] * wide.comm.world
+            p.recv_counts = [0] * wide.comm.world
+            c = p._derive_begin(pos_owned)
+            plans.append(p)
+            pending.extend(c)
+            sizes.append(sum(int(t.shape[0]) for t in c))
+        flat = host(torch.cat(pending)) if pending else []
+        off = 0
+        for p, n in zip(plans, sizes):
+            p._derive_finish(flat[off:off + n])
+            off += n
+        return plans
 
     def extend(self, feats_owned):
         """[n_owned, C] -> [n_owned + n_ghost, C] (owned rows first, ghosts in the order of ``pos_ext``): one all-to-all-v,
@@ -447,15 +500,15 @@ class GhostPlan:
         return lambda: torch.cat([feats_owned] + wait(), dim=0).contiguous()
 
     def extend_from(self, wide, wide_ext):
-        """``extend`` without communication, from the same features already extended by the wider plan this one derives
-        from (directly or through intermediate plans)."""
-        chain, p = [], self
-        while p is not wide:
-            chain.append(p)
-            p = p.parent
+        """``extend`` without communication, from the same features already extended by a wider plan of the same point set:
+        the set's widest plan (this one's parent) or another plan derived from it -- the narrower test keeps a subset of the
+        wider one's ghosts, in the same order."""
         ghosts = wide_ext[self.n_owned:]
-        for p in reversed(chain):
-            ghosts = ghosts[p.in_parent]
+        if wide is self.parent:
+            ghosts = ghosts[self.in_parent]
+        else:
+            assert wide.parent is self.parent and wide.width >= self.width
+            ghosts = ghosts[torch.searchsorted(wide.in_parent, self.in_parent)]
         return torch.cat([wide_ext[:self.n_owned], ghosts], dim=0)
 
 
@@ -481,6 +534,8 @@ class ShardedSimulator:
         self.reserved_gib = None
         self.exchanged_rows = 0
         self.migrated_rows_total = 0
+        self.host_syncs_last_step = None  # device -> host reads of the last step (each one drains the queue): see Stats
+        self.launch_rows = []             # (point set, radius, input rows of the launch, owned rows) per convolution of the last step
         m = model
         for key in ("translate", "scale", "grav_eqvar"):
             if key in m.transformation:
@@ -505,10 +560,7 @@ class ShardedSimulator:
             wide = self._wide[name]
             if float(width) * (1.0 + 1e-5) + 1e-6 > wide.width:
                 raise RuntimeError(f"ghost plan of {name!r} asked for width {width} > the step's widest {wide.width}")
-            # derive from the narrowest existing plan that is still wide enough (fewer rows to test)
-            parent = min((p for (n, _), p in self._plans.items() if n == name and p.width >= float(width) * (1.0 + 1e-5) + 1e-6),
-                         key=lambda p: p.width)
-            plan = GhostPlan(self.comm, self.decomp, self._sets[name], width, parent=parent)
+            plan = GhostPlan(self.comm, self.decomp, self._sets[name], width, parent=wide)
             if os.environ.get("DMCF_SHARD_CHECK") == "1" and self.comm.world > 1:
                 direct = GhostPlan(self.comm, self.decomp, self._sets[name], width)
                 if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
@@ -567,6 +619,8 @@ class ShardedSimulator:
                         self._shared.pop(next(iter(self._shared)))
                     self._shared[id(feats)] = hit
             ext = hit[2] if plan is wide else plan.extend_from(wide, hit[2])
+        # (the launch reads the ghosts within ITS radius, whatever width the rows travelled at)
+        self.launch_rows.append((inp, 0.5 * float(extent), int(plan.pos_ext.shape[0]), int(n_own)))
         return conv(ext, plan.pos_ext, out_pos, extent, None)
 
     def _ghost_prefetch(self, requests):
@@ -595,6 +649,8 @@ class ShardedSimulator:
             if state["pos"].is_cuda:
                 self.reserved_gib = reserve_for_scene(self.reserve_gib, int(state["pos"].shape[0] + state["box"].shape[0]),
                                                       state["pos"].device)
+        syncs0 = stats().host_syncs
+        self.launch_rows = []
         try:
             with neighbor_cache(estimate=True):
                 out = self._step(state)
@@ -606,6 +662,7 @@ class ShardedSimulator:
         if int(host(flag[0])) == 0:
             with neighbor_cache(estimate=False):
                 out = self._step(state)
+        self.host_syncs_last_step = stats().host_syncs - syncs0
         return out
 
     def _step(self, state):
@@ -740,10 +797,21 @@ class ShardedSimulator:
         # every ghost plan the layers will ask for, NOW: a derived plan costs two small host round trips (its selection
         # sizes), and here the queue is short -- inside the forward pass each would drain it
         if comm.world > 1:
+            want = []
             for name in list(self._sets):
                 for r in m.particle_radii:
-                    if float(r) * (1.0 + 1e-5) + 1e-6 <= self._wide[name].width:
-                        self._plan(name, float(np.float32(0.5) * (np.float32(r) * np.float32(2))))
+                    w = float(np.float32(0.5) * (np.float32(r) * np.float32(2)))
+                    if float(r) * (1.0 + 1e-5) + 1e-6 <= self._wide[name].width and (name, round(w, 9)) not in self._plans \
+                            and (name, round(w, 9)) not in [(n, round(x, 9)) for n, x in want]:
+                        want.append((name, w))
+            for (name, w), plan in zip(want, GhostPlan.derive_batch([(self._wide[name], self._sets[name], w) for name, w in want])):
+                if os.environ.get("DMCF_SHARD_CHECK") == "1":
+                    direct = GhostPlan(self.comm, self.decomp, self._sets[name], w)
+                    if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
+                            not torch.equal(a, b) for a, b in zip(direct.send_idx, plan.send_idx)):
+                        raise RuntimeError("a derived ghost plan differs from the directly built one")
+                self._plans[(name, round(w, 9))] = plan
+                self._register_lattice(name, plan)
         return sets, None
 
 

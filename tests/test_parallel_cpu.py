@@ -44,8 +44,9 @@ def _run_rank(comm, decomp, scene, steps):
     state = parallel.shard_scene(scene, decomp, comm.rank, "cpu")
     for _ in range(steps):
         state = sim.step(state)
+    wide = {name: int(p.ghost_pos.shape[0]) for name, p in sim._wide.items()}
     return dict(gid=state["gid"].numpy(), pos=state["pos"].numpy(), vel=state["vel"].numpy(),
-                exchanged=sim.exchanged_rows)
+                exchanged=sim.exchanged_rows, host_syncs=sim.host_syncs_last_step, launch_rows=list(sim.launch_rows), wide_ghosts=wide)
 
 
 def _assemble(parts, n):
@@ -107,6 +108,23 @@ def test_virtual_block_ranks_equal_single_rank(monkeypatch, grid):
     pos, vel = _assemble(parts, n)
     _close(pos, pos1)
     _close(vel, vel1, 2e-4)
+    # Host round trips of a sharded step (each one drains the GPU's queue), counted WITHOUT the
+    # cross-check above (it builds every plan twice): 1 migration + 5 widest ghost plans (selection sizes; sets: all / fluid /
+    # boundary / two lattices) + 1 lattice centre + the plans of the lattice margins + 1 for ALL other narrow plans together
+    # + 1 end-of-step agreement = 13 with this communicator; torch.distributed adds the receive counts of the 5 widest plans
+    # and of the migration, a GPU step the two lattice union boxes: 21.  None inside the forward pass; the same number on every
+    # rank (they are collectives or sit beside one).  Round 3: 33.
+    monkeypatch.delenv("DMCF_SHARD_CHECK")
+    plain = parallel.run_local_ranks(decomp.world, lambda comm: _run_rank(comm, decomp, scene, 2))
+    assert {p["host_syncs"] for p in plain} == {13}, [p["host_syncs"] for p in plain]
+    for a, b in zip(parts, plain):
+        assert np.array_equal(a["pos"], b["pos"])
+    # ... and every launch reads the ghosts within ITS OWN radius, not the widest plan's (item 6c): the R = 0.1 layers of the
+    # all-points set take fewer input rows than the widest plan holds
+    for p in parts:
+        narrow = [rows - own for name, r, rows, own in p["launch_rows"] if name == "s0" and abs(r - 0.1) < 1e-6]
+        assert narrow and max(narrow) < p["wide_ghosts"]["s0"], (narrow, p["wide_ghosts"])
+        assert len(p["launch_rows"]) >= 14
 
 
 def test_bench_self_launch_dry_run():
@@ -179,7 +197,7 @@ def _gloo_worker(rank, world, port, scene, steps, out_dir):
         comm = parallel.TorchDistComm()
         decomp = parallel.SlabDecomposition.uniform(0, 0.0, 0.6, world)
         res = _run_rank(comm, decomp, scene, steps)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v for k, v in res.items() if k != "exchanged"})
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{k: v for k, v in res.items() if k in ("gid", "pos", "vel")})
     finally:
         dist.destroy_process_group()
 

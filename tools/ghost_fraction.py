@@ -53,15 +53,27 @@ def main():
             plans = {f"{w:g}": int(p.ghost_pos.shape[0]) for (n, w), p in sorted(sim._plans.items()) if n == name}
             sets[str(name)] = dict(owned=int(pos.shape[0]), widest=float(sim._wide[name].width),
                                    ghosts_widest=int(sim._wide[name].ghost_pos.shape[0]), ghosts_by_width=plans)
+        launch = {}
+        for name, r, n_rows, own in sim.launch_rows:  # input rows of every convolution launch: owned + the ghosts within ITS radius
+            k = f"{name}@{r:g}"
+            launch[k] = dict(launches=launch.get(k, {}).get("launches", 0) + 1, owned=own, ghosts=n_rows - own)
         return dict(rank=comm.rank, block=decomp.coords(comm.rank), fluid=int(state["pos"].shape[0]), sets=sets,
-                    feature_rows_per_step=rows[-1], step_seconds=times)
+                    feature_rows_per_step=rows[-1], step_seconds=times, host_syncs_per_step=sim.host_syncs_last_step,
+                    launch_inputs=launch)
 
     res = parallel.run_local_ranks(world, rank_fn)
     out = dict(side=side, grid=grid, fluid_total=side ** 3 * world, ranks=res)
     print(json.dumps(out))
     last = max(r["step_seconds"][-1] for r in res)
+    per_step = [max(r["step_seconds"][i] for r in res) for i in range(steps)]
+    print(f"steps (all {world} ranks on ONE GPU, ms): " + ", ".join(f"{1e3 * t:.1f}" for t in per_step) + f"; per rank: "
+          + ", ".join(f"{1e3 * t / world:.1f}" for t in per_step) + f"; host round trips per step and rank: {res[0]['host_syncs_per_step']}",
+          file=sys.stderr)
     print(f"last step: {1e3 * last:.1f} ms for all {world} ranks on ONE GPU = {1e3 * last / world:.1f} ms of GPU time per rank and step "
           "(the ranks' kernels share the device; their host work overlaps)", file=sys.stderr)
+    r0 = res[0]
+    print("rank 0 launch inputs (owned + ghosts within the launch's own radius): "
+          + ", ".join(f"{k}: {v['launches']} x ({v['owned']} + {v['ghosts']})" for k, v in sorted(r0["launch_inputs"].items())), file=sys.stderr)
     # summary on stderr
     for r in res:
         s = r["sets"]
