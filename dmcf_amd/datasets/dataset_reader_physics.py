@@ -212,17 +212,25 @@ def get_rollout(dataset, stride=1, time_start=0, time_end=None, cnt=None, transl
 
 def write_results(path, name, data):
     """:520-526: HDF5 file with one group ``name`` and one dataset per (array, props) entry, attrs ``type`` / ``dim``
-    -- what utils/draw_sim2d.py reads.  Needs h5py."""
+    -- what utils/draw_sim2d.py:170-174 reads.  Written through h5py when that is installed (the reference's own call
+    sequence), otherwise by the built-in writer (dmcf_amd/utils/hdf5_writer.py: contiguous little-endian datasets in a
+    version-0 HDF5 file; checked against the HDF5 C library in tests/test_hdf5_writer.py)."""
     try:
         import h5py
-    except ImportError as e:  # not installed in this image; no stand-in is silently substituted
-        raise ImportError("write_results needs h5py (HDF5); use write_results_npz for an .npz with the same content") from e
-    with h5py.File(os.path.join(path), "w") as f:
-        grp = f.create_group(name)
-        for d, props in data:
-            dset = grp.create_dataset(props["name"], data=d)
-            dset.attrs["type"] = props.get("type", "DENSITY")
-            dset.attrs["dim"] = d.shape
+    except ImportError:
+        h5py = None
+    if h5py is not None:
+        with h5py.File(os.path.join(path), "w") as f:
+            grp = f.create_group(name)
+            for d, props in data:
+                dset = grp.create_dataset(props["name"], data=d)
+                dset.attrs["type"] = props.get("type", "DENSITY")
+                dset.attrs["dim"] = d.shape
+        return
+    from ..utils.hdf5_writer import write_hdf5
+    write_hdf5(os.path.join(path), name,
+               [(props["name"], np.asarray(d), {"type": props.get("type", "DENSITY"), "dim": np.asarray(np.shape(d), dtype=np.int64)})
+                for d, props in data])
 
 
 def write_results_npz(path, name, data):

@@ -158,9 +158,9 @@ class Simulator:
 
     def run_test(self, epoch=None):
         """simulator.py:111-165: roll out every scene of the test split over its full length and write
-        ``<out_dir>/visual/<scene>/<epoch>.hdf5`` with the datasets pred / gt / bnd (``.npz`` with the same content when
-        h5py is not installed).  Returns the list of output paths."""
-        from ..datasets import get_rollout, write_results, write_results_npz
+        ``<out_dir>/visual/<scene>/<epoch>.hdf5`` with the datasets pred / gt / bnd (an HDF5 file utils/draw_sim2d.py reads:
+        through h5py when installed, else by the built-in writer).  Returns the list of output paths."""
+        from ..datasets import get_rollout, write_results
         cfg = self.cfg
         gen = dict(cfg.get("data_generator") or {})
         test_kw = dict(gen.pop("test", None) or {})
@@ -180,14 +180,12 @@ class Simulator:
             output = [(pos, {"name": "pred", "type": "PARTICLE"}), (data["pos"], {"name": "gt", "type": "PARTICLE"}),
                       (data["box"][0], {"name": "bnd", "type": "PARTICLE"})]
             path = os.path.join(out_dir, "%04d.hdf5" % epoch)
-            for stale in os.listdir(out_dir):  # simulator.py:156-160: one result file per scene directory
-                if stale.endswith((".hdf5", ".npz")):
+            write_results(path, self.model.name, output)
+            # simulator.py:155-162: write first, THEN drop the scene directory's other result files (a failed write must not
+            # cost the previous results)
+            for stale in os.listdir(out_dir):
+                if stale.endswith((".hdf5", ".npz")) and os.path.join(out_dir, stale) != path:
                     os.remove(os.path.join(out_dir, stale))
-            try:
-                write_results(path, self.model.name, output)
-            except ImportError:
-                path = path[:-5] + ".npz"
-                write_results_npz(path, self.model.name, output)
             paths.append(path)
         if cfg.get("test_compute_metric", False):
             raise NotImplementedError("test_compute_metric (run_valid: Chamfer / EMD metrics) is out of scope of the hot path")
