@@ -127,10 +127,11 @@ class HRNet(PBFNet):
                         widest = max(filter_extent[max(inp_scale, s)] for s in range(n_scales))
                         if acc is not None:
                             conv.accumulate_into, conv.extra_bias = acc, pending_bias
-                        ans_conv = self.apply_conv(conv, conv_in, pos[inp_scale], pos[scale], ext, widest if conv_in is feats else None)
-                        if acc is not None:
-                            if conv.accumulate_into is None:  # (taken: the result IS the sum)
+                        try:
+                            ans_conv = self.apply_conv(conv, conv_in, pos[inp_scale], pos[scale], ext, widest if conv_in is feats else None)
+                            if acc is not None and conv.accumulate_into is None:  # (taken: the result IS the sum)
                                 pending_bias = None
+                        finally:  # (a call that raised -- a ghost exchange, an allocation -- must not leave the request behind)
                             conv.accumulate_into = conv.extra_bias = None
                     if fuse:
                         if acc is None:

@@ -32,6 +32,12 @@ def reserve_for_scene(reserve_gib, n_points, device):
     RESERVE_BYTES_PER_POINT each, at most a quarter of the device, nothing below 0.25 GiB (small scenes: the allocator's own
     growth is a few MB).  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
     gib = reserve_gib
+    if gib and device is not None and torch.device(device).type == "cuda":
+        # torch's allocator serves requests up to 1 MB from 2 MB segments of their own ("small pool"): row splits, counts,
+        # headers, the 2-D scenes' whole lists.  That pool grows one hipMalloc at a time whenever a step needs one block more
+        # than any step before it (round 3: six such steps in the 3200-step rollout) -- hold 64 MB of it from the start.
+        small = [torch.empty(1 << 20, dtype=torch.uint8, device=device) for _ in range(64)]
+        del small
     if gib == "auto":
         gib = n_points * RESERVE_BYTES_PER_POINT / 2 ** 30
         gib = min(gib, torch.cuda.mem_get_info(device)[1] / 2 ** 30 / 4)  # (total device memory)

@@ -41,7 +41,7 @@ class _NeighborCache:
         # back to a neighbour list in the middle of a rollout, every later search took its neighbour's estimate -- a 35-entry
         # stride for a 286-entry list -- and the step was repeated.)
         self.hints = {}
-        self.caps = {}  # same keys -> entries of the padded buffers of the previous step (kept while they still fit)
+        self.caps = {}  # (class, n-th search of that class in the step) -> entries of its padded buffers in the previous step
         # consumers per list: learnt in one step, used in the next to hand a list's buffers back to the allocator as soon
         # as its last consumer has enqueued its kernel (12 lists of 2.4 - 3.4 GB each at 1M particles; all of them alive
         # until the end of the step was 160 GB at 4M particles and sent the caching allocator into free / malloc cycles)
@@ -50,7 +50,7 @@ class _NeighborCache:
         self.slot_of = {}
         self.done = []
         self.use_hints = False
-        self.order = 0
+        self.nth = {}  # searches of each class so far in this step (the second half of a list's key in expect / uses / caps)
         self.pending = []
         self.lists = {}
         self.tables = {}
@@ -70,7 +70,7 @@ class _NeighborCache:
 
     def __enter__(self):
         if self.depth == 0:
-            self.order = 0
+            self.nth = {}
             self.pending = []
         self.depth += 1
         return self
@@ -168,15 +168,21 @@ class _NeighborCache:
         if table is None or table.n_queries_capacity < queries.shape[0]:
             table = ops.build_spatial_hash_table(points, radius, n_queries=max(points.shape[0], queries.shape[0]))
             self.tables[tkey] = table
-        slot, self.order = self.order, self.order + 1
         hkey = _hint_key(frs, points, queries, radius)
+        # what the estimates of a list are filed under -- who consumes it, how big its buffer was -- is what the search IS
+        # (its class) plus, for searches of one class within a step, their order among themselves: a layer that switches
+        # between the lattice form and a neighbour list mid-rollout then shifts nobody else's entry (as position in the
+        # step's whole search sequence did)
+        nth = self.nth.get(hkey, 0)
+        self.nth[hkey] = nth + 1
+        slot = (hkey, nth)
         hint = self.hints.get(hkey) if self.use_hints else None
         if hint is not None:
             # Padded rows of row_stride(longest row of the previous step) entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
             # stride is detected at the end of the step (one sync) and the step is repeated with the exact search.
-            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(hkey))
-            self.caps[hkey] = getattr(res, "capacity", None)
+            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(slot))
+            self.caps[slot] = getattr(res, "capacity", None)
         else:
             res = frs(points, queries, radius, hash_table=table)
         self.pending.append((hkey, res))
@@ -280,12 +286,14 @@ def neighbor_hints():
 
 
 def row_stride(longest):
-    """Row capacity for the padded single-pass search from the longest row of the previous step: 1/4 slack, rounded up
-    to 1/8 of the enclosing power of two (a handful of distinct buffer sizes for the caching allocator).  (Wider slack for the
-    short-row lists -- 3 x up to 192 entries, then 4 x up to 384 -- was tried against the repeated step of the 1M bench scene's
-    driver window and changed nothing: the repeat came from estimates applied to the wrong search, see _hint_key; with that fixed
-    this slack runs the window without a repeat, and the wider one only cost 8.5 GiB of reservation.)"""
-    x = int(longest) + int(longest) // 4 + 8
+    """Row capacity for the padded single-pass search from the longest row of the previous step: 1/4 slack for long rows; short
+    rows get MORE room -- twice the longest row up to 64 entries, + 64 beyond -- because there the maximum over a million rows is
+    a noisy statistic (a splash that lands on a wall takes the longest s0 -> s0 row of the 100k dam break from ~35 to ~60 in one
+    step: round 3's only repeated step of that 200-step rollout) and room is free: a row's unused tail is neither written nor
+    read, and a 1.1M-row list of 80 instead of 56 entries is 110 MB more of 288 GB.  Rounded up to 1/8 of the enclosing power
+    of two (a handful of distinct buffer sizes for the caching allocator)."""
+    longest = int(longest)
+    x = longest + max(longest // 4, min(longest, 64)) + 8
     g = max(8, 1 << max(x.bit_length() - 4, 0))  # 1/8 of the enclosing power of two
     return (x + g - 1) // g * g
 
@@ -419,10 +427,11 @@ class ContinuousConv(torch.nn.Module):
         self.accumulate_into = self.extra_bias = None
         if acc is not None and (self.use_dense_layer_for_center or self.activation is not None or not acc.is_contiguous()
                                 or tuple(acc.shape) != (out_positions.shape[0], self.filters) or acc.dtype != torch.float32):
-            self.extra_bias = extra_bias  # (not expressible in the epilogue: the plain call, then the sum)
-            return acc.add_(self.forward(inp_features, inp_positions, out_positions, extents, inp_importance,
-                                         fixed_radius_search_hash_table, user_neighbors_index, user_neighbors_row_splits,
-                                         user_neighbors_importance))
+            # not expressible in the epilogue: the plain call, then the sums (the extra bias OUTSIDE the layer's activation)
+            acc.add_(self.forward(inp_features, inp_positions, out_positions, extents, inp_importance,
+                                  fixed_radius_search_hash_table, user_neighbors_index, user_neighbors_row_splits,
+                                  user_neighbors_importance))
+            return acc if extra_bias is None else acc.add_(extra_bias)
         if isinstance(extents, torch.Tensor):
             if extents.dim() > 0 and extents.numel() != 1:
                 raise NotImplementedError("per-point extents (RadiusSearch, convolutions.py:366-370) are never "

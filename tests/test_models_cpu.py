@@ -162,16 +162,17 @@ def test_scene_file_io_roundtrip_and_reference_fixture(tmp_path):
     assert r["pos"].shape == (3, 1280, 3) and r["box"].shape == (3, 10006, 3) and list(r["frame_id"]) == [0, 1, 2]
     np.testing.assert_array_equal(r["pos"][1], frames[1]["pos"] + np.float32([0.5, 0, 0]))
     assert get_rollout(ds, time_start=1, time_end=2)[0]["pos"].shape[0] == 1
-    # result writers: npz always, HDF5 only with h5py (absent here: a clear error, no silent substitute)
+    # result writers: the reference's HDF5 file (h5py or, without it, the built-in writer: tests/test_hdf5_writer.py reads it
+    # back with the HDF5 C library), and an .npz with the same content
     out = [(r["pos"], {"name": "pred", "type": "PARTICLE"}), (frames[0]["box"], {"name": "bnd", "type": "PARTICLE"})]
     write_results_npz(str(tmp_path / "r.npz"), "SymNet", out)
     z = np.load(str(tmp_path / "r.npz"))
     assert z["SymNet/pred"].shape == (3, 1280, 3) and str(z["SymNet/bnd.type"]) == "PARTICLE"
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(ImportError):
-            write_results(str(tmp_path / "r.hdf5"), "SymNet", out)
+    write_results(str(tmp_path / "r.hdf5"), "SymNet", out)
+    import test_hdf5_writer as h5t
+    got = h5t._walk(str(tmp_path / "r.hdf5"))["SymNet"]
+    np.testing.assert_array_equal(got["pred"], r["pos"])
+    np.testing.assert_array_equal(got["bnd"], frames[0]["box"])
 
 
 def test_fps_multiscale_host_logic(oracle, monkeypatch):
