@@ -48,6 +48,8 @@ class NeighborSearchResult:
     def release(self):
         """Drop the index / distance buffers (the per-step neighbour cache calls this once a list's last consumer has
         enqueued its kernel: a 3e8-pair list is 2.4 GB, padded 3.4 GB).  Row splits / counts stay."""
+        if self._index_buf is not None:
+            self._capacity = self._index_buf.shape[0]  # (still needed to validate an estimated size at the end of the step)
         self._index_buf = self._dist_buf = None
         self._redo = None
 
@@ -58,7 +60,7 @@ class NeighborSearchResult:
 
     @property
     def capacity(self):
-        return self._index_buf.shape[0]
+        return self._index_buf.shape[0] if self._index_buf is not None else self._capacity
 
     def resolve(self):
         """Make the result exact: one synchronisation; repeats the write pass if the estimate was too small."""
@@ -70,7 +72,7 @@ class NeighborSearchResult:
         return self._total
 
     def overflowed(self, total):
-        return self._total is None and total > self._index_buf.shape[0]
+        return self._total is None and total > self.capacity
 
     @property
     def neighbors_index(self):

@@ -29,8 +29,7 @@ RESERVE_BYTES_PER_POINT = 40 * 1024
 
 def reserve_for_scene(reserve_gib, n_points, device):
     """The ``reserve_gib`` rule of Simulator / ShardedSimulator for a scene of ``n_points`` particles (fluid + boundary): "auto" =
-    RESERVE_BYTES_PER_POINT each, at most a quarter of the device, nothing below 0.25 GiB (small scenes: the allocator's own
-    growth is a few MB).  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
+    RESERVE_BYTES_PER_POINT each, at most a quarter of the device, at least 0.25 GiB.  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
     gib = reserve_gib
     if gib and device is not None and torch.device(device).type == "cuda":
         # torch's allocator serves requests up to 1 MB from 2 MB segments of their own ("small pool"): row splits, counts,
@@ -38,11 +37,15 @@ def reserve_for_scene(reserve_gib, n_points, device):
         # than any step before it (round 3: six such steps in the 3200-step rollout) -- hold 64 MB of it from the start.
         small = [torch.empty(1 << 20, dtype=torch.uint8, device=device) for _ in range(64)]
         del small
+        # ... and load the code of the library kernels a rollout may meet late: grid_pos's sort-based form (torch.unique +
+        # argsort, taken once stray particles make the lattices' bounding box too sparse for a dense cell table) cost the
+        # 100k dam break 300 ms in the step that first needed it
+        from ..utils.tools.losses import _unique_first_occurrence
+        _unique_first_occurrence(torch.arange(8, dtype=torch.int64, device=device) % 3)
     if gib == "auto":
         gib = n_points * RESERVE_BYTES_PER_POINT / 2 ** 30
         gib = min(gib, torch.cuda.mem_get_info(device)[1] / 2 ** 30 / 4)  # (total device memory)
-        if gib < 0.25:
-            gib = 0
+        gib = max(gib, 0.25)  # (the 2-D scenes: their lists are a few MB, but grow with every particle that leaves the tank)
     return ops.reserve_device_memory(float(gib), device) if gib else 0.0
 
 

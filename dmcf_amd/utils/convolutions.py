@@ -42,6 +42,8 @@ class _NeighborCache:
         # stride for a 286-entry list -- and the step was repeated.)
         self.hints = {}
         self.caps = {}  # (class, n-th search of that class in the step) -> entries of its padded buffers in the previous step
+        self.totals = {}  # same keys -> pairs of that list in the previous step (padded rows or CSR: see search())
+        self.last_overflow = []  # diagnostics: the lists that outgrew their estimates in the last step that had to be repeated
         # consumers per list: learnt in one step, used in the next to hand a list's buffers back to the allocator as soon
         # as its last consumer has enqueued its kernel (12 lists of 2.4 - 3.4 GB each at 1M particles; all of them alive
         # until the end of the step was 160 GB at 4M particles and sent the caching allocator into free / malloc cycles)
@@ -62,10 +64,10 @@ class _NeighborCache:
         """Swap in the estimates (hints / caps / expect) of ``key`` (outermost scope only)."""
         if key == self.key:
             return
-        self.states[self.key] = (self.hints, self.caps, self.expect)
+        self.states[self.key] = (self.hints, self.caps, self.expect, self.totals)
         while len(self.states) > 16:  # a handful of (model, scene) rollouts at a time
             self.states.pop(next(iter(self.states)))
-        self.hints, self.caps, self.expect = self.states.pop(key, ({}, {}, {}))
+        self.hints, self.caps, self.expect, self.totals = self.states.pop(key, ({}, {}, {}, {}))
         self.key = key
 
     def __enter__(self):
@@ -80,7 +82,7 @@ class _NeighborCache:
         if self.depth == 0:
             pending, self.pending = self.pending, []
             self._flush()
-            for _, r in pending:  # layers keep their last list in .nns: do not let that pin the buffers into the next step
+            for _, _, r in pending:  # layers keep their last list in .nns: do not let that pin the buffers into the next step
                 r.release()
             if exc_type is None:
                 self.expect = dict(self.uses)
@@ -92,23 +94,34 @@ class _NeighborCache:
             self.tables.clear()
             self.keepalive.clear()
             if exc_type is None and pending:
-                # one synchronisation per step: validate the estimated row capacities, refresh the estimates
-                # (hint = the longest row of the list)
-                def longest(r):
+                # one synchronisation per step: validate the estimated capacities, refresh the estimates (the longest row and
+                # the number of pairs of every list)
+                def stats(r):
                     if isinstance(r, ops.PaddedNeighborList):
-                        return r.max_count[0].long()
+                        return torch.stack([r.max_count[0].long(), r.total_ref.long()])
                     rs = r.neighbors_row_splits
-                    return torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(())
-                maxima = torch.stack([longest(r) for _, r in pending]).tolist()
-                bad = False
+                    return torch.stack([torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(()), rs[-1]])
+                vals = torch.stack([stats(r) for _, _, r in pending]).tolist()
                 fresh = {}
-                for (hkey, r), mx in zip(pending, maxima):
+                over = []
+                for (hkey, slot, r), (mx, total) in zip(pending, vals):
                     if isinstance(r, ops.PaddedNeighborList):
-                        bad |= r.overflowed(mx)
+                        if r.overflowed(mx):
+                            over.append((hkey, "row", r.stride, int(mx)))
+                    elif r.overflowed(total):
+                        over.append((hkey, "pairs", r.capacity, int(total)))
                     fresh[hkey] = max(fresh.get(hkey, 0), int(mx))  # (searches of one class share the longest of their rows)
+                    self.totals[slot] = int(total)
+                # estimates come from the PREVIOUS step only: a class this step did not search is forgotten (its next search runs
+                # the exact two passes once).  Keeping old entries let one search inherit another's: in the dam break the
+                # lattices grow through the half-octave size classes, and at step 81 the s0 -> s2 list (2,300-entry rows)
+                # arrived in the class the s2 -> s1 list (300) had left 30 steps earlier -- a repeated step.
+                self.hints.clear()
                 self.hints.update(fresh)
-                if bad:
-                    raise ops.NeighborCapacityExceeded("a neighbour row outgrew its estimated capacity; repeat the step")
+                if over or self.use_hints:  # (the repeat of a step runs without estimates: it keeps the record of what was outgrown)
+                    self.last_overflow = over
+                if over:
+                    raise ops.NeighborCapacityExceeded("a neighbour list outgrew its estimated capacity; repeat the step")
         return False
 
     @staticmethod
@@ -177,15 +190,33 @@ class _NeighborCache:
         self.nth[hkey] = nth + 1
         slot = (hkey, nth)
         hint = self.hints.get(hkey) if self.use_hints else None
+        if hint is None and self.use_hints:
+            # a class the previous step did not search: most often the SAME search whose point sets have drifted across a size
+            # class boundary (half octaves: the lattices of a spreading scene cross one every few dozen steps, and an exact
+            # search -- a host round trip in the middle of the step -- each time showed in the 2-D rollouts' p99).  Take the
+            # longest row of the previous step's searches with this radius and these flags one size class away, the largest of
+            # them if there are several: a stride that is too wide costs memory, never a repeated step.
+            near = [v for k, v in self.hints.items() if k[0] == hkey[0] and k[3:] == hkey[3:]
+                    and abs(k[1] - hkey[1]) <= 1 and abs(k[2] - hkey[2]) <= 1]
+            if near:
+                hint = max(near)
         if hint is not None:
             # Padded rows of row_stride(longest row of the previous step) entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
             # stride is detected at the end of the step (one sync) and the step is repeated with the exact search.
-            res = frs(points, queries, radius, hash_table=table, row_stride=row_stride(hint), capacity_hint=self.caps.get(slot))
-            self.caps[slot] = getattr(res, "capacity", None)
+            stride, total = row_stride(hint), self.totals.get(slot)
+            if total is not None and queries.shape[0] * stride > 4 * total + (1 << 22):
+                # ... unless the padded rows would be mostly air: a scene that has dissolved into spray (the 100k dam break
+                # after ~40 steps: three times as many lattice points as at the start, most of them around single droplets,
+                # next to a bulk whose rows still hold 2,700 entries) took 6 GB per list and 34 GB per step that way.  Then
+                # count + scan + write into a buffer sized from the previous step's pairs -- still no host round trip.
+                res = frs(points, queries, radius, hash_table=table, capacity_hint=total + total // 4)
+            else:
+                res = frs(points, queries, radius, hash_table=table, row_stride=stride, capacity_hint=self.caps.get(slot))
+                self.caps[slot] = getattr(res, "capacity", None)
         else:
             res = frs(points, queries, radius, hash_table=table)
-        self.pending.append((hkey, res))
+        self.pending.append((hkey, slot, res))
         self.lists[key] = res
         self.slot_of[key] = slot
         self._consumer(key, res)
