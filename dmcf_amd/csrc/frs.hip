@@ -461,6 +461,9 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
             // One LDS round trip instead of the six dependent ds_bpermute steps of a binary search (measured:
             // 3.8 -> 3.1 ms for a 307M-pair list).
             auto locate = [&](int32_t f0, uint32_t* mk) -> int32_t {
+#ifdef FRS_X_NOLOCATE
+                return (__builtin_amdgcn_readfirstlane(rel) + f0 + lane) & 0xfffff;
+#endif
                 const uint32_t tag = (uint32_t)(++mark_tag) << 8;
                 const int32_t sl = excl - f0;
                 if (len > 0 && sl >= 0 && sl < kWave) mk[sl] = tag | (uint32_t)lane;
@@ -474,7 +477,11 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
                 run = wave_inclusive_max(run);
                 run = max(run, carry);
                 carry = __builtin_amdgcn_readlane(run, kWave - 1);
+#ifdef FRS_X_NOLOCATE
+                return __builtin_amdgcn_readfirstlane(rel) + f0 + lane;
+#else
                 return __shfl(rel, run, kWave) + f0 + lane;
+#endif
             };
             auto test = [&](int32_t f0, const float4& p) {
                 const int32_t f = f0 + lane;

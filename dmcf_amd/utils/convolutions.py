@@ -102,7 +102,7 @@ class _NeighborCache:
                     rs = r.neighbors_row_splits
                     return torch.stack([torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(()), rs[-1]])
                 vals = torch.stack([stats(r) for _, _, r in pending]).tolist()
-                fresh = {}
+                fresh, tot = {}, {}
                 over = []
                 for (hkey, slot, r), (mx, total) in zip(pending, vals):
                     if isinstance(r, ops.PaddedNeighborList):
@@ -111,13 +111,15 @@ class _NeighborCache:
                     elif r.overflowed(total):
                         over.append((hkey, "pairs", r.capacity, int(total)))
                     fresh[hkey] = max(fresh.get(hkey, 0), int(mx))  # (searches of one class share the longest of their rows)
-                    self.totals[slot] = int(total)
+                    tot[slot] = int(total)
                 # estimates come from the PREVIOUS step only: a class this step did not search is forgotten (its next search runs
                 # the exact two passes once).  Keeping old entries let one search inherit another's: in the dam break the
                 # lattices grow through the half-octave size classes, and at step 81 the s0 -> s2 list (2,300-entry rows)
                 # arrived in the class the s2 -> s1 list (300) had left 30 steps earlier -- a repeated step.
                 self.hints.clear()
                 self.hints.update(fresh)
+                self.totals.clear()
+                self.totals.update(tot)
                 if over or self.use_hints:  # (the repeat of a step runs without estimates: it keeps the record of what was outgrown)
                     self.last_overflow = over
                 if over:
@@ -190,16 +192,10 @@ class _NeighborCache:
         self.nth[hkey] = nth + 1
         slot = (hkey, nth)
         hint = self.hints.get(hkey) if self.use_hints else None
-        if hint is None and self.use_hints:
-            # a class the previous step did not search: most often the SAME search whose point sets have drifted across a size
-            # class boundary (half octaves: the lattices of a spreading scene cross one every few dozen steps, and an exact
-            # search -- a host round trip in the middle of the step -- each time showed in the 2-D rollouts' p99).  Take the
-            # longest row of the previous step's searches with this radius and these flags one size class away, the largest of
-            # them if there are several: a stride that is too wide costs memory, never a repeated step.
-            near = [v for k, v in self.hints.items() if k[0] == hkey[0] and k[3:] == hkey[3:]
-                    and abs(k[1] - hkey[1]) <= 1 and abs(k[2] - hkey[2]) <= 1]
-            if near:
-                hint = max(near)
+        # (A class the previous step did not search -- a new layer form, or the same search whose point sets drifted across a size
+        # class boundary -- runs the exact two-pass search once.  Borrowing the stride of a neighbouring class was tried: it
+        # saves that step's host round trip, but a borrowed 2,700-entry stride for 300,000 rows is a blind multi-GB request
+        # -- the dam break went from 0 to 3 - 12 fresh device blocks per rollout.)
         if hint is not None:
             # Padded rows of row_stride(longest row of the previous step) entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the

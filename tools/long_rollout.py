@@ -41,6 +41,8 @@ def main():
     ap.add_argument("steps", type=int)
     ap.add_argument("--oracle-steps", type=int, default=5)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--gc", action="store_true", help="diagnostic: leave Python's cyclic garbage collector on (the loop otherwise runs "
+                                                      "as Simulator.run_rollout does: inside pipelines.simulator.steady_steps)")
     args = ap.parse_args()
     from dmcf_amd import models
     from dmcf_amd.pipelines import Simulator
@@ -59,6 +61,12 @@ def main():
     allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
     t_all = time.time()
     for t in range(args.steps):
+        if not args.gc and t == 4:
+            from dmcf_amd.pipelines.simulator import steady_steps
+            steady = steady_steps()
+            steady.__enter__()
+        if not args.gc and t > 4:
+            steady.tick()
         before = [None if x is None else x.cpu().numpy() for x in state] if t < args.oracle_steps else None
         a0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
         rep0 = sim.repeated_steps
