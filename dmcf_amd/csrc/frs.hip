@@ -257,17 +257,6 @@ __global__ __launch_bounds__(256) void frs_rank_and_place(const float* __restric
     sorted[b + rank] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int32_t)i));
 }
 
-// inclusive max-scan of non-negative ints over the 64 lanes with DPP row shifts / broadcasts (no LDS traffic)
-__device__ __forceinline__ int wave_inclusive_max(int v) {
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false));  // row_shr:1
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false));  // row_shr:2
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false));  // row_shr:4
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false));  // row_shr:8
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 #ifndef FRS_WIN
 #define FRS_WIN 4
 #endif
@@ -453,35 +442,35 @@ __device__ __forceinline__ int32_t frs_scan(float qx, float qy, float qz, const 
             const int32_t total = __builtin_amdgcn_readlane(incl, kWave - 1);
             const int32_t excl = incl - len;
             const int32_t rel = start - excl;  // candidate c of this run sits at sorted[rel + flat]
-            int carry = 0;                     // the run that contains the first flat index of the window
-            // Which run does flat index f fall into?  Every non-empty run that STARTS inside the window
-            // [f0, f0 + 64) drops its number at its start slot of a per-wave LDS array (tagged with the window
-            // counter so the array never needs clearing); an inclusive max-scan over the lanes (DPP, no LDS)
-            // then carries the latest start to every slot, and `carry` covers the slots before the first start.
-            // One LDS round trip instead of the six dependent ds_bpermute steps of a binary search (measured:
-            // 3.8 -> 3.1 ms for a 307M-pair list).
+            // Which run does flat index f fall into?  The non-empty runs are numbered consecutively in lane order (ballot +
+            // mbcnt) and leave their `rel` in a 64-entry per-wave LDS table under that number.  Every non-empty run that STARTS
+            // inside the window [f0, f0 + 64) tags its start slot of a per-wave LDS array (the tag is the window counter, so
+            // the array never needs clearing); a ballot over the slots gives the mask of starts, and the run of slot l is
+            // (runs started before the window) + (starts at slots <= l) - 1: one LDS round trip, two mbcnt and a table read.
+            // (Round 1: a 6-step ds_bpermute binary search, 3.8 ms for a 307M-pair list; rounds 2 - 3: the start slots carried
+            // the run's LANE and a 6-step DPP max-scan spread it over the slots, 3.1 ms, a fifth of the loop's instructions
+            // and 27 s_nops per four windows behind the DPP hazards.)
+            const unsigned long long nonempty = __ballot(len > 0);
+            const int crun = __builtin_amdgcn_mbcnt_hi((unsigned)(nonempty >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)nonempty, 0));
+            int32_t* relT = (int32_t*)(marks + kWin * kWave);
+            if (len > 0) relT[crun] = rel;
+            int started = 0;                   // non-empty runs that start before the current window
             auto locate = [&](int32_t f0, uint32_t* mk) -> int32_t {
-#ifdef FRS_X_NOLOCATE
-                return (__builtin_amdgcn_readfirstlane(rel) + f0 + lane) & 0xfffff;
-#endif
-                const uint32_t tag = (uint32_t)(++mark_tag) << 8;
+                const uint32_t tag = (uint32_t)(++mark_tag);
                 const int32_t sl = excl - f0;
-                if (len > 0 && sl >= 0 && sl < kWave) mk[sl] = tag | (uint32_t)lane;
+                if (len > 0 && sl >= 0 && sl < kWave) mk[sl] = tag;
                 // lanes talk to each other through LDS here: without a (wavefront-scope) fence the compiler may keep
                 // using this lane's own last value of mk[lane] (seen: it sank the load into the store's branch)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t mv = mk[lane];
-                int run = ((mv & ~255u) == tag) ? (int)(mv & 255u) : 0;
-                run = wave_inclusive_max(run);
-                run = max(run, carry);
-                carry = __builtin_amdgcn_readlane(run, kWave - 1);
-#ifdef FRS_X_NOLOCATE
-                return __builtin_amdgcn_readfirstlane(rel) + f0 + lane;
-#else
-                return __shfl(rel, run, kWave) + f0 + lane;
-#endif
+                const bool mine = mk[lane] == tag;
+                const unsigned long long starts = __ballot(mine);
+                const int upto = __builtin_amdgcn_mbcnt_hi((unsigned)(starts >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)starts, 0)) +
+                                 (mine ? 1 : 0);
+                const int run = max(started + upto - 1, 0);
+                started += __popcll(starts);
+                return relT[run] + f0 + lane;
             };
             auto test = [&](int32_t f0, const float4& p) {
                 const int32_t f = f0 + lane;
@@ -550,7 +539,7 @@ __global__ __launch_bounds__(256) void frs_query(const float* __restrict__ queri
                                                  int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits,
                                                  int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist,
                                                  int64_t capacity, uint8_t* __restrict__ qflags) {
-    __shared__ uint32_t marks[4][kWin * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave + kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;  // whole wave leaves
     // a row that does not fit the caller's buffers is skipped as a whole (the caller detects the overflow from
@@ -579,7 +568,7 @@ __global__ __launch_bounds__(256) void frs_query_padded(const float* __restrict_
                                                         int32_t* __restrict__ row_count, int32_t* __restrict__ nbr_index,
                                                         float* __restrict__ nbr_dist, int32_t* __restrict__ max_count,
                                                         uint8_t* __restrict__ qflags) {
-    __shared__ uint32_t marks[4][kWin * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave + kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
@@ -605,7 +594,7 @@ __global__ __launch_bounds__(256) void frs_window_sum(const float* __restrict__ 
                                                       const FrsHeader* __restrict__ h, const uint32_t* __restrict__ cell_start,
                                                       const float4* __restrict__ sorted, float radius, int flags, int window,
                                                       float* __restrict__ out, uint8_t* __restrict__ qflags) {
-    __shared__ uint32_t marks[4][kWin * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave + kWave];
     const int64_t qi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (qi >= m) return;
     const float qx = queries[3 * qi], qy = queries[3 * qi + 1], qz = queries[3 * qi + 2];
@@ -633,7 +622,7 @@ __global__ __launch_bounds__(256) void frs_fix(const float* __restrict__ queries
                                                int32_t* __restrict__ counts, const int64_t* __restrict__ row_splits, int64_t stride,
                                                int32_t* __restrict__ nbr_index, float* __restrict__ nbr_dist, int64_t capacity,
                                                int window, float* __restrict__ out) {
-    __shared__ uint32_t marks[4][kWin * kWave];
+    __shared__ uint32_t marks[4][kWin * kWave + kWave];
     const int lane = lane_id();
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);

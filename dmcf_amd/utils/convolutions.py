@@ -193,9 +193,10 @@ class _NeighborCache:
         slot = (hkey, nth)
         hint = self.hints.get(hkey) if self.use_hints else None
         # (A class the previous step did not search -- a new layer form, or the same search whose point sets drifted across a size
-        # class boundary -- runs the exact two-pass search once.  Borrowing the stride of a neighbouring class was tried: it
-        # saves that step's host round trip, but a borrowed 2,700-entry stride for 300,000 rows is a blind multi-GB request
-        # -- the dam break went from 0 to 3 - 12 fresh device blocks per rollout.)
+        # class boundary -- runs the exact two-pass search once.  Borrowing the stride and pair count of a search one class
+        # away was tried in two forms (the largest of the candidates; a unique candidate only): it saves that step's host round
+        # trip -- 0.2 ms per step of the 1M bench window, where the lattices grow through the classes -- but the borrowed sizes
+        # are fresh block sizes for the allocator: the dam break went from 0 to 2 - 12 device mallocs per rollout.)
         if hint is not None:
             # Padded rows of row_stride(longest row of the previous step) entries: ONE candidate scan per query, no
             # count pass, no prefix scan, no host round trip (HBM is plentiful: 288 GB).  A row that outgrows the
