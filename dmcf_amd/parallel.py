@@ -99,6 +99,13 @@ class Comm:
         recv = self.all_to_all(send, recv_counts=recv_counts)
         return lambda: recv
 
+    def exchange_rows_start(self, rows, send_counts, recv_counts):
+        """The exchange of a ghost plan: ``rows`` [sum(send_counts), C] already in peer order (one gather by the plan's
+        concatenated send list), both count lists known on the host.  Returns a function that waits and returns the received
+        rows in one piece [sum(recv_counts), C] -- no per-peer gathers, splits or concatenations (a step has 18 of these)."""
+        wait = self.all_to_all_start(list(torch.split(rows, [int(c) for c in send_counts], dim=0)), recv_counts)
+        return lambda: torch.cat(wait(), dim=0)
+
 
 class TorchDistComm(Comm):
     """torch.distributed communicator: counts then payload, each one all_to_all_single.  Backend "nccl" (= RCCL over xGMI)
@@ -172,6 +179,31 @@ class TorchDistComm(Comm):
                 work.wait()  # (the current stream waits; ``inp`` / ``out`` stay referenced by this closure until then)
             return [p.reshape((p.shape[0],) + trailing) for p in torch.split(out, rc, dim=0)]
         return wait
+
+
+def _torchdist_exchange_rows_start(self, rows, send_counts, recv_counts):
+    if self.stage:
+        return Comm.exchange_rows_start(self, rows, send_counts, recv_counts)
+    sc, rc = [int(c) for c in send_counts], [int(c) for c in recv_counts]
+    rows = rows.contiguous()
+    out = torch.empty((sum(rc),) + tuple(rows.shape[1:]), dtype=rows.dtype, device=rows.device)
+    work = self.dist.all_to_all_single(out, rows, output_split_sizes=rc, input_split_sizes=sc, group=self.group, async_op=True)
+
+    def wait():
+        st = stats()
+        if st.profile:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work.wait()
+            e1.record()
+            st.wait_events.append((e0, e1))
+        else:
+            work.wait()  # (``rows`` / ``out`` stay referenced by this closure until then)
+        return out
+    return wait
+
+
+TorchDistComm.exchange_rows_start = _torchdist_exchange_rows_start
 
 
 class _LocalHub:
@@ -340,8 +372,21 @@ FORCE_COMM = os.environ.get("DMCF_SHARD_FORCE_COMM") == "1"
 
 
 def _bounds_tensor(decomp, ranks, device):
-    """float32 [len(ranks), 3, 2]: (lo, hi) per axis of the blocks of ``ranks``."""
-    return torch.tensor([[[lo, hi] for lo, hi in decomp.bounds(r)] for r in ranks], dtype=torch.float32, device=device)
+    """float32 [len(ranks), 3, 2]: (lo, hi) per axis of the blocks of ``ranks`` (kept per decomposition: a tensor made from
+    Python numbers is a blocking host -> device copy, and a step asks for the same few dozens of times)."""
+    cache = decomp.__dict__.setdefault("_bounds_cache", {})
+    key = (tuple(ranks), str(device))
+    t = cache.get(key)
+    if t is None:
+        t = cache[key] = torch.tensor([[[lo, hi] for lo, hi in decomp.bounds(r)] for r in ranks], dtype=torch.float32, device=device)
+    return t
+
+
+def _gap2_all(pos, bounds):
+    """Squared distances of every pos[i] to every block of ``bounds`` ([P, 3, 2]) -> [P, n]; per pair the arithmetic of _gap2."""
+    g = torch.clamp(torch.maximum(bounds[:, None, :, 0] - pos[None], pos[None] - bounds[:, None, :, 1]), min=0.0)
+    g = g * g
+    return (g[..., 0] + g[..., 1]) + g[..., 2]
 
 
 def _gap2(pos, bounds_rows):
@@ -389,8 +434,7 @@ class GhostPlan:
                         near |= (hi - x) <= self.width
                 cand = torch.nonzero(near).reshape(-1)
                 cpos = pos_owned[cand]
-                b = _bounds_tensor(decomp, peers, dev)                      # [P, 3, 2]
-                flags = torch.stack([_gap2(cpos, b[i:i + 1].expand(cpos.shape[0], 3, 2)) <= w2 for i in range(len(peers))])
+                flags = _gap2_all(cpos, _bounds_tensor(decomp, peers, dev)) <= w2   # [P, candidates]
                 hit = torch.nonzero(flags)                                  # rows ordered by peer, then by point
                 counts = host(torch.bincount(hit[:, 0], minlength=len(peers)))
                 rows = cand[hit[:, 1]]
@@ -420,22 +464,34 @@ class GhostPlan:
         w2 = self.width * self.width
         self._pos_owned = pos_owned
         counts = []
+        # What does not depend on the narrower width is formed once per wide plan: its send rows in one piece with their peer
+        # number and their squared distance to that peer's block, and the same for the received copies and this rank's block.
+        geo = parent.__dict__.get("_derive_geo")
+        if geo is None:
+            peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
+            rows = seg = sgap = None
+            if peers:
+                rows = torch.cat([parent.send_idx[r] for r in peers])
+                seg = torch.repeat_interleave(torch.arange(len(peers), device=dev),
+                                              torch.tensor([parent.send_idx[r].shape[0] for r in peers], device=dev))
+                sgap = _gap2(pos_owned[rows], _bounds_tensor(decomp, peers, dev)[seg])
+            g = parent.ghost_pos
+            src = rgap = None
+            if g.shape[0]:
+                src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
+                rgap = _gap2(g, _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2))
+            geo = parent.__dict__["_derive_geo"] = (peers, rows, seg, sgap, src, rgap)
+        self._peers, rows, seg, sgap, src, rgap = geo
         # sender side: the rows of the wide lists that are within the narrower width of the peer's block
-        self._peers = [r for r in range(world) if parent.send_idx[r].shape[0] > 0]
         if self._peers:
-            rows = torch.cat([parent.send_idx[r] for r in self._peers])
-            seg = torch.repeat_interleave(torch.arange(len(self._peers), device=dev),
-                                          torch.tensor([parent.send_idx[r].shape[0] for r in self._peers], device=dev))
-            keep = _gap2(pos_owned[rows], _bounds_tensor(decomp, self._peers, dev)[seg]) <= w2
+            keep = sgap <= w2
             counts.append(torch.bincount(seg[keep], minlength=len(self._peers)))
             self._rows = rows[keep]
         # receiver side: the same test on the received copies
         g = parent.ghost_pos
         self._recv = g.shape[0] > 0
         if self._recv:
-            src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
-            mine = _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2)
-            keep = _gap2(g, mine) <= w2
+            keep = rgap <= w2
             self.in_parent = torch.nonzero(keep).reshape(-1)
             counts.append(torch.bincount(src[keep], minlength=world))
             self.ghost_pos = g[self.in_parent]
@@ -488,16 +544,18 @@ class GhostPlan:
         no host round trip (the counts are the plan's)."""
         if self.comm.world == 1 and not FORCE_COMM:
             return feats_owned
-        recv = self.comm.all_to_all([feats_owned[i] for i in self.send_idx], recv_counts=self.recv_counts)
-        return torch.cat([feats_owned] + recv, dim=0).contiguous()
+        return self.extend_start(feats_owned)()
 
     def extend_start(self, feats_owned):
         """:meth:`extend`, started now and finished by the returned function (the exchange overlaps whatever is enqueued in
         between)."""
         if self.comm.world == 1 and not FORCE_COMM:
             return lambda: feats_owned
-        wait = self.comm.all_to_all_start([feats_owned[i] for i in self.send_idx], self.recv_counts)
-        return lambda: torch.cat([feats_owned] + wait(), dim=0).contiguous()
+        cat = self.__dict__.get("_send_cat")
+        if cat is None:
+            cat = self._send_cat = (torch.cat(self.send_idx), [int(i.shape[0]) for i in self.send_idx])
+        wait = self.comm.exchange_rows_start(feats_owned[cat[0]], cat[1], self.recv_counts)
+        return lambda: torch.cat([feats_owned, wait()], dim=0)
 
     def extend_from(self, wide, wide_ext):
         """``extend`` without communication, from the same features already extended by a wider plan of the same point set:
