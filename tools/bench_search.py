@@ -29,4 +29,11 @@ for name, pts, qs, R in [("s0->s0 R0.1", s0, s0, 0.1), ("s0->s1 R0.2", s0, s1, 0
     total = r.neighbors_index.shape[0]
     t2 = timed(lambda: ops.fixed_radius_search(pts, qs, R, hash_table=table))
     t1 = timed(lambda: ops.fixed_radius_search(pts, qs, R, hash_table=table, capacity_hint=total))
-    print(f"{name}: {total/1e6:7.1f}M pairs  exact {t2:6.2f} ms (incl. host round trip)  estimated {t1:6.2f} ms", flush=True)
+    # the rollout's form: ONE pass into padded rows (stride from the longest row, as the per-step cache would choose it), index only
+    from dmcf_amd.utils.convolutions import row_stride
+    stride = row_stride(int(torch.diff(r.neighbors_row_splits).max()))
+    pad = lambda: ops.fixed_radius_search(pts, qs, R, hash_table=table, row_stride=stride, return_distances=False)
+    pad()
+    t0 = timed(pad)
+    print(f"{name}: {total/1e6:7.1f}M pairs  exact {t2:6.2f} ms (incl. host round trip)  estimated {t1:6.2f} ms  padded {t0:6.2f} ms "
+          f"({qs.shape[0]} queries, stride {stride})", flush=True)

@@ -67,12 +67,25 @@ def pmc(src, tag, P):
     case_of = dict(pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC")
     lines = [f"# SQ counters of every kernel above 3 % of the 1M step ({tag})\n",
              "`tools/pmc_kernel.sh`: three separate `rocprofv3 --kernel-trace --pmc` passes per kernel (no other trace domain), on the micro-benchmark "
-             "case that exercises the kernel (`tools/microbench.py`, 1 + 5 launches; the search: 4 steps of `bench.py`).  Derived per launch: "
+             "case that exercises the kernel (`tools/microbench.py`, 1 + 5 launches; the search: `tools/bench_search.py`, the lattice form: "
+            "`tools/bench_lattice.py`, pairs and ms averaged over the lists / layers the kernel ran on).  Derived per launch: "
              "SQ_INSTS_* / launches / pairs = wave instructions per neighbour pair; busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) resp. "
              "SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of a launch (1024 SIMDs x 2.4 GHz x its time).\n",
              "| kernel | case | pairs | ms | VALU / pair | SALU / pair | LDS / pair | VMEM / pair | matrix instr / pair | VALU busy | matrix busy | waves per SIMD | LDS bank-conflict cycles / LDS cycles |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     raw = {}
+    # the search (tools/bench_search.py: 1 + 5 padded launches per list) and the lattice form (tools/bench_lattice.py: 1 + 5
+    # launches per layer): pairs / ms per launch averaged over the lists / layers the kernel ran on
+    special = {}
+    if os.path.exists(f"{src}/search.log"):
+        rows = [(float(l.split("M pairs")[0].split(":")[1]) * 1e6, float(l.split("padded")[1].split("ms")[0])) for l in open(f"{src}/search.log") if "padded" in l]
+        if rows:
+            special["frs_query_padded"] = ("5 lists + s2->s2", sum(r[0] for r in rows) / len(rows), sum(r[1] for r in rows) / len(rows))
+    if os.path.exists(f"{src}/lattice.log"):
+        rows = [(float(l.split("pairs")[1].split("M")[0]) * 1e6, float(l.split("lattice")[1].split("ms")[0])) for l in open(f"{src}/lattice.log") if "lattice" in l and "pairs" in l]
+        if len(rows) == 3:
+            special["lat_conv_kernel<1, 2>"] = ("s1->s1 8->16, s1->s2 8->8 (stencil offsets x outputs as pairs)", (rows[0][0] + rows[1][0]) / 2, (rows[0][1] + rows[1][1]) / 2)
+            special["lat_conv_kernel<1, 1>"] = ("s2->s2 4->8", rows[2][0], rows[2][1])
     for f in sorted(glob.glob(f"{src}/pmc/*.json")):
         label = os.path.basename(f)[:-5]
         res = json.load(open(f))
@@ -82,6 +95,8 @@ def pmc(src, tag, P):
             case = case_of.get(label)
             if case and case in mb:
                 pairs, ms = mb[case]
+            elif k.split("::")[-1] in special:
+                case, pairs, ms = special[k.split("::")[-1]]
             else:
                 pairs, ms = None, None
             if pairs:
@@ -103,8 +118,8 @@ def rollouts(src, tag, P):
             "break as specified (h = 0.05, jitter seed 0, open 2-layer tank), Liquid3d weights; configs 2 / 3: the architectures with seeded "
             "stand-in weights (their checkpoints are not shipped) on ~2k / 3.6k-particle 2-D boxes.  Every step: finite, momentum residual = "
             "|sum of the ASCC output over fluid + boundary| / sum of |.|; the first 5 steps against the CPU oracle fed with the HIP path's own state.  "
-            "The searches reproduce the reference's visibility (DMCF_FRS_OPEN3D_CORNER_VOXELS): in the rare steps where a query loses its own voxel "
-            "the pair terms of that particle do not cancel -- in the reference as here -- and the residual rises to ~1 / (number of particles).\n",
+            "The searches return the set of the distance test (the default: symmetric lists).  The loop runs as Simulator.run_rollout does "
+            "(pipelines.simulator.steady_steps: Python's cyclic GC off).\n",
             "| rollout | particles (+boundary) | steps | all finite | worst momentum residual | worst oracle rel err (5 steps) | repeated steps | "
             "steps with a fresh device allocation (after step 3) | median ms/step | p99 ms | max ms | reserved GiB at the end |",
             "|---|---|---:|---|---:|---:|---:|---:|---:|---:|---:|---:|"]

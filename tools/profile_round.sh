@@ -24,9 +24,18 @@ bash tools/pmc_kernel.sh $P cls2n_L6 cconv_cls -- env ONLY=L6 python tools/micro
 bash tools/pmc_kernel.sh $P cls4_LP cconv_cls -- env ONLY=LP python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P z3_L14 cconv_z3 -- env ONLY=L14 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P direct_ASCC cconv_direct -- env ONLY=ASCC python tools/microbench.py >> $OUT/pmc.txt 2>&1
-bash tools/pmc_kernel.sh $P frs frs_query_padded -- python bench.py --steps 2 --warmup 2 --cpu-side 0 >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P frs frs_query_padded -- python tools/bench_search.py >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P lat lat_conv_kernel -- python tools/bench_lattice.py >> $OUT/pmc.txt 2>&1
+python tools/bench_search.py > $OUT/search.log 2>&1
+python tools/bench_lattice.py > $OUT/lattice.log 2>&1
 timeout 600 python tools/microbench.py > $OUT/microbench.log 2>&1
 for r in "liquid3d_dam 200" "waterramps 600" "wbcsph 3200"; do set -- $r; timeout 900 python tools/long_rollout.py $1 $2 --out $OUT/rollout_$1.json >> $OUT/rollouts.log 2>&1; done
-timeout 900 python tools/ghost_fraction.py 100 2 2 2 2 > $OUT/ghost_weak.json 2> $OUT/ghost_weak.log
-timeout 900 python tools/ghost_fraction.py 50 2 2 2 3 > $OUT/ghost_strong.json 2> $OUT/ghost_strong.log
+timeout 900 python tools/ghost_fraction.py 100 2 2 2 4 > $OUT/ghost_weak.json 2> $OUT/ghost_weak.log
+timeout 900 python tools/ghost_fraction.py 50 2 2 2 4 > $OUT/ghost_strong.json 2> $OUT/ghost_strong.log
+# kernel time per virtual rank (rocprofv3 kernel trace of 4 steps) for 1 / 2 / 4 / 8 ranks: the input of DESIGN section 6's scaling model
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for g in "1 1 1" "2 1 1" "2 2 1" "2 2 2"; do n=$(echo $g | tr -d " ")
+  rocprofv3 --kernel-trace --stats -d $OUT/vprof_$n -o p -- python tools/ghost_fraction.py 100 $g 4 > /dev/null 2> $OUT/vranks_$n.log
+  python tools/rocpd_stats.py $(ls $OUT/vprof_$n/*.db | head -1) $OUT/vranks_stats_$n.md > /dev/null; rm -rf $OUT/vprof_$n
+done
 tail -1 $OUT/bench.log | cut -c1-300; tail -1 $OUT/bench_driver.log | cut -c1-200
