@@ -384,6 +384,49 @@ def test_estimated_neighbour_buffers_recover_from_overflow(dev):
     assert torch.equal(a[0], b[0])
 
 
+def test_lists_of_a_scene_with_spray_take_the_estimated_csr_form(dev):
+    """A bulk whose rows hold thousands of entries next to thousands of isolated droplets (the 100k dam break after ~40 steps):
+    padded rows -- every query reserves the longest row's stride -- would be mostly air (34 GB per step there).  From the
+    second step on the per-step cache sees that from the previous step's pair counts and enqueues count + scan + write into
+    buffers sized from them instead (no host round trip either): same positions bit for bit as the exact searches, no repeated
+    step, and a fraction of the memory."""
+    from dmcf_amd import ops
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.utils.convolutions import neighbor_hints
+    from tools import configs, scenes
+    w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
+    scene = scenes.box_scene(14, seed=3)
+    rng = np.random.default_rng(8)
+    g = np.stack(np.meshgrid(*[np.arange(16)] * 3, indexing="ij"), -1).reshape(-1, 3)[:3000]
+    spray = (np.float32([3.0, 3.0, 3.0]) + np.float32(1.1) * g + rng.uniform(-0.05, 0.05, size=(3000, 3))).astype(np.float32)
+    scene = dict(scene, pos=np.concatenate([scene["pos"], spray]), vel=np.concatenate([scene["vel"], np.zeros_like(spray)]))
+    sim = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+    state = scenes.model_inputs(scene, device=dev)
+    outs, kinds = [], []
+    for _ in range(3):
+        torch.cuda.reset_peak_memory_stats(dev)
+        ops.timer = ops.LaunchTimer()
+        state = sim.step([state])[0]
+        recs, ops.timer = ops.timer.results(), None
+        kinds.append([k for k, _, _ in recs if k.startswith("frs_")])
+        outs.append((state[0].clone(), torch.cuda.max_memory_allocated(dev)))
+    assert sim.repeated_steps == 0
+    # steps 2 and 3 run on estimates (every class of step 3 was searched in step 2: nothing falls back to the exact form): some
+    # lists padded, some as count + write into estimated buffers
+    assert "frs_search_padded" in kinds[2] and "frs_write" in kinds[2] and kinds[1] == kinds[2], kinds
+    fresh = Simulator(_build(configs.LIQUID3D, w, dev), device="cuda")
+    neighbor_hints().clear()
+    ref = scenes.model_inputs(scene, device=dev)
+    os.environ["DMCF_NO_ESTIMATE"] = "1"
+    try:
+        for t in range(3):
+            ref = fresh.step([ref])[0]
+            assert torch.equal(ref[0], outs[t][0]), f"step {t}"
+    finally:
+        os.environ.pop("DMCF_NO_ESTIMATE")
+    print("peak allocated per step (MiB):", [round(m / 2 ** 20) for _, m in outs])
+
+
 def test_density_feature_flags_2d(dev):
     """dens_feats + pres_feats + dens_norm (pbf_model.py:351-365,421-431; hrnet.py:87-89) on the WaterRamps
     architecture: fused density kernel, PointSampling to the coarse scales, doubled layer inputs."""
