@@ -21,7 +21,8 @@ import torch
 from .. import ops
 from ..utils import convolutions as _convs
 from ..utils.convolutions import ContinuousConv, PointSampling
-from ..utils.tools.losses import compute_density, compute_pressure, get_dilated_pos, get_window_func
+from ..utils.tools.losses import (compute_density, compute_pressure, compute_transformed_dx, get_dilated_pos,
+                                  get_window_func)
 from .base_model import BaseModel, Dense
 
 
@@ -51,9 +52,7 @@ class PBFNet(BaseModel):
         super().__init__(name=name, **kwargs)
         if dens_radius is None:
             dens_radius = particle_radii
-        if equivar:
-            # False in every shipped config; needs compute_transformed_dx + quaternion features (losses.py:330-364)
-            raise NotImplementedError("equivar=True is not implemented (SURVEY.md section 2 row 14)")
+        self.equivar = equivar  # pbf_model.py:92 (False in every shipped config)
         # NN setup (pbf_model.py:79-97)
         self.kernel_size = kernel_size
         self.channel = channels
@@ -99,6 +98,9 @@ class PBFNet(BaseModel):
         self.obs_dense = Dense(units=channels, name="obs_dense")
         if dens_norm:  # pbf_model.py:177-181
             self.sampling = PointSampling(name="sampling", window_function=get_window_func(window_dens), normalize=True)
+        if self.equivar:  # :183-189 (rot_dens is built by the reference too, its use is commented out there: :458-459)
+            self.scale_dens = Dense(units=1, name="scale")
+            self.rot_dens = Dense(units=4, name="rot")
         if self.use_pre_adv:  # pbf_model.py:154-175
             self.adv_convs = torch.nn.ModuleList([
                 self.get_cconv(name="adv_conv0", filters=channels, activation=None, window_func=self.window,
@@ -401,6 +403,10 @@ class PBFNet(BaseModel):
             self.num_fluid_neighbors = counts[:pcnt]
 
         out = prev
+        if self.equivar:  # :456-463: the network's output scales the mean offset to the neighbours (rot stays None there too)
+            if self.shard is not None:
+                raise NotImplementedError("equivar in a sharded step (its search has no ghost plan)")
+            out = compute_transformed_dx(self.all_pos, self.scale_dens(out), None, radius=self.particle_radii[0])
         if out.shape[-1] == 1:  # :466-469
             out = out.repeat(1, 3)
         elif out.shape[-1] == 2:

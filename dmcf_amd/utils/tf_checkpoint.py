@@ -153,6 +153,9 @@ def model_weight_items(model):
         items.append((cands, conv))
     items.append((["model/fluid_dense"], model.fluid_dense))
     items.append((["model/obs_dense"], model.obs_dense))
+    if getattr(model, "equivar", False):  # models/pbf_model.py:183-189
+        items.append((["model/scale_dens"], model.scale_dens))
+        items.append((["model/rot_dens"], model.rot_dens))
     for i, dense in enumerate(getattr(model, "adv_dense", []) or []):
         items.append(([f"model/adv_dense/{i}"], dense))
     denses = getattr(model, "denses", [])

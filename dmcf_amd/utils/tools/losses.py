@@ -164,6 +164,25 @@ def compute_density(out_pos, in_pos=None, radius=0.005, win=None):
     return ops.reduce_subarrays_sum(win(nns.neighbors_distance / (radius * radius)), nns.neighbors_row_splits)
 
 
+def compute_transformed_dx(pos, scale=None, rot=None, radius=0.005):
+    """losses.py:337-364: per point the MEAN over its neighbours within ``radius`` (itself included) of ``(x_j - x_i) *
+    scale_j``.  The reference's caller passes ``rot=None`` (models/pbf_model.py:458-460 has the quaternion branch commented
+    out); a rotation raises here.  The pair list comes from the fixed-radius search, the ragged sums from
+    dmcf_reduce_subarrays_sum; a point without neighbours gives 0 / 0 = NaN as tf.reduce_mean over an empty row does."""
+    from ... import ops
+    if rot is not None:
+        raise NotImplementedError("compute_transformed_dx with a rotation (quat_mean / quat_rot): the reference never passes one")
+    nns = ops.fixed_radius_search(pos, pos, float(radius), return_distances=False)
+    idx, rs = nns.neighbors_index.long(), nns.neighbors_row_splits
+    counts = torch.diff(rs)
+    row = torch.repeat_interleave(torch.arange(pos.shape[0], device=pos.device), counts, output_size=idx.shape[0])
+    dx = pos[idx] - pos[row]
+    if scale is not None:
+        dx = dx * scale[idx]
+    sums = torch.stack([ops.reduce_subarrays_sum(dx[:, k].contiguous(), rs) for k in range(dx.shape[1])], dim=1)
+    return sums / counts.to(sums.dtype).unsqueeze(1)
+
+
 def compute_pressure(out_pts, inp_pts=None, dens=None, rest_dens=3.5, stiffness=20.0, win=None):
     """losses.py:367-377 (note: the reference ignores a radius here too: compute_density's default applies)."""
     if inp_pts is None:

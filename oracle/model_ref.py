@@ -303,6 +303,15 @@ class ModelRef:
         pcnt = pos.shape[0]
         self.num_fluid_neighbors = O.reduce_subarrays_sum(np.ones(self.fluid_nns[0].shape[0], f32),
                                                           self.fluid_nns[1])[:pcnt]
+        if self.cfg.get("equivar"):  # pbf_model.py:456-463 with rot = None; losses.py:337-364
+            scale = self._dense("model/scale_dens", out)
+            idx, rs, _ = O.fixed_radius_search(self.all_pos, self.all_pos, float(self.cfg["particle_radii"][0]))
+            cnt = np.diff(rs)
+            row = np.repeat(np.arange(len(cnt)), cnt)
+            dx = ((self.all_pos[idx] - self.all_pos[row]) * scale[idx]).astype(f32)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out = (np.stack([O.reduce_subarrays_sum(np.ascontiguousarray(dx[:, k]), rs) for k in range(3)], 1)
+                       / cnt[:, None].astype(f32)).astype(f32)
         if out.shape[-1] == 1:
             out = np.repeat(out, 3, axis=-1)
         elif out.shape[-1] == 2:

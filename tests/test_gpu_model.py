@@ -438,6 +438,22 @@ def test_density_feature_flags_2d(dev):
     assert ref.dens is not None
 
 
+def test_equivar_scaled_mean_offset_head_2d(dev):
+    """``equivar: True`` (pbf_model.py:183-189,456-463; losses.py:337-364; no shipped config sets it): the network's output goes
+    through Dense(1) and scales the mean offset to the neighbours within the first radius (the quaternion branch is commented
+    out in the reference: rot = None)."""
+    from tools import configs, scenes
+    cfg = dict(configs.WATERRAMPS, equivar=True)
+    w = scenes.random_weights(cfg, seed=11)
+    cout = w["model/sym_convs/0/kernel"].shape[-1]
+    rng = np.random.default_rng(12)
+    w["model/scale_dens/kernel"] = rng.uniform(-0.5, 0.5, size=(cout, 1)).astype(np.float32)
+    w["model/scale_dens/bias"] = np.float32([0.7])
+    scene = scenes.box_scene(30, h=0.005, dim=2, origin=(-0.07, -0.07, 0.0))
+    model, ref = _compare_step(cfg, w, scene, dev, steps=2)
+    assert model.equivar and float(model.pos_correction.abs().max()) > 0
+
+
 def test_canyon_sample_with_inflow(dev):
     """The reference's demo (run_sample.py: canyon scene, Liquid3d checkpoint, inflow every other step) on frames of the
     reference's own scene file (tests/golden/canyon_crop.msgpack.zst): every step of dmcf_amd.run_sample.run_rollout
