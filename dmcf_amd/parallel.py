@@ -409,6 +409,13 @@ class GhostPlan:
     def __init__(self, comm, decomp, pos_owned, width, parent=None):
         self.comm, self.decomp = comm, decomp
         self.width = float(width) * (1.0 + 1e-5) + 1e-6  # superset slack; the search re-tests distances exactly
+        # The cut planes live in SCENE coordinates; a model with a transformation (models/pbf_model.py:252-301: translate,
+        # scale, the rotation of grav_eqvar) convolves transformed positions.  ``decomp.view`` maps those back for the
+        # ownership and ghost tests, ``decomp.inflate`` widens the halo by the largest shrink factor of the scale so that it
+        # still holds everything within ``width`` in the model's metric (ShardedSimulator.begin sets both).
+        view = getattr(decomp, "view", None)
+        self.test_pos = view(pos_owned) if view is not None else pos_owned
+        self.test_width = self.width * float(getattr(decomp, "inflate", 1.0))
         self.n_owned = pos_owned.shape[0]
         dev = pos_owned.device
         world, rank = comm.world, comm.rank
@@ -417,23 +424,23 @@ class GhostPlan:
         self.recv_counts = [0] * world
         self.in_parent = None
         self.parent = parent
-        w2 = self.width * self.width
+        w2 = self.test_width * self.test_width
         if world == 1:
             self.ghost_pos = pos_owned[:0]
             self.in_parent = empty
         elif parent is None:
-            peers = decomp.neighbours(rank, self.width)
+            peers = decomp.neighbours(rank, self.test_width)
             if peers and self.n_owned:
                 # candidates: owned points within ``width`` of one of the block's own finite faces
                 near = torch.zeros(self.n_owned, dtype=torch.bool, device=dev)
                 for k, (lo, hi) in enumerate(decomp.bounds(rank)):
-                    x = pos_owned[:, k]
+                    x = self.test_pos[:, k]
                     if lo != -float("inf"):
-                        near |= (x - lo) <= self.width
+                        near |= (x - lo) <= self.test_width
                     if hi != float("inf"):
-                        near |= (hi - x) <= self.width
+                        near |= (hi - x) <= self.test_width
                 cand = torch.nonzero(near).reshape(-1)
-                cpos = pos_owned[cand]
+                cpos = self.test_pos[cand]
                 flags = _gap2_all(cpos, _bounds_tensor(decomp, peers, dev)) <= w2   # [P, candidates]
                 hit = torch.nonzero(flags)                                  # rows ordered by peer, then by point
                 counts = host(torch.bincount(hit[:, 0], minlength=len(peers)))
@@ -461,8 +468,9 @@ class GhostPlan:
         dev = pos_owned.device
         world, rank = comm.world, comm.rank
         assert parent.parent is None and parent.n_owned == self.n_owned and self.width <= parent.width
-        w2 = self.width * self.width
+        w2 = self.test_width * self.test_width
         self._pos_owned = pos_owned
+        view = getattr(decomp, "view", None)
         counts = []
         # What does not depend on the narrower width is formed once per wide plan: its send rows in one piece with their peer
         # number and their squared distance to that peer's block, and the same for the received copies and this rank's block.
@@ -474,12 +482,12 @@ class GhostPlan:
                 rows = torch.cat([parent.send_idx[r] for r in peers])
                 seg = torch.repeat_interleave(torch.arange(len(peers), device=dev),
                                               torch.tensor([parent.send_idx[r].shape[0] for r in peers], device=dev))
-                sgap = _gap2(pos_owned[rows], _bounds_tensor(decomp, peers, dev)[seg])
+                sgap = _gap2(parent.test_pos[rows], _bounds_tensor(decomp, peers, dev)[seg])
             g = parent.ghost_pos
             src = rgap = None
             if g.shape[0]:
                 src = torch.repeat_interleave(torch.arange(world, device=dev), torch.tensor(parent.recv_counts, device=dev))
-                rgap = _gap2(g, _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2))
+                rgap = _gap2(view(g) if view is not None else g, _bounds_tensor(decomp, [rank], dev).expand(g.shape[0], 3, 2))
             geo = parent.__dict__["_derive_geo"] = (peers, rows, seg, sgap, src, rgap)
         self._peers, rows, seg, sgap, src, rgap = geo
         # sender side: the rows of the wide lists that are within the narrower width of the peer's block
@@ -524,6 +532,8 @@ class GhostPlan:
             p = GhostPlan.__new__(GhostPlan)
             p.comm, p.decomp, p.parent = wide.comm, wide.decomp, wide
             p.width = float(width) * (1.0 + 1e-5) + 1e-6
+            p.test_pos = wide.test_pos
+            p.test_width = p.width * float(getattr(wide.decomp, "inflate", 1.0))
             p.n_owned = pos_owned.shape[0]
             empty = torch.zeros(0, dtype=torch.int64, device=pos_owned.device)
             p.send_idx = [empty] * wide.comm.world
@@ -595,11 +605,11 @@ class ShardedSimulator:
         self.host_syncs_last_step = None  # device -> host reads of the last step (each one drains the queue): see Stats
         self.launch_rows = []             # (point set, radius, input rows of the launch, owned rows) per convolution of the last step
         m = model
-        for key in ("translate", "scale", "grav_eqvar"):
-            if key in m.transformation:
-                # ownership / ghost tests run on transformed positions with cuts given in scene coordinates
-                raise NotImplementedError(f"transformation {key!r} is not wired into the sharded path (the 2-D scenes that "
-                                          "use it do not amortise a halo: SURVEY.md section 8e, last row)")
+        import copy
+        # the decomposition the ghost plans test against: the caller's cut planes (scene coordinates) seen through the model's
+        # transformation (translate / scale / grav_eqvar, pbf_model.py:252-301) -- a copy per simulator, its view is set per step
+        self._mdecomp = copy.copy(decomp)
+        self._mdecomp.__dict__.pop("_bounds_cache", None)
         if m.dens_feats or m.pres_feats or m.dens_norm or m.use_pre_adv or m.use_feats:
             raise NotImplementedError("dens_feats / pres_feats / dens_norm / use_pre_adv / use_feats in the sharded path")
         if not m.use_bnds and type(m).__name__ == "SymNet":
@@ -618,9 +628,9 @@ class ShardedSimulator:
             wide = self._wide[name]
             if float(width) * (1.0 + 1e-5) + 1e-6 > wide.width:
                 raise RuntimeError(f"ghost plan of {name!r} asked for width {width} > the step's widest {wide.width}")
-            plan = GhostPlan(self.comm, self.decomp, self._sets[name], width, parent=wide)
+            plan = GhostPlan(self.comm, self._mdecomp, self._sets[name], width, parent=wide)
             if os.environ.get("DMCF_SHARD_CHECK") == "1" and self.comm.world > 1:
-                direct = GhostPlan(self.comm, self.decomp, self._sets[name], width)
+                direct = GhostPlan(self.comm, self._mdecomp, self._sets[name], width)
                 if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
                         not torch.equal(a, b) for a, b in zip(direct.send_idx, plan.send_idx)):
                     raise RuntimeError("a derived ghost plan differs from the directly built one")
@@ -632,7 +642,7 @@ class ShardedSimulator:
         """Register an owned point set and build its widest ghost plan (the only one that communicates)."""
         self._sets[name] = pos
         self._name_of[id(pos)] = name
-        wide = GhostPlan(self.comm, self.decomp, pos, width)
+        wide = GhostPlan(self.comm, self._mdecomp, pos, width)
         self._wide[name] = wide
         self._plans[(name, round(float(width), 9))] = wide
         return wide
@@ -773,6 +783,7 @@ class ShardedSimulator:
         """The point sets of the step exist: register the one every layer reads (its widest ghost plan is the only one that
         communicates); fluid-only / boundary-only sets are registered when a convolution first reads them."""
         m = self.model
+        self._set_view(all_pos.device)
         filter_extent = [float(np.float32(r) * np.float32(2)) for r in m.particle_radii]
         r_max = 0.5 * filter_extent[-1]
         multi = any(s != 1 for s in m.strides)
@@ -780,6 +791,33 @@ class ShardedSimulator:
         self._wide_w = max(r_max, margin)  # the widest ghost set any layer (or the lattice construction) of the step needs
         self._pending = {id(pos): ("pos", pos), id(box): ("box", box)}
         self._add_set("s0", all_pos, self._wide_w)
+
+    def _set_view(self, dev):
+        """How the positions the model convolves (after PBFNet.transform) map back to the scene coordinates of the cut planes:
+        model = ((scene + translate) * scale) @ R, so scene = (model @ R^T) / scale - translate (the inverse the model itself
+        applies, pbf_model.py:280-301, with its clamp of the scale).  Distances shrink by at most min(scale): the halo tested in
+        scene coordinates is widened by 1 / min(scale) so that it holds every point within the layer's radius in the model's
+        metric (extra ghosts are harmless)."""
+        tr = self.model.transformation
+        d = self._mdecomp
+        if not any(k in tr for k in ("translate", "scale", "grav_eqvar")):
+            d.view, d.inflate = None, 1.0
+            return
+        t = torch.tensor(tr.get("translate", [0.0, 0.0, 0.0]), dtype=torch.float32, device=dev)
+        sc = [float(v) for v in tr.get("scale", [1.0, 1.0, 1.0])]
+        for k in range(3):
+            if sc[k] <= 1e-5 and d.grid[k] > 1:
+                raise NotImplementedError(f"scale {sc} collapses axis {k}, which the decomposition cuts")
+        s = torch.tensor(sc, dtype=torch.float32, device=dev).clamp(min=1e-5)
+        R = self.model.R.t().contiguous() if "grav_eqvar" in tr else None
+
+        def view(x):
+            if R is not None:
+                x = x @ R
+            return x / s - t
+        d.view = view
+        d.inflate = 1.0 / min([v for v in sc if v > 1e-5] + [1.0]) if any(v < 1.0 for v in sc) else 1.0
+        self._transformed = True
 
     def _set_name(self, pos):
         name = self._name_of.get(id(pos))
@@ -812,7 +850,7 @@ class ShardedSimulator:
             cand = self._plan(base_name, self._lattice_margin(stride)).pos_ext
             g, gbox = grid_pos(cand, vs, centralize=m.centralize, pad=m.sample_pad, hyst=m.sample_hyst, center=center,
                                return_box=True)
-            g = g[self.decomp.owner(g) == comm.rank].contiguous()
+            g = g[self._mdecomp.owner(self._mdecomp.view(g) if getattr(self._mdecomp, 'view', None) is not None else g) == comm.rank].contiguous()
             name = f"s{si}"
             if center is not None and g.is_cuda:
                 # all lattices of the step share the agreed centre: the layers between them (and their owned + ghost
@@ -839,7 +877,8 @@ class ShardedSimulator:
                     # in the block, ghosts within that distance of it); the union only bounds the outer, open sides.  The
                     # dense volumes of the lattice form are zero-filled and walked box by box: with the union box of eight
                     # ranks the four lattice layers took 3x the time of the single-rank step (1.8 against 0.6 ms each).
-                    for k, (b_lo, b_hi) in enumerate(self.decomp.bounds(comm.rank)):
+                    # (model coordinates = scene coordinates only without a transformation: otherwise the union box stays)
+                    for k, (b_lo, b_hi) in enumerate(self.decomp.bounds(comm.rank) if getattr(self._mdecomp, 'view', None) is None else []):
                         v = float(vs[k])
                         if v > 1e-5 and b_lo != -float("inf"):
                             ulo[k] = max(ulo[k], int(np.floor((b_lo - wide_w - center_host[k]) / v)) - 2)
@@ -864,7 +903,7 @@ class ShardedSimulator:
                         want.append((name, w))
             for (name, w), plan in zip(want, GhostPlan.derive_batch([(self._wide[name], self._sets[name], w) for name, w in want])):
                 if os.environ.get("DMCF_SHARD_CHECK") == "1":
-                    direct = GhostPlan(self.comm, self.decomp, self._sets[name], w)
+                    direct = GhostPlan(self.comm, self._mdecomp, self._sets[name], w)
                     if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
                             not torch.equal(a, b) for a, b in zip(direct.send_idx, plan.send_idx)):
                         raise RuntimeError("a derived ghost plan differs from the directly built one")

@@ -26,20 +26,20 @@ def _scene():
     return dict(pos=pos, vel=vel, box=box, box_normals=nrm)
 
 
-def _build_model():
+def _build_model(transformation=None):
     from dmcf_amd import models
     from dmcf_amd.utils import tf_checkpoint as tc
     from tools import configs
-    cfg = configs.LIQUID3D
+    cfg = configs.LIQUID3D if transformation is None else dict(configs.LIQUID3D, transformation=transformation)
     w = dict(np.load(os.path.join(GOLDEN, "liquid3d_weights.npz")))
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, w, device="cpu")
     return model
 
 
-def _run_rank(comm, decomp, scene, steps):
+def _run_rank(comm, decomp, scene, steps, transformation=None):
     from dmcf_amd import parallel
-    model = _build_model()
+    model = _build_model(transformation)
     sim = parallel.ShardedSimulator(model, comm, decomp)
     state = parallel.shard_scene(scene, decomp, comm.rank, "cpu")
     for _ in range(steps):
@@ -125,6 +125,32 @@ def test_virtual_block_ranks_equal_single_rank(monkeypatch, grid):
         narrow = [rows - own for name, r, rows, own in p["launch_rows"] if name == "s0" and abs(r - 0.1) < 1e-6]
         assert narrow and max(narrow) < p["wide_ghosts"]["s0"], (narrow, p["wide_ghosts"])
         assert len(p["launch_rows"]) >= 14
+
+
+def test_sharded_step_with_a_model_transformation(monkeypatch):
+    """translate + scale + grav_eqvar (models/pbf_model.py:252-301): the model convolves transformed positions, the cut planes
+    stay in scene coordinates -- ownership and ghost tests look at the positions through the inverse transformation, the halo is
+    widened by the scale's largest shrink factor.  2x2x1 virtual ranks against one rank, tilted gravity (a real rotation)."""
+    import shims
+    from dmcf_amd import parallel
+    shims.install(monkeypatch)
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")
+    scene = _scene()
+    n = scene["pos"].shape[0]
+    g = np.float32([2.0, -9.0, 1.5])
+    scene["acc"] = np.broadcast_to(g, scene["pos"].shape).astype(np.float32).copy()
+    tr = dict(translate=[0.05, -0.02, 0.01], scale=[0.9, 0.9, 0.9], grav_eqvar=[0.0, -1.0, 0.0])
+    ref = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2, tr))
+    pos1, vel1 = _assemble(ref, n)
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [0.6, 0.3, 0.3], [2, 2, 1])
+    parts = parallel.run_local_ranks(decomp.world, lambda comm: _run_rank(comm, decomp, scene, 2, tr))
+    assert all(p["exchanged"] > 0 for p in parts)
+    pos, vel = _assemble(parts, n)
+    _close(pos, pos1)
+    _close(vel, vel1, 2e-4)
+    # and the transformation did something: without it the same scene moves elsewhere
+    plain = parallel.run_local_ranks(1, lambda comm: _run_rank(comm, parallel.SlabDecomposition(0, []), scene, 2))
+    assert np.abs(_assemble(plain, n)[0] - pos1).max() > 1e-5
 
 
 def test_bench_self_launch_dry_run():
