@@ -557,6 +557,7 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     p.out = a->out;
     if (cconv_direct_eligible(a, dz, dy, dx)) return cconv_direct_launch(p, a, dz, dy, dx, workspace, stream);
     if (a->flags & DMCF_FLAG_SKIP_SELF) return DMCF_EUNSUPPORTED;  // (only the direct form tests the index against the row)
+    if (cconv_ws_eligible(a, dz, dy, dx)) return cconv_ws_launch(p, a, workspace, stream);
     if (cconv_pair_eligible(a, dz, dy, dx)) return cconv_pair_launch(p, a, workspace, stream);
     if (cconv_p16_eligible(a, dz, dy, dx)) return cconv_p16_launch(p, a, workspace, stream);
     if (cconv_z3_eligible(a, dz, dy, dx)) return cconv_z3_launch(p, a, workspace, stream);
@@ -614,6 +615,8 @@ int dmcf_cconv_kernel_name(const dmcf_cconv_args* a, char* name, size_t name_byt
     const bool sym = (a->flags & DMCF_FLAG_SYMMETRIC) != 0;
     if (cconv_direct_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_direct_kernel<%d, %s>", cout, specialised(a) ? "false" : "true");
+    else if (cconv_ws_eligible(a, dz, dy, dx))
+        snprintf(name, name_bytes, "cconv_ws_kernel<%d, %s>", ntt, cconv_plain(a) ? "true" : "false");
     else if (cconv_pair_eligible(a, dz, dy, dx))
         snprintf(name, name_bytes, "cconv_pair_kernel<%d, %s>", ntt, cconv_plain(a) ? "true" : "false");
     else if (cconv_p16_eligible(a, dz, dy, dx))

@@ -272,6 +272,11 @@ bool cconv_pair_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 int cconv_pair_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
 
 
+// cconv_ws.hip
+bool cconv_ws_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
+int cconv_ws_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);
+
+
 // cconv_p16.hip
 bool cconv_p16_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx);
 int cconv_p16_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream);

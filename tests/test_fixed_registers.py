@@ -45,7 +45,7 @@ def _highest_compiler_register(lines):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="needs hipcc")
 @pytest.mark.parametrize("name,first_tile,extra,total", [("cconv_z3", 80, (), 128), ("cconv_cls", 92, ("-fno-slp-vectorize",), 128),
-                                                          ("cconv_pair", 116, (), 256), ("cconv_p16", 76, (), 128)])
+                                                          ("cconv_pair", 116, (), 256), ("cconv_ws", 112, (), 256), ("cconv_p16", 76, (), 128)])
 def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, extra, total):
     lines = _assembly(tmp_path, name, extra)
     top = {k: v for k, v in _highest_compiler_register(lines).items() if "kernel" in k and "pack" not in k}

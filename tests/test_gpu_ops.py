@@ -500,7 +500,7 @@ def test_scale_properties_200k(oracle, dev):
     assert torch.allclose(b, 2 * a, rtol=1e-4, atol=1e-4 * a.abs().max().item())
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "pair", "g16", "direct"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "pair", "ws", "g16", "direct"])
 @pytest.mark.parametrize("window,sym", [("poly6", False), ("cubic", False), ("peak", True)])
 def test_window_without_distance_array_is_bit_identical(dev, monkeypatch, kernel, window, sym):
     """neighbors_value = None with a distance window: the kernels re-form d^2 from the two positions exactly as the search
@@ -568,6 +568,7 @@ def test_skip_self_flag_shares_the_list_with_query_points(dev, monkeypatch):
 
 @pytest.mark.parametrize("kernel,ca,cb,oa,ob", [("cls", 4, 8, 32, 32), ("cls", 8, 4, 16, 8), ("z3", 8, 16, 32, 32), ("z3", 16, 12, 16, 16),
                                                   ("pair", 8, 16, 32, 32), ("pair", 16, 12, 16, 16), ("pair", 4, 8, 32, 32),
+                                                  ("ws", 8, 16, 32, 32), ("ws", 16, 12, 16, 16), ("ws", 4, 8, 32, 32),
                                                   ("g16", 4, 8, 32, 32), ("g16", 8, 4, 16, 8),
                                                   ("blk", 4, 8, 32, 32), (None, 4, 8, 32, 32)])
 def test_filter_tile_mask_of_a_block_diagonal_pair(oracle, dev, monkeypatch, kernel, ca, cb, oa, ob):
@@ -602,7 +603,7 @@ def test_filter_tile_mask_of_a_block_diagonal_pair(oracle, dev, monkeypatch, ker
     _close(hinted[:, oa:].cpu().numpy(), ref_b)
 
 
-@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "pair", "g16"])
+@pytest.mark.parametrize("kernel", ["lds", "mfma", "blk", "cls", "z3", "pair", "ws", "g16"])
 @pytest.mark.parametrize("cin,cout,ks,dim", [(16, 16, (4, 4, 4), 3), (4, 32, (4, 4, 4), 3), (24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2),
                                             (7, 8, (1, 8, 1), 1), (9, 5, (3, 5, 2), 3)])
 def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, cout, ks, dim):
@@ -623,7 +624,7 @@ def test_both_splat_kernels_match_oracle(oracle, dev, monkeypatch, kernel, cin, 
 @pytest.mark.parametrize("cin,cout,sym,radius", [(4, 8, False, 0.3), (8, 32, False, 0.45), (16, 16, False, 0.6), (24, 8, False, 0.3),
                                                  (32, 64, False, 0.3), (36, 3, False, 0.3), (8, 3, True, 0.3), (32, 3, True, 0.45),
                                                  (20, 5, False, 0.3), (28, 40, False, 0.45)])
-@pytest.mark.parametrize("kernel", ["blk", "cls", "z3", "pair", "g16"])
+@pytest.mark.parametrize("kernel", ["blk", "cls", "z3", "pair", "ws", "g16"])
 def test_pair_per_instruction_kernel(oracle, dev, monkeypatch, kernel, cin, cout, sym, radius):
     """cconv_blk.hip (4x4x4 filters, one pair per 4x4x1 MFMA) and cconv_cls.hip (class-sorted, four pairs per 16x16x4
     MFMA): rows from empty to several batches, every channel-chunk count, bias + accumulate, and the antisymmetric form."""
@@ -894,6 +895,7 @@ def test_row_length_hint_picks_the_kernel_for_wide_layers(oracle, dev):
 
 @pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("cls", 24, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
                                                 ("z3", 24, 16, (4, 4, 4)), ("pair", 24, 16, (4, 4, 4)), ("pair", 32, 40, (4, 4, 4)),
+                                                ("ws", 24, 16, (4, 4, 4)), ("ws", 32, 40, (4, 4, 4)), ("ws", 8, 16, (4, 4, 4)),
                                                 ("g16", 16, 16, (4, 4, 4)), ("g16", 8, 40, (4, 4, 4)),
                                                 ("direct", 32, 3, (6, 6, 6)), ("lds", 4, 8, (3, 5, 2))])
 def test_padded_single_pass_search_and_conv(dev, monkeypatch, kernel, cin, cout, ks):
