@@ -32,6 +32,15 @@
 
 namespace dmcf {
 
+// Diagnostic build (make -C dmcf_amd/csrc ws_trace -> variants/WTRACE.so, read by tools/wtrace.py): cycle stamps at the phase
+// boundaries of both roles, summed over the first producer / consumer of every 16th workgroup.  Compiled out of the product.
+#ifdef WS_TRACE
+__device__ unsigned long long g_wtrace[32];
+#define WT(k) { const uint64_t now_ = __builtin_readcyclecounter(); wt[k] += now_ - wlast; wlast = now_; }
+#else
+#define WT(k)
+#endif
+
 constexpr int kWProd = 4, kWCons = 4;
 constexpr int kWThreads = 64 * (kWProd + kWCons);
 constexpr int WTM = 16;             // output points per tile = rows of the B tile
@@ -39,8 +48,8 @@ constexpr int kWPts = WTM / kWProd; // points per producer
 constexpr int kWRow = 2048;         // floats per B row: [2 chunks of 16 channels][k' = (z * 4 + y) * 64 + channel * 4 + x]
 constexpr int kWRecG = 36;          // floats per record group: 8 products x 4 pairs, padded (bank = 4 g + 4 q + t)
 constexpr int kWRec = 16 * kWRecG;
-constexpr int kWWaveF = kWRec + 64 + 32; // per producer: records + index buffer + row table
-constexpr int kWMaxNT = 4;
+constexpr int kWWaveF = kWRec + 64 + 512; // per producer: records + index buffer + the ring's row table
+constexpr int kWMaxNT = 2;           // (the LDS: 128 KB of B tile + 18 KB of producer staging + 4 x 2 KB of sums per column tile)
 constexpr int kWRed = kWCons * WTM * 16 * kWMaxNT;  // partial sums of the consumers
 constexpr int kWCompilerVgprs = 56; // (the attribute counts HALF of the unified file: v0 .. v111)
 
@@ -121,16 +130,18 @@ __device__ __forceinline__ void ws_filter_coords(float& x, float& y, float& z, f
 // ---- the producers' per-pair stages (plain functions: a lambda's closure object -- a dozen captured values -- is stored to
 // scratch and never read when its body is inlined this late)
 
-// row of stream position sp (rows start at 0, off1, off2, off3)
-__device__ __forceinline__ int ws_row(int sp, int off1, int off2, int off3) {
-    return (sp >= off1 ? 1 : 0) + (sp >= off2 ? 1 : 0) + (sp >= off3 ? 1 : 0);
-}
+// the ring of rows of a producer: lane r % 64 holds row r's first stream position and its end (start + pairs) and, for the
+// first row of a tile, the tile's base in the index array and the entries the four rows span from there
+struct WsRing {
+    int start, end, rblo, rbhi, span;
+};
 
-// index (and explicit neighbour value) of the pair at stream position sp; positions without a pair read entry 0 of the buffer
-__device__ __forceinline__ void ws_ld_idx(int sp, int off1, int off2, int off3, const float* Tab, __amdgpu_buffer_rsrc_t rI, const float* nval,
-                                          int64_t rb0, int& j, float& nv) {
-    const int k = ws_row(sp, off1, off2, off3);
-    const f32x2 ed = *(const f32x2*)(Tab + 8 * k);
+// index (and explicit neighbour value) of the pair at stream position sp of the tile whose rows are r4 .. r4 + 3 and start at
+// (the tile's first batch), o1, o2, o3; positions without a pair read entry 0 of the buffer.  kk = the ring entry of the row.
+__device__ __forceinline__ void ws_ld_idx(int sp, int r4, int o1, int o2, int o3, const float* Tab, __amdgpu_buffer_rsrc_t rI, const float* nval,
+                                          int64_t rb0, int& j, float& nv, int& kk) {
+    kk = (r4 + (sp >= o1 ? 1 : 0) + (sp >= o2 ? 1 : 0) + (sp >= o3 ? 1 : 0)) & 63;
+    const f32x2 ed = *(const f32x2*)(Tab + 8 * kk);
     // (__builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler: by value through __float_as_int)
     const int e = __float_as_int(ed.x), d = __float_as_int(ed.y);
     const bool ok = sp < e;
@@ -148,11 +159,10 @@ __device__ __forceinline__ void ws_ld_pos(const float* inp_pos, int j, float& x,
 }
 
 // the pair's 8 trilinear products and its class
-__device__ __forceinline__ WsRec ws_geom(int sp, int off1, int off2, int off3, const float* Tab, int window, const float* nval, const float* imp,
+__device__ __forceinline__ WsRec ws_geom(int sp, int kk, const float* Tab, int window, const float* nval, const float* imp,
                                          float inv_r2, float window_fac, float inv_extent, int j, float nv, float x, float y, float z, bool& ok) {
     WsRec c;
-    const int k = ws_row(sp, off1, off2, off3);
-    const f32x4 o = *(const f32x4*)(Tab + 8 * k + 4);
+    const f32x4 o = *(const f32x4*)(Tab + 8 * kk + 4);
     ok = sp < __float_as_int(o.w);
     x -= o.x;
     y -= o.y;
@@ -172,6 +182,71 @@ __device__ __forceinline__ WsRec ws_geom(int sp, int off1, int off2, int off3, c
     c.lo = (f32x4){a0 * y00, a0 * y01, a0 * y10, a0 * y11};
     c.hi = (f32x4){a1 * y00, a1 * y01, a1 * y10, a1 * y11};
     return c;
+}
+
+// Rows 32 wi .. 32 wi + 31 of a producer (8 tiles) -> the ring: lanes / table entries 32 (wi & 1) .. + 31.  Synchronous (one
+// round trip to the row bounds and the output positions), once per 8 tiles.
+__device__ __forceinline__ void ws_refill(WsKP kp0, int wi, int lane, int wave, int t_begin, int t_end, int nslots, float* Tab, int& stream_end,
+                                          WsRing& ring) {
+    WsKP kp = kp0;
+    asm volatile("" : "+s"(kp));
+    const int lb = 32 * (wi & 1);
+    const bool act = (unsigned)(lane - lb) < 32u;
+    const int r = 32 * wi + (lane - lb);
+    const int tile = t_begin + (r >> 2) * nslots;
+    const int64_t i = (int64_t)tile * WTM + kWPts * wave + (r & 3);
+    int64_t rb = 0;
+    int nt = 0;
+    float ox = 0.0f, oy = 0.0f, oz = 0.0f;
+    if (act && tile < t_end && i < kp->n_out) {
+        const int64_t* const rs = kp->rs;
+        const int32_t* const cnt = kp->cnt;
+        const float* const out_pos = kp->out_pos;
+        const int64_t b = rs[i];
+        int64_t e = cnt ? b + cnt[i] : rs[i + 1];
+        if (e > kp->pair_cap) e = b;
+        rb = b;
+        nt = (int)min(e - b, (int64_t)0x01ffffc0);
+        ox = out_pos[3 * i];
+        oy = out_pos[3 * i + 1];
+        oz = out_pos[3 * i + 2];
+    }
+    // stream positions: a row owns its pairs rounded up to blocks of 8 (at least one), a tile whole batches
+    const int slots = (max(nt, 1) + 7) & ~7;
+    const int q = lane & 3;
+    const int s1 = __shfl_up(slots, 1), s2 = __shfl_up(slots, 2), s3 = __shfl_up(slots, 3);
+    const int intra = (q >= 1 ? s1 : 0) + (q >= 2 ? s2 : 0) + (q >= 3 ? s3 : 0);
+    const int ttot = (__shfl(intra + slots, lane | 3) + 63) & ~63;
+    int tp = 0, wtot = 0;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int tm = __builtin_amdgcn_readlane(ttot, lb + 4 * m);
+        if (((lane - lb) >> 2) > m) tp += tm;
+        wtot += tm;
+    }
+    const int start = stream_end + tp + intra;
+    // ONE buffer per tile over its four rows (consecutive rows of the list): entry e of a row sits gap + e entries behind the
+    // start of the tile's first row
+    const int64_t rb0 = ((int64_t)__shfl((int)(rb >> 32), lane & ~3) << 32) | (uint32_t)__shfl((int)rb, lane & ~3);
+    const int64_t gap = nt > 0 ? rb - rb0 : 0;
+    // (eligibility bounds n_inp -- and with it every row -- by 2^24 entries: four consecutive rows always fit one buffer)
+    if (__builtin_amdgcn_ballot_w64(act && (gap < 0 || gap + nt >= ((int64_t)1 << 29))) != 0) __builtin_trap();
+    int sp = (int)gap + nt;
+    sp = max(sp, __shfl_xor(sp, 1));
+    sp = max(sp, __shfl_xor(sp, 2));
+    if (act) {
+        const int e = start + nt;
+        const int d = (int)(((uint32_t)(int)gap - (uint32_t)start) * 4u);
+        *(f32x4*)(Tab + 8 * lane) = (f32x4){__int_as_float(e), __int_as_float(d), 0.0f, 0.0f};
+        *(f32x4*)(Tab + 8 * lane + 4) = (f32x4){ox, oy, oz, __int_as_float(e)};
+        ring.start = start;
+        ring.end = e;
+        ring.rblo = (int)rb0;
+        ring.rbhi = (int)(rb0 >> 32);
+        ring.span = sp;
+    }
+    stream_end += wtot;
+    wfence();
 }
 
 // PLAIN: see cconv_plain() in cconv_common.h
@@ -196,7 +271,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         // =============================================== PRODUCER ===============================================
         float* Rec = smem + WTM * kWRow + wave * kWWaveF;  // [16 groups][kWRecG]: product q of pair 4 g + t at g * kWRecG + 4 q + t
         uint32_t* Jof = (uint32_t*)(Rec + kWRec);          // [64]: byte offset of the pair's feature row (kWOob: no pair)
-        float* Tab = Rec + kWRec + 64;                     // [4 rows][8]: {end, byte delta, -, -, x, y, z, end} of the producer's rows
+        float* Tab = Rec + kWRec + 64;                     // [64 rows (ring)][8]: {end, byte delta, -, -, x, y, z, end} of a row
         float* Fst = Bt + (kWPts * wave + kWPts - 1) * kWRow;  // [16 groups][32 channels (permuted)][4 pairs]: the LAST point's row
         // splat roles: this lane's channel (B operand, accumulator column) and plane offset z'
         const int ch = lane & 31, half = lane >> 5;
@@ -217,233 +292,260 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             "204,206,208,210,212,214,216,218,220,222,224,226,228,230,232,234,236,238,240,242,244,246,248,250,252,254\n\t"
             "v_mov_b64 v[\\r:\\r+1], 0\n\t.endr" ::: "memory", WS_FIXED_REGS);
 
-#pragma unroll 1
-        for (int tile = t_begin; tile < t_end; tile += nslots) {
-            WsKP kp = kp0;
-            asm volatile("" : "+s"(kp));
-            const int window = PLAIN ? (int)DMCF_WINDOW_POLY6 : kp->window;
-            const float* const nval = PLAIN ? nullptr : kp->nval;
-            const float* const imp = PLAIN ? nullptr : kp->inp_imp;
-            const float inv_r2 = kp->inv_r2, window_fac = kp->window_fac, inv_extent = kp->inv_extent;
-            const float* const inp_pos = kp->inp_pos;
-            const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)kp->inp_feat, 0, (int)((uint32_t)kp->n_inp * rowBy), 0x00020000);
-            // ---- the four rows of this producer: ONE dense stream.  Row k's pairs sit at stream positions [off_k, off_k + nt_k),
-            // off_k a multiple of 8 (the splat runs in blocks of 8 pairs and a block feeds ONE point's tiles).  Lane l reads the
-            // bounds and the position of row l & 3; what a lane needs of ITS pair's row later (the row's end in the stream, the
-            // byte distance of the row's entries from their stream positions, the output position) goes to a four-entry table
-            // in LDS -- as scalars these 20 values, live through the batch loop, were most of ~200 scalar spills.
-            int64_t rbl = 0;
-            int ntl = 0;
-            float oxl = 0.0f, oyl = 0.0f, ozl = 0.0f;
-            {
-                const int64_t n_out = kp->n_out, pair_cap = kp->pair_cap;
-                const int64_t* const rs = kp->rs;
-                const int32_t* const cnt = kp->cnt;
-                const float* const out_pos = kp->out_pos;
-                const int64_t i = (int64_t)tile * WTM + kWPts * wave + (lane & 3);
-                if (i < n_out) {
-                    const int64_t b = rs[i];
-                    int64_t e = cnt ? b + cnt[i] : rs[i + 1];
-                    if (e > pair_cap) e = b;
-                    rbl = b;
-                    ntl = (int)min(e - b, (int64_t)0x01ffffc0);
-                    oxl = out_pos[3 * i];
-                    oyl = out_pos[3 * i + 1];
-                    ozl = out_pos[3 * i + 2];
-                }
-            }
-            const int nt0 = __builtin_amdgcn_readlane(ntl, 0), nt1 = __builtin_amdgcn_readlane(ntl, 1);
-            const int nt2 = __builtin_amdgcn_readlane(ntl, 2), nt3 = __builtin_amdgcn_readlane(ntl, 3);
-            const int off1 = (nt0 + 7) & ~7, off2 = off1 + ((nt1 + 7) & ~7), off3 = off2 + ((nt2 + 7) & ~7);
-            const int S = off3 + nt3;
-            const int64_t rb0 = ((int64_t)__builtin_amdgcn_readlane((int)(rbl >> 32), 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)rbl, 0);
-            // ONE buffer over the four rows (consecutive rows of the list): entry e of row k sits gap_k + e entries behind row 0's
-            // start; offsets without a pair are replaced by an out-of-range one and read as index 0 (a valid point, unused)
-            const int64_t gapl = ntl > 0 ? rbl - rb0 : 0;
-            // (eligibility bounds n_inp -- and with it every row -- by 2^24 entries: four consecutive rows always fit one buffer)
-            if (gapl < 0 || gapl + ntl >= ((int64_t)1 << 29)) __builtin_trap();
-            const int spanl = (int)gapl + ntl;
-            const int span = wsgpr(max(max(__builtin_amdgcn_readlane(spanl, 0), __builtin_amdgcn_readlane(spanl, 1)),
-                                       max(__builtin_amdgcn_readlane(spanl, 2), __builtin_amdgcn_readlane(spanl, 3))));
-            const __amdgpu_buffer_rsrc_t rI = __builtin_amdgcn_make_buffer_rsrc((void*)(kp->idx + rb0), 0, span * 4, 0x00020000);
-            {
-                const int kl = lane & 3;
-                const int offl = kl == 0 ? 0 : (kl == 1 ? off1 : (kl == 2 ? off2 : off3));
-                if (lane < 4) {
-                    const int endl = offl + ntl;
-                    const int dltl = (int)(((uint32_t)(int)gapl - (uint32_t)offl) * 4u);
-                    *(f32x4*)(Tab + 8 * lane) = (f32x4){__int_as_float(endl), __int_as_float(dltl), 0.0f, 0.0f};
-                    *(f32x4*)(Tab + 8 * lane + 4) = (f32x4){oxl, oyl, ozl, __int_as_float(endl)};
-                }
-            }
-            wfence();
-            const int NB = (S + 63) >> 6, nblk_total = (S + 7) >> 3;
-            // point k is complete before block gb_k of the stream
-            const int gb0 = off1 >> 3, gb1 = off2 >> 3, gb2 = off3 >> 3;
+        // ---- ONE continuous stream of 64-pair batches over ALL tiles of this producer.  Row r (tile r / 4 of the workgroup's
+        // tiles, the producer's point r % 4 of it) owns the stream positions [start_r, start_r + nt_r); start_r is a multiple of
+        // 8 (the splat runs in blocks of 8 pairs and a block feeds ONE point's tiles), a tile's first row starts a batch (the
+        // feature staging of a batch is the B row of the tile's last point), and an empty row still owns one block, so every
+        // tile has a batch.  The loads run ahead ACROSS tiles (indices three batches, positions two, features one): with one
+        // batch loop per tile the four dependent round trips of a tile's start (row bounds -> indices -> positions -> features,
+        // ~8k clocks) were exposed in every tile -- a producer is alone on its SIMD but for the consumer's matrix instructions.
+        // What a stage needs of a row lives in a ring of 64 rows: lane r % 64 of the registers below and entry r % 64 of the
+        // table in LDS; 32 rows (8 tiles) are refilled at a time, 16 or more rows ahead of the splat.
+        const int T = (t_end - t_begin + nslots - 1) / nslots;  // tiles of this workgroup
+        WsRing ring = {0, 0, 0, 0, 0};
+        int stream_end = 0;
+        ws_refill(kp0, 0, lane, wave, t_begin, t_end, nslots, Tab, stream_end, ring);
+        ws_refill(kp0, 1, lane, wave, t_begin, t_end, nslots, Tab, stream_end, ring);
 
-            auto npairs = [S](int t) -> int { return max(0, min(64, S - 64 * t)); };
-            auto push_index = [=](int j, bool ok) { Jof[lane] = ok ? __umul24((uint32_t)j, rowBy) : kWOob; };
-            auto push_rec = [=](const WsRec& c) {
-                float* r = Rec + (lane >> 2) * kWRecG + (lane & 3);
-                r[0] = c.lo.x; r[4] = c.lo.y; r[8] = c.lo.z; r[12] = c.lo.w;
-                r[16] = c.hi.x; r[20] = c.hi.y; r[24] = c.hi.z; r[28] = c.hi.w;
-            };
-            int pk_cur = 0;  // the packed class bytes of the staged batch (lanes 0, 4, 8, ...: four pairs each)
-            auto pack_classes = [=](int cls4, uint32_t (&c)[16]) -> int {
-                int pk = cls4 | (__builtin_amdgcn_mov_dpp(cls4, 0xb1, 0xf, 0xf, true) << 8);   // quad_perm [1, 0, 3, 2]
-                pk = pk | (__builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true) << 16);          // quad_perm [2, 3, 0, 1]
+        WsKP kp = kp0;
+        asm volatile("" : "+s"(kp));
+        const int window = PLAIN ? (int)DMCF_WINDOW_POLY6 : kp->window;
+        const float* const nval = PLAIN ? nullptr : kp->nval;
+        const float* const imp = PLAIN ? nullptr : kp->inp_imp;
+        const float inv_r2 = kp->inv_r2, window_fac = kp->window_fac, inv_extent = kp->inv_extent;
+        const float* const inp_pos = kp->inp_pos;
+        const int32_t* const idx = kp->idx;
+        const __amdgpu_buffer_rsrc_t rF = __builtin_amdgcn_make_buffer_rsrc((void*)kp->inp_feat, 0, (int)((uint32_t)kp->n_inp * rowBy), 0x00020000);
+
+        auto push_index = [=](int j, bool ok) { Jof[lane] = ok ? __umul24((uint32_t)j, rowBy) : kWOob; };
+        auto push_rec = [=](const WsRec& c) {
+            float* r = Rec + (lane >> 2) * kWRecG + (lane & 3);
+            r[0] = c.lo.x; r[4] = c.lo.y; r[8] = c.lo.z; r[12] = c.lo.w;
+            r[16] = c.hi.x; r[20] = c.hi.y; r[24] = c.hi.z; r[28] = c.hi.w;
+        };
+        int pk_cur = 0;  // the packed class bytes of the staged batch (lanes 0, 4, 8, ...: four pairs each)
+        auto pack_classes = [=](int cls4, uint32_t (&c)[16]) -> int {
+            int pk = cls4 | (__builtin_amdgcn_mov_dpp(cls4, 0xb1, 0xf, 0xf, true) << 8);   // quad_perm [1, 0, 3, 2]
+            pk = pk | (__builtin_amdgcn_mov_dpp(pk, 0x4e, 0xf, 0xf, true) << 16);          // quad_perm [2, 3, 0, 1]
 #pragma unroll
-                for (int m = 0; m < 16; ++m) c[m] = (uint32_t)__builtin_amdgcn_readlane(pk, 4 * m);
-                return pk;
-            };
-            auto f_issue = [=](int np, f32x4 (&f)[8]) {
+            for (int m = 0; m < 16; ++m) c[m] = (uint32_t)__builtin_amdgcn_readlane(pk, 4 * m);
+            return pk;
+        };
+        auto f_issue = [=](int np, f32x4 (&f)[8]) {
 #pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    if (hh == 0 || np > 32) {
-                        uint32_t jo[4];
+            for (int hh = 0; hh < 2; ++hh) {
+                if (hh == 0 || np > 32) {
+                    uint32_t jo[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) jo[r] = Jof[8 * (4 * hh + r) + fr];
+                    for (int r = 0; r < 4; ++r) jo[r] = Jof[8 * (4 * hh + r) + fr];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            f[4 * hh + r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rF, __builtin_elementwise_add_sat(jo[r], cbyte), 0, 0));
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        f[4 * hh + r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rF, __builtin_elementwise_add_sat(jo[r], cbyte), 0, 0));
                 }
-            };
-            auto f_publish = [=](int np, const f32x4 (&f)[8]) {
+            }
+        };
+        auto f_publish = [=](int np, const f32x4 (&f)[8]) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    if (r < 4 || np > 32) {
-                        w01[256 * r] = f[r].x;
-                        w01[256 * r + 32] = f[r].y;
-                        w23[256 * r + 64] = f[r].z;
-                        w23[256 * r + 96] = f[r].w;
-                    }
+            for (int r = 0; r < 8; ++r) {
+                if (r < 4 || np > 32) {
+                    w01[256 * r] = f[r].x;
+                    w01[256 * r + 32] = f[r].y;
+                    w23[256 * r + 64] = f[r].z;
+                    w23[256 * r + 96] = f[r].w;
                 }
-            };
-            auto splat = [=](int nblk, const uint32_t (&c)[16], uint32_t a_rec, uint32_t a_fst) {
-                uint32_t s0;
-                __builtin_amdgcn_s_setprio(3);
-                asm volatile(
+            }
+        };
+        auto splat = [=](int nblk, const uint32_t (&c)[16], uint32_t a_rec, uint32_t a_fst) {
+            uint32_t s0;
+            __builtin_amdgcn_s_setprio(3);
+            asm volatile(
 #include "cconv_pair_splat.inc"
-                    : [s0] "=&s"(s0)
-                    : [pa] "v"(a_rec), [pf] "v"(a_fst), [nb] "s"(wsgpr(nblk)), [c0] "s"(wsgpr(c[0])), [c1] "s"(wsgpr(c[1])), [c2] "s"(wsgpr(c[2])),
-                      [c3] "s"(wsgpr(c[3])), [c4] "s"(wsgpr(c[4])), [c5] "s"(wsgpr(c[5])), [c6] "s"(wsgpr(c[6])), [c7] "s"(wsgpr(c[7])),
-                      [c8] "s"(wsgpr(c[8])), [c9] "s"(wsgpr(c[9])), [c10] "s"(wsgpr(c[10])), [c11] "s"(wsgpr(c[11])), [c12] "s"(wsgpr(c[12])),
-                      [c13] "s"(wsgpr(c[13])), [c14] "s"(wsgpr(c[14])), [c15] "s"(wsgpr(c[15]))
-                    : "scc", "m0", "memory", WS_FIXED_REGS);
-                __builtin_amdgcn_s_setprio(0);
-            };
-            // Point kd is done: merge its tiles in registers (lanes 0 .. 31: planes 0, 1; lanes 32 .. 63: planes 2, 3 of the
-            // lane's channel), store all 32 channels to its B row, clear the tiles for the next point.
-            int kd = 0;
-            auto complete = [=, &kd]() {
-                const int row = kWPts * wave + kd;
-                const uint32_t b = row_lane + (uint32_t)row * (kWRow * 4u) + ((uint32_t)((ch & 15) ^ (row & 15)) << 4);
-                asm volatile(
-#include "cconv_pair_merge.inc"
-                    ::: "memory", WS_FIXED_REGS);
-                asm volatile(
-#include "cconv_pair_store.inc"
-                    :: [b] "v"(b) : "memory", WS_FIXED_REGS);
-                asm volatile(
-#include "cconv_pair_zero.inc"
-                    ::: "memory", WS_FIXED_REGS);
-                ++kd;
-            };
+                : [s0] "=&s"(s0)
+                : [pa] "v"(a_rec), [pf] "v"(a_fst), [nb] "s"(wsgpr(nblk)), [c0] "s"(wsgpr(c[0])), [c1] "s"(wsgpr(c[1])), [c2] "s"(wsgpr(c[2])),
+                  [c3] "s"(wsgpr(c[3])), [c4] "s"(wsgpr(c[4])), [c5] "s"(wsgpr(c[5])), [c6] "s"(wsgpr(c[6])), [c7] "s"(wsgpr(c[7])),
+                  [c8] "s"(wsgpr(c[8])), [c9] "s"(wsgpr(c[9])), [c10] "s"(wsgpr(c[10])), [c11] "s"(wsgpr(c[11])), [c12] "s"(wsgpr(c[12])),
+                  [c13] "s"(wsgpr(c[13])), [c14] "s"(wsgpr(c[14])), [c15] "s"(wsgpr(c[15]))
+                : "scc", "m0", "memory", WS_FIXED_REGS);
+            __builtin_amdgcn_s_setprio(0);
+        };
 
-#ifdef WS_DBG_NOPROD
-            WS_BARRIER();
-            WS_BARRIER();
-            continue;
+        // ---- the index stage's tile: rows 4 tq .. 4 tq + 3 start at (the tile's first batch), o1, o2, o3; its batches end at gendq
+        int tq = 0, gq = 0, o1 = 0, o2 = 0, o3 = 0, gendq = 0, elastq = 0;
+        int64_t rb0q = 0;
+        __amdgpu_buffer_rsrc_t rI;
+#define WS_TILE_CTX()                                                                                                        \
+    {                                                                                                                        \
+        const int l0_ = (4 * tq) & 63;                                                                                       \
+        o1 = __builtin_amdgcn_readlane(ring.start, l0_ + 1);                                                                 \
+        o2 = __builtin_amdgcn_readlane(ring.start, l0_ + 2);                                                                 \
+        o3 = __builtin_amdgcn_readlane(ring.start, l0_ + 3);                                                                 \
+        elastq = __builtin_amdgcn_readlane(ring.end, l0_ + 3);                                                               \
+        gendq = __builtin_amdgcn_readlane(ring.start, (l0_ + 4) & 63) >> 6;                                                  \
+        rb0q = ((int64_t)__builtin_amdgcn_readlane(ring.rbhi, l0_) << 32) | (uint32_t)__builtin_amdgcn_readlane(ring.rblo, l0_); \
+        rI = __builtin_amdgcn_make_buffer_rsrc((void*)(idx + rb0q), 0, __builtin_amdgcn_readlane(ring.span, l0_) * 4, 0x00020000); \
+    }
+        // index (and explicit neighbour value) of the pair at this lane's position of batch gq; kk = the ring entry of its row;
+        // np = the batch's pairs (positions past the tile's last pair hold none)
+#define WS_IDX_STAGE(J, NV, KK, NP)                                                                                          \
+    {                                                                                                                        \
+        if (gq >= gendq) {                                                                                                   \
+            ++tq;                                                                                                            \
+            WS_TILE_CTX()                                                                                                    \
+        }                                                                                                                    \
+        ws_ld_idx(64 * gq + lane, 4 * tq, o1, o2, o3, Tab, rI, nval, rb0q, J, NV, KK);                                       \
+        NP = max(0, min(64, elastq - 64 * gq));                                                                              \
+        ++gq;                                                                                                                \
+    }
+        WS_TILE_CTX()
+
+        int ti = 0;      // the splat stage's tile
+        int rdone = 0;   // ... and its next row to complete
+        // Row rdone is done: merge its tiles in registers (lanes 0 .. 31: planes 0, 1; lanes 32 .. 63: planes 2, 3 of the lane's
+        // channel), store all 32 channels to its B row, clear the tiles for the next point.
+        auto complete = [=, &rdone]() {
+            const int row = kWPts * wave + (rdone & 3);
+            const uint32_t b = row_lane + (uint32_t)row * (kWRow * 4u) + ((uint32_t)((ch & 15) ^ (row & 15)) << 4);
+            asm volatile(
+#include "cconv_pair_merge.inc"
+                ::: "memory", WS_FIXED_REGS);
+            asm volatile(
+#include "cconv_pair_store.inc"
+                :: [b] "v"(b) : "memory", WS_FIXED_REGS);
+            asm volatile(
+#include "cconv_pair_zero.inc"
+                ::: "memory", WS_FIXED_REGS);
+            ++rdone;
+        };
+
+        // Stages (nothing hides a round trip at one producer per SIMD but the consumer's matrix instructions, so every load is
+        // issued a whole splat before its first use): indices three batches ahead, positions two, geometry + index push + ALL
+        // feature loads of batch g + 1 before the splat of batch g, published after it.
+#ifdef WS_TRACE
+        uint64_t wt[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t wlast = __builtin_readcyclecounter();
+        const uint64_t wstart = wlast;
+        int nbatches = 0;
 #endif
-            // Stages (nothing hides a round trip at one producer per SIMD but the consumer's matrix instructions, so every
-            // load is issued a whole splat before its first use): indices three batches ahead, positions two, geometry + index
-            // push + ALL feature loads of batch t + 1 before the splat of batch t, published after it.
-            int j1 = 0, j2 = 0;
-            float nv1 = 0.0f, nv2 = 0.0f, px = 0.0f, py = 0.0f, pz = 0.0f;
-            uint32_t cc[16];
-            f32x4 ff[8];
-            if (NB > 0) {
-                int j0;
-                float nv0, qx, qy, qz;
-                bool ok0;
-                ws_ld_idx(lane, off1, off2, off3, Tab, rI, nval, rb0, j0, nv0);
-                ws_ld_idx(64 + lane, off1, off2, off3, Tab, rI, nval, rb0, j1, nv1);
-                ws_ld_idx(128 + lane, off1, off2, off3, Tab, rI, nval, rb0, j2, nv2);
-                ws_ld_pos(inp_pos, j0, qx, qy, qz);
-                ws_ld_pos(inp_pos, j1, px, py, pz);
-                const WsRec first = ws_geom(lane, off1, off2, off3, Tab, window, nval, imp, inv_r2, window_fac, inv_extent, j0, nv0, qx, qy, qz, ok0);
-                push_index(j0, ok0);
-                push_rec(first);
-                pk_cur = pack_classes(first.cls4, cc);
-                wfence();
-                f_issue(npairs(0), ff);
-            }
-            WS_BARRIER();  // "free": the consumers hold the previous tile in registers -- the B rows (and the staging in them) are ours
-            if (NB > 0) {
-                f_publish(npairs(0), ff);
-                wfence();
+        int j1, j2, kk1, kk2, np0, np1, np2;
+        float nv1, nv2, px, py, pz;
+        uint32_t cc[16];
+        f32x4 ff[8];
+        {
+            int j0, kk0;
+            float nv0, qx, qy, qz;
+            bool ok0;
+            WS_IDX_STAGE(j0, nv0, kk0, np0)
+            WS_IDX_STAGE(j1, nv1, kk1, np1)
+            WS_IDX_STAGE(j2, nv2, kk2, np2)
+            ws_ld_pos(inp_pos, j0, qx, qy, qz);
+            ws_ld_pos(inp_pos, j1, px, py, pz);
+            const WsRec first = ws_geom(lane, kk0, Tab, window, nval, imp, inv_r2, window_fac, inv_extent, j0, nv0, qx, qy, qz, ok0);
+            push_index(j0, ok0);
+            push_rec(first);
+            pk_cur = pack_classes(first.cls4, cc);
+            wfence();
+            f_issue(np0, ff);
+        }
+        WT(0)
+        WS_BARRIER();  // "free": the B rows (and the staging in them) are ours
+        WT(5)
+        f_publish(np0, ff);
+        wfence();
+        WT(6)
+        // the splat stage's tile: its real end in blocks, the batch after its last
+        // (an empty last row owns one block, so that a tile's last row completes in the tile's last batch)
+        int nblk_tile = (max(__builtin_amdgcn_readlane(ring.end, 3), __builtin_amdgcn_readlane(ring.start, 3) + 1) + 7) >> 3;
+        int gend = __builtin_amdgcn_readlane(ring.start, 4) >> 6;
 #pragma unroll 1
-                for (int t = 0; t < NB; ++t) {
-                    // here: Rec / Fst / cc = batch t; (j1, nv1, px, py, pz) = batch t + 1; (j2, nv2) = the indices of batch t + 2
-                    const bool more = t + 1 < NB;
-                    const int np1 = more ? npairs(t + 1) : 0;
-                    WsRec nxt;
-                    int jn;
-                    float nvn, qx, qy, qz;
-                    if (more) {
-                        bool ok1;
-                        nxt = ws_geom(64 * (t + 1) + lane, off1, off2, off3, Tab, window, nval, imp, inv_r2, window_fac, inv_extent, j1, nv1, px, py, pz, ok1);
-                        push_index(j1, ok1);
-                        wfence();
-                        f_issue(np1, ff);
-                    }
-                    // (unconditional -- past the stream's end the index load is out of the buffer's range and returns entry 0)
-                    ws_ld_pos(inp_pos, j2, qx, qy, qz);
-                    ws_ld_idx(64 * (t + 3) + lane, off1, off2, off3, Tab, rI, nval, rb0, jn, nvn);
-                    // ONE splat site, run once per segment of the batch: a segment ends where a point's pairs end
-                    const int blo = 8 * t, bhi = min(8 * t + 8, nblk_total);
-                    int b0 = blo;
-                    for (;;) {
-                        const int gbk = kd == 0 ? gb0 : (kd == 1 ? gb1 : (kd == 2 ? gb2 : nblk_total));
-                        const int b1 = min(gbk, bhi);
-                        if (b1 > b0) {
-                            const int sh = b0 - blo;
-                            if (sh > 0) {  // (cc is dead after this batch: the next one packs its own)
+        for (int g = 0;; ++g) {
+            // here: Rec / Fst / cc = batch g; (j1, nv1, kk1, px, py, pz, np1) = batch g + 1; (j2, nv2, kk2, np2) = batch g + 2
+            const bool tile_last = g + 1 == gend;
+            const bool more = !(tile_last && ti + 1 == T);
+            WsRec nxt;
+            int jn, kkn, npn;
+            float nvn, qx, qy, qz;
+            if (more) {
+                bool ok1;
+                nxt = ws_geom(64 * (g + 1) + lane, kk1, Tab, window, nval, imp, inv_r2, window_fac, inv_extent, j1, nv1, px, py, pz, ok1);
+                push_index(j1, ok1);
+                wfence();
+                f_issue(np1, ff);
+            }
+            ws_ld_pos(inp_pos, j2, qx, qy, qz);
+            WS_IDX_STAGE(jn, nvn, kkn, npn)
+            WT(0)
+            // ONE splat site, run once per segment of the batch: a segment ends where a point's pairs end
+            const int blo = 8 * g, bhi = min(8 * g + 8, nblk_tile);
+            int b0 = blo;
+            bool tile_done = false;
+            for (;;) {
+                const int gbk = (rdone & 3) == 3 ? nblk_tile : (__builtin_amdgcn_readlane(ring.start, (rdone + 1) & 63) >> 3);
+                const int b1 = min(gbk, bhi);
+                if (b1 > b0) {
+                    const int sh = b0 - blo;
+                    if (sh > 0) {  // (cc is dead after this batch: the next one packs its own)
 #pragma unroll
-                                for (int m = 0; m < 16; ++m) cc[m] = (uint32_t)__builtin_amdgcn_readlane(pk_cur, (4 * m + 8 * sh) & 63);
-                            }
-                            splat(b1 - b0, cc, a_rec0 + (uint32_t)(2 * kWRecG * 4) * (uint32_t)sh, a_fst0 + 1024u * (uint32_t)sh);
-                            b0 = b1;
-                        }
-                        if (gbk > bhi) break;
-                        complete();
-                        if (kd == kWPts) break;
+                        for (int m = 0; m < 16; ++m) cc[m] = (uint32_t)__builtin_amdgcn_readlane(pk_cur, (4 * m + 8 * sh) & 63);
                     }
-                    // (the compiler may not move the rotation of the in-flight loads -- register copies, each behind a wait for
-                    // every load issued before it -- in front of the splat: volatile asm statements keep their order)
-                    asm volatile("" : "+v"(jn), "+v"(nvn), "+v"(qx), "+v"(qy), "+v"(qz));
-                    if (more) {
-                        wfence();
-                        f_publish(np1, ff);
-                        push_rec(nxt);
-                        pk_cur = pack_classes(nxt.cls4, cc);
-                        j1 = j2;
-                        nv1 = nv2;
-                        j2 = jn;
-                        nv2 = nvn;
-                        px = qx;
-                        py = qy;
-                        pz = qz;
-                        wfence();
-                    }
+                    splat(b1 - b0, cc, a_rec0 + (uint32_t)(2 * kWRecG * 4) * (uint32_t)sh, a_fst0 + 1024u * (uint32_t)sh);
+                    b0 = b1;
+                    WT(1)
+                }
+                if (gbk > bhi) break;
+                const bool last_row = (rdone & 3) == 3;
+                complete();
+                WT(2)
+                if (last_row) {
+                    tile_done = true;
+                    break;
                 }
             }
-            while (kd < kWPts) complete();  // (empty rows at the end of the stream, or no pairs at all)
-            WS_BARRIER();  // "full": the 16 rows of the tile are in LDS
+            // (the compiler may not move the rotation of the in-flight loads -- register copies, each behind a wait for every load
+            // issued before it -- in front of the splat: volatile asm statements keep their order)
+            asm volatile("" : "+v"(jn), "+v"(nvn), "+v"(qx), "+v"(qy), "+v"(qz), "+v"(kkn));
+#ifdef WS_TRACE
+            ++nbatches;
+#endif
+            WT(7)
+            if (tile_done) {
+                WS_BARRIER();  // "full": the 16 rows of the tile are in LDS
+                WT(3)
+                ++ti;
+                if ((ti & 7) == 0) ws_refill(kp0, (ti >> 3) + 1, lane, wave, t_begin, t_end, nslots, Tab, stream_end, ring);
+                nblk_tile = (max(__builtin_amdgcn_readlane(ring.end, (4 * ti + 3) & 63), __builtin_amdgcn_readlane(ring.start, (4 * ti + 3) & 63) + 1) + 7) >> 3;
+                gend = __builtin_amdgcn_readlane(ring.start, (4 * ti + 4) & 63) >> 6;
+                WT(4)
+                WS_BARRIER();  // "free": the consumers hold the tile in registers
+                WT(5)
+            }
+            if (!more) break;
+            wfence();
+            f_publish(np1, ff);
+            push_rec(nxt);
+            pk_cur = pack_classes(nxt.cls4, cc);
+            j1 = j2;
+            nv1 = nv2;
+            kk1 = kk2;
+            np1 = np2;
+            j2 = jn;
+            nv2 = nvn;
+            kk2 = kkn;
+            np2 = npn;
+            px = qx;
+            py = qy;
+            pz = qz;
+            wfence();
+            WT(6)
         }
-        WS_BARRIER();  // (the consumers' last "free")
-        WS_BARRIER();  // (... and the barrier behind which they store the last tile's sums)
+        WS_BARRIER();  // (the barrier behind which the consumers store the last tile's sums)
+#ifdef WS_TRACE
+        if (lane == 0 && wave == 0 && (blockIdx.x & 15) == 0) {
+            for (int k = 0; k < 8; ++k) atomicAdd(&g_wtrace[k], wt[k]);
+            atomicAdd(&g_wtrace[8], wlast - wstart);
+            atomicAdd(&g_wtrace[9], (unsigned long long)T);
+            atomicAdd(&g_wtrace[10], (unsigned long long)nbatches);
+        }
+#endif
     } else {
         // =============================================== CONSUMER ===============================================
         const int cw = wave - kWProd;             // 0 .. 3
@@ -527,12 +629,18 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         for (int q = 0; q < kRing; ++q)
             if (q < cin) w_issue(q, bw[q]);
         WS_BARRIER();  // "free" of the first tile
+#ifdef WS_TRACE
+        uint64_t wt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t wlast = __builtin_readcyclecounter();
+        const uint64_t wstart = wlast;
+#endif
 #pragma unroll 1
         for (int tile = t_begin; tile < t_end; tile += nslots) {
             const int64_t pt0 = (int64_t)tile * WTM;
             WsKP kp = kp0;
             asm volatile("" : "+s"(kp), "+s"(cwo), "+v"(a_lane), "+v"(w_lane));
             WS_BARRIER();  // "full"
+            WT(0)
 #ifdef WS_DBG_NOCONS
             WS_BARRIER();
             continue;
@@ -548,7 +656,10 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             WS_PULL4(0) WS_PULL4(1) WS_PULL4(2) WS_PULL4(3) WS_PULL4(4) WS_PULL4(5) WS_PULL4(6) WS_PULL4(7)
             // ---- the previous tile's sums (every consumer wrote its part before the barrier above)
             if (prev_pt0 >= 0) reduce_store(kp);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WT(1)
             WS_BARRIER();  // "free" (waits for the pull and for the reads of the sums)
+            WT(2)
             // ---- what the epilogue adds to, requested now (read behind the next barrier)
 #pragma unroll
             for (int r = 0; r < NTT; ++r) {
@@ -593,13 +704,31 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
                     for (int r = 0; r < 4; ++r) red[(cw * 16 + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
                 }
             }
+            WT(3)
         }
         WS_BARRIER();  // every consumer's sums of the last tile are in LDS
+#ifdef WS_TRACE
+        if (lane == 0 && cw == 0 && (blockIdx.x & 15) == 0) {
+            for (int k = 0; k < 4; ++k) atomicAdd(&g_wtrace[16 + k], wt[k]);
+            atomicAdd(&g_wtrace[20], wlast - wstart);
+        }
+#endif
 #ifndef WS_DBG_NOCONS
         reduce_store(kp0);
 #endif
     }
 }
+
+#ifdef WS_TRACE
+}
+extern "C" int dmcf_wtrace(unsigned long long* out) {
+    unsigned long long z[32] = {0};
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(dmcf::g_wtrace), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(dmcf::g_wtrace), z, sizeof(z));
+    return 0;
+}
+namespace dmcf {
+#endif
 
 static constexpr size_t kWsLds = (size_t)(WTM * kWRow + kWProd * kWWaveF + kWRed) * sizeof(float);
 
@@ -637,11 +766,9 @@ int cconv_ws_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hi
     const unsigned grid = (unsigned)per_xcd * 8u;
     const void* fn;
     if (cconv_plain(a))
-        fn = NT <= 1 ? (const void*)cconv_ws_kernel<1, true>
-                     : (NT <= 2 ? (const void*)cconv_ws_kernel<2, true> : (const void*)cconv_ws_kernel<4, true>);
+        fn = NT <= 1 ? (const void*)cconv_ws_kernel<1, true> : (const void*)cconv_ws_kernel<2, true>;
     else
-        fn = NT <= 1 ? (const void*)cconv_ws_kernel<1, false>
-                     : (NT <= 2 ? (const void*)cconv_ws_kernel<2, false> : (const void*)cconv_ws_kernel<4, false>);
+        fn = NT <= 1 ? (const void*)cconv_ws_kernel<1, false> : (const void*)cconv_ws_kernel<2, false>;
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWsLds);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;

@@ -895,7 +895,7 @@ def test_row_length_hint_picks_the_kernel_for_wide_layers(oracle, dev):
 
 @pytest.mark.parametrize("kernel,cin,cout,ks", [("lds", 8, 16, (4, 4, 4)), ("blk", 16, 16, (4, 4, 4)), ("cls", 24, 16, (4, 4, 4)), ("mfma", 16, 8, (1, 8, 8)),
                                                 ("z3", 24, 16, (4, 4, 4)), ("pair", 24, 16, (4, 4, 4)), ("pair", 32, 40, (4, 4, 4)),
-                                                ("ws", 24, 16, (4, 4, 4)), ("ws", 32, 40, (4, 4, 4)), ("ws", 8, 16, (4, 4, 4)),
+                                                ("ws", 24, 16, (4, 4, 4)), ("ws", 32, 32, (4, 4, 4)), ("ws", 8, 16, (4, 4, 4)),
                                                 ("g16", 16, 16, (4, 4, 4)), ("g16", 8, 40, (4, 4, 4)),
                                                 ("direct", 32, 3, (6, 6, 6)), ("lds", 4, 8, (3, 5, 2))])
 def test_padded_single_pass_search_and_conv(dev, monkeypatch, kernel, cin, cout, ks):
