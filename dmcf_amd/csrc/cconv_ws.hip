@@ -119,6 +119,19 @@ __device__ __forceinline__ void ws_filter_coords(float& x, float& y, float& z, f
                  :                                                                                                          \
                  : "v"((BV).x), "v"((BV).y), "v"((BV).z), "v"((BV).w)                                                      \
                  : WS_FIXED_REGS)
+// two column tiles, interleaved: a matrix instruction whose accumulator the previous one wrote issues a few clocks later
+#define WS_MFMA2(IT, BV0, BV1)                                                                                              \
+    asm volatile("v_mfma_f32_16x16x4_f32 v[112:115], v[128+4*(" #IT ")+0], %0, v[112:115]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[116:119], v[128+4*(" #IT ")+0], %4, v[116:119]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[112:115], v[128+4*(" #IT ")+1], %1, v[112:115]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[116:119], v[128+4*(" #IT ")+1], %5, v[116:119]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[112:115], v[128+4*(" #IT ")+2], %2, v[112:115]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[116:119], v[128+4*(" #IT ")+2], %6, v[116:119]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[112:115], v[128+4*(" #IT ")+3], %3, v[112:115]\n\t"                               \
+                 "v_mfma_f32_16x16x4_f32 v[116:119], v[128+4*(" #IT ")+3], %7, v[116:119]"                                    \
+                 :                                                                                                          \
+                 : "v"((BV0).x), "v"((BV0).y), "v"((BV0).z), "v"((BV0).w), "v"((BV1).x), "v"((BV1).y), "v"((BV1).z), "v"((BV1).w) \
+                 : WS_FIXED_REGS)
 #define WS_ACC_READ(N, DST)                                                                                                 \
     asm volatile("v_mov_b32 %0, v[112+4*" #N "+0]\n\tv_mov_b32 %1, v[112+4*" #N "+1]\n\tv_mov_b32 %2, v[112+4*" #N "+2]\n\t"     \
                  "v_mov_b32 %3, v[112+4*" #N "+3]"                                                                          \
@@ -553,46 +566,35 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         const int mi = lane & 15, mg = lane >> 4;
         float* red = smem + WTM * kWRow + kWProd * kWWaveF;  // [kWCons][16][16 * NT]
         const int NT = kp0->NT, ncol = 16 * NT;
-        // This consumer's k' blocks: b = cw + 4 it of the 16 (z, y) x cin / 4 channel quads, b = zy * nqt + quad (it < cin)
+        // This consumer's k' blocks: b = cw + 4 it of the 16 (z, y) x cin / 4 channel quads, b = zy * nqt + quad (it < cin).  What a
+        // block needs -- the offset of its A fragments in a B row, the offset of its filter fragments in the packed filter -- is
+        // the same for every tile: lane it of two registers holds them (one v_readlane per use; computed per block in scalar
+        // code, they were hoisted out of the tile loop and spilled).  The block count is rounded up to a multiple of the ring of
+        // filter fragments (8 blocks in flight, which runs on across tiles), so that block it finds its fragments in slot it % 8;
+        // the blocks past cin in that count have A fragments of zeros and filter offsets outside the buffer (zeros as well).
+        constexpr int kRing = 8;
+        const int cin_ring = (cin + kRing - 1) & ~(kRing - 1);
         const int nqt = cin >> 2;
-        const int dm = nqt == 1 ? 1024 : (nqt == 2 ? 512 : (nqt == 3 ? 342 : (nqt == 4 ? 256 : (nqt == 5 ? 205 : (nqt == 6 ? 171 : (nqt == 7 ? 147 : 128))))));
-        int cwo = cw;  // (made opaque per tile: nothing derived from it is hoisted out of the tile loop)
-        auto decode = [=, &cwo](int it, int& chunk, int& blk, int& qg) {
-            const int b = cwo + 4 * it;
-            const int zy = (b * dm) >> 10;  // b / nqt, exact below 128
-            qg = b - zy * nqt;
-            chunk = qg >> 2;
-            blk = zy * 4 + (qg & 3);
-        };
+        int a_tab, w_tab, w_next;  // lane it: block it's A offset (bytes, inside a row: chunk and k' block) / filter offset / block it + 8's
+        {
+            const int b = cw + 4 * (lane & 31);
+            const int zy = b / nqt, qg = b - zy * nqt;
+            const int chunk = qg >> 2, blk = zy * 4 + (qg & 3);
+            const bool real = (lane & 31) < cin;
+            a_tab = real ? chunk * 4096 + blk * 64 : -1;
+            w_tab = real ? (chunk * 64 + blk) * NT * 1024 : 0x7fff0000;
+            int nx = (lane & 31) + kRing;
+            if (nx >= cin_ring) nx -= cin_ring;
+            w_next = __shfl(w_tab, nx);
+        }
         const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc(
             (void*)kp0->Wp, 0, (int)((uint32_t)kp0->nchunks * 64u * (uint32_t)NT * 1024u), 0x00020000);
-        const uint32_t wmask = kp0->wmask;
         uint32_t w_lane = ((uint32_t)mg * (uint32_t)NT * 16u + (uint32_t)mi) * 16u;
-        // blocks whose filter fragments are in flight (the ring runs on across tiles -- a consumer's blocks are the same for every
-        // tile -- over the block count rounded up to a multiple of the ring, so that a block always finds its fragments in slot
-        // it % kRing; the blocks past cin in that count do not exist: nothing is requested, nothing multiplied)
-        constexpr int kRing = NTT <= 2 ? 8 : 4;
-        const int cin_ring = (cin + kRing - 1) & ~(kRing - 1);
         f32x4 bw[kRing][NTT];
-        auto w_issue = [&](int it, f32x4 (&dst)[NTT]) {
-            int chunk, blk, qg;
-            decode(it, chunk, blk, qg);
-            const uint32_t w_blk = (uint32_t)(chunk * 64 + blk) * (uint32_t)NT * 1024u;
-            const uint32_t wm = wmask >> (4 * qg);  // (all-zero filter blocks: not fetched; cin <= 32: quads 0 .. 7)
-#pragma unroll
-            for (int n = 0; n < NTT; ++n)
-                if (n < NT && ((wm >> n) & 1))
-                    dst[n] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, w_lane, w_blk + 256u * (uint32_t)n, 0));
-        };
         // A fragments: lane (row mi, k' group mg) of block blk of chunk reads 4 floats at row * kWRow + chunk * 1024 +
         // ((blk * 16 + mg * 4) ^ (mi << 2)) = ... + ((blk * 16) ^ lane_x)
         uint32_t a_lane = wlds(Bt + mi * kWRow);
-        const uint32_t lane_x = (uint32_t)((mg << 2) ^ (mi << 2));
-        auto a_addr = [&](int it) -> uint32_t {
-            int chunk, blk, qg;
-            decode(it, chunk, blk, qg);
-            return a_lane + (uint32_t)chunk * 4096u + ((((uint32_t)blk * 16u) ^ lane_x) << 2);
-        };
+        const uint32_t lane_x = (uint32_t)((mg << 2) ^ (mi << 2)) << 2;
         // epilogue roles: this lane's outputs e = ctid + 256 r of the tile (point e / cout, channel e % cout) -- the same for every tile
         int e_pt[NTT], e_o[NTT];
         float e_bias[NTT];
@@ -625,9 +627,14 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             }
         };
 #define WS_RING(IT) bw[(IT) % kRing]
-#pragma unroll
-        for (int q = 0; q < kRing; ++q)
-            if (q < cin) w_issue(q, bw[q]);
+#define WS_WLOAD(IT, OFF)                                                                                                    \
+    {                                                                                                                        \
+        const uint32_t o_ = w_lane + (uint32_t)__builtin_amdgcn_readlane(OFF, IT);                                           \
+        WS_RING(IT)[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, o_, 0, 0));                     \
+        if (NTT > 1) WS_RING(IT)[1 % NTT] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rW, o_ + 256u, 0, 0)); \
+    }
+        WS_WLOAD(0, w_tab) WS_WLOAD(1, w_tab) WS_WLOAD(2, w_tab) WS_WLOAD(3, w_tab)
+        WS_WLOAD(4, w_tab) WS_WLOAD(5, w_tab) WS_WLOAD(6, w_tab) WS_WLOAD(7, w_tab)
         WS_BARRIER();  // "free" of the first tile
 #ifdef WS_TRACE
         uint64_t wt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -638,7 +645,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         for (int tile = t_begin; tile < t_end; tile += nslots) {
             const int64_t pt0 = (int64_t)tile * WTM;
             WsKP kp = kp0;
-            asm volatile("" : "+s"(kp), "+s"(cwo), "+v"(a_lane), "+v"(w_lane));
+            asm volatile("" : "+s"(kp), "+v"(a_lane), "+v"(w_lane), "+v"(a_tab), "+v"(w_next));
             WS_BARRIER();  // "full"
             WT(0)
 #ifdef WS_DBG_NOCONS
@@ -646,14 +653,21 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             continue;
 #endif
             // ---- pull this consumer's blocks of the 16 rows into v128 .. v255
-#define WS_PULL4(G)                                         \
-    if (4 * (G) < cin) {                                    \
-        WS_PULL(4 * (G) + 0, a_addr(4 * (G) + 0));          \
-        WS_PULL(4 * (G) + 1, a_addr(4 * (G) + 1));          \
-        WS_PULL(4 * (G) + 2, a_addr(4 * (G) + 2));          \
-        WS_PULL(4 * (G) + 3, a_addr(4 * (G) + 3));          \
+#define WS_PULL1(IT)                                                                                         \
+    {                                                                                                            \
+        const int ao_ = __builtin_amdgcn_readlane(a_tab, IT);                                                    \
+        if (ao_ >= 0) {                                                                                          \
+            WS_PULL(IT, a_lane + (((uint32_t)ao_) ^ lane_x));                                                    \
+        } else {                                                                                                 \
+            asm volatile("v_mov_b64 v[128+4*(" #IT "):128+4*(" #IT ")+1], 0\n\tv_mov_b64 v[128+4*(" #IT ")+2:128+4*(" #IT ")+3], 0" ::: WS_FIXED_REGS); \
+        }                                                                                                        \
     }
-            WS_PULL4(0) WS_PULL4(1) WS_PULL4(2) WS_PULL4(3) WS_PULL4(4) WS_PULL4(5) WS_PULL4(6) WS_PULL4(7)
+#define WS_PULL8(G)                                                                                              \
+    if (8 * (G) < cin_ring) {                                                                                    \
+        WS_PULL1(8 * (G) + 0) WS_PULL1(8 * (G) + 1) WS_PULL1(8 * (G) + 2) WS_PULL1(8 * (G) + 3)                  \
+        WS_PULL1(8 * (G) + 4) WS_PULL1(8 * (G) + 5) WS_PULL1(8 * (G) + 6) WS_PULL1(8 * (G) + 7)                  \
+    }
+            WS_PULL8(0) WS_PULL8(1) WS_PULL8(2) WS_PULL8(3)
             // ---- the previous tile's sums (every consumer wrote its part before the barrier above)
             if (prev_pt0 >= 0) reduce_store(kp);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -671,23 +685,29 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             // ---- contraction from registers
             // (a vector write -> matrix read as the accumulator: two wait states)
             asm volatile(".irp r,112,114,116,118,120,122,124,126\n\tv_mov_b64 v[\\r:\\r+1], 0\n\t.endr\n\ts_nop 1" ::: WS_FIXED_REGS);
-#define WS_BLOCK(IT)                                                                  \
-    if ((IT) < cin) {                                                                 \
-        int chunk_, blk_, qg_;                                                        \
-        decode((IT), chunk_, blk_, qg_);                                              \
-        const uint32_t wm_ = wmask >> (4 * qg_);                                      \
-        if (((wm_ >> 0) & 1)) WS_MFMA(IT, 0, WS_RING(IT)[0]);                            \
-        if (NTT > 1 && 1 < NT && ((wm_ >> 1) & 1)) WS_MFMA(IT, 1, WS_RING(IT)[1 % NTT]);  \
-        if (NTT > 2 && 2 < NT && ((wm_ >> 2) & 1)) WS_MFMA(IT, 2, WS_RING(IT)[2 % NTT]);  \
-        if (NTT > 2 && 3 < NT && ((wm_ >> 3) & 1)) WS_MFMA(IT, 3, WS_RING(IT)[3 % NTT]);  \
-    }                                                                                 \
-    if ((IT) < cin_ring && kRing < cin) {                                             \
-        int nx_ = (IT) + kRing;                                                       \
-        if (nx_ >= cin_ring) nx_ -= cin_ring;                                         \
-        if (nx_ < cin) w_issue(nx_, WS_RING(IT));                                     \
-    }
-#define WS_BLOCK4(G) WS_BLOCK(4 * (G) + 0) WS_BLOCK(4 * (G) + 1) WS_BLOCK(4 * (G) + 2) WS_BLOCK(4 * (G) + 3)
-            WS_BLOCK4(0) WS_BLOCK4(1) WS_BLOCK4(2) WS_BLOCK4(3) WS_BLOCK4(4) WS_BLOCK4(5) WS_BLOCK4(6) WS_BLOCK4(7)
+            // Straight-line code with ONE way out per group of 8 blocks: the compiler then counts the filter loads in flight and
+            // waits for exactly the block's own (s_waitcnt vmcnt(14)); with a branch around every block it waited for ALL of them
+            // -- the eight blocks' worth just requested included: a round trip to L2 per block, 27k clocks per tile for the 8.2k
+            // of matrix time of a 32 -> 32 layer (tools/wtrace.py).
+#define WS_BLOCK(IT)                                                      \
+    if (NTT > 1) {                                                        \
+        WS_MFMA2(IT, WS_RING(IT)[0], WS_RING(IT)[1 % NTT]);               \
+    } else {                                                              \
+        WS_MFMA(IT, 0, WS_RING(IT)[0]);                                   \
+    }                                                                     \
+    WS_WLOAD(IT, w_next)
+#define WS_BLOCK8(G)                                                                                             \
+    WS_BLOCK(8 * (G) + 0) WS_BLOCK(8 * (G) + 1) WS_BLOCK(8 * (G) + 2) WS_BLOCK(8 * (G) + 3)                      \
+    WS_BLOCK(8 * (G) + 4) WS_BLOCK(8 * (G) + 5) WS_BLOCK(8 * (G) + 6) WS_BLOCK(8 * (G) + 7)
+            do {
+                WS_BLOCK8(0)
+                if (cin_ring <= 8) break;
+                WS_BLOCK8(1)
+                if (cin_ring <= 16) break;
+                WS_BLOCK8(2)
+                if (cin_ring <= 24) break;
+                WS_BLOCK8(3)
+            } while (false);
             // ---- partial sums (the results of the last matrix instructions are 11 wait states away from a vector read)
             asm volatile("s_nop 15" ::: WS_FIXED_REGS);
             f32x4 acc[NTT];
@@ -747,7 +767,10 @@ bool cconv_ws_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     // 24-bit multiplies form the byte offsets of feature and position rows; the buffers must stay below 2 GB
     if (a->n_inp >= (1 << 24) || a->n_inp * (int64_t)cin * 4 >= ((int64_t)1 << 31)) return false;
     if (e) return true;
-    return false;
+    // short rows (the layers at the network's base radius) whose contraction is at least as much work as their splat: the 32 -> 32
+    // layer takes 2.96 ms here against 3.35 with splat E, 24 -> 16 2.36 against 2.56; 16 -> 32 and 8 -> 16 lose (2.45 / 2.07 against
+    // 1.83 / 1.30: the producers are alone on their SIMDs and every phase of theirs runs at its latency) -- profiles/r05_microbench.md
+    return a->row_length_hint == 1 && cin >= 24;
 }
 
 int cconv_ws_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, hipStream_t stream) {

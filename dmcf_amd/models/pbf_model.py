@@ -406,7 +406,14 @@ class PBFNet(BaseModel):
         if self.equivar:  # :456-463: the network's output scales the mean offset to the neighbours (rot stays None there too)
             if self.shard is not None:
                 raise NotImplementedError("equivar in a sharded step (its search has no ghost plan)")
-            out = compute_transformed_dx(self.all_pos, self.scale_dens(out), None, radius=self.particle_radii[0])
+            scale = self.scale_dens(out)
+            if scale.shape[0] != self.all_pos.shape[0]:
+                # use_bnds=False: the network's output has the fluid rows only while compute_transformed_dx gathers scale[idx]
+                # with neighbour indices over ALL points (losses.py:310-336).  The reference has the same mismatch; TensorFlow's
+                # GPU gather returns zeros for the out-of-range rows where a device gather here would read out of bounds
+                raise NotImplementedError("equivar with use_bnds=False: the scale has %d rows for %d points (the reference's own "
+                                          "gather is out of range there)" % (scale.shape[0], self.all_pos.shape[0]))
+            out = compute_transformed_dx(self.all_pos, scale, None, radius=self.particle_radii[0])
         if out.shape[-1] == 1:  # :466-469
             out = out.repeat(1, 3)
         elif out.shape[-1] == 2:

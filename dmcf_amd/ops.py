@@ -310,6 +310,8 @@ SEARCH_SETS = {"distance": 0, "open3d": FRS_OPEN3D_VOXEL_WALK, "open3d_corners":
 
 def search_set():
     """The neighbour set in force: environment variable DMCF_FRS_SET (see SEARCH_SETS), "distance" when unset."""
+    if "DMCF_FRS_BRUTE_FORCE_SET" in os.environ:  # (round 3's switch; silently ignoring it would run another neighbour set than asked for)
+        raise ValueError("DMCF_FRS_BRUTE_FORCE_SET is gone: use DMCF_FRS_SET=distance (what it selected) | open3d | open3d_corners")
     name = os.environ.get("DMCF_FRS_SET", "distance")
     if name not in SEARCH_SETS:
         raise ValueError(f"DMCF_FRS_SET={name!r}: expected one of {sorted(SEARCH_SETS)}")

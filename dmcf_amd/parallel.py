@@ -593,7 +593,7 @@ class ShardedSimulator:
     ``forward`` (models/hrnet.py, sym_net.py, cconv.py): this class only installs ``model.conv_hook``, through which
     every ContinuousConv call of the forward pass gets its input rows extended by the ghosts within the layer's radius."""
 
-    def __init__(self, model, comm, decomp, reserve_gib="auto"):
+    def __init__(self, model, comm, decomp, reserve_gib=None):
         self.model = model
         self.comm = comm
         self.decomp = decomp
@@ -812,8 +812,11 @@ class ShardedSimulator:
         R = self.model.R.t().contiguous() if "grav_eqvar" in tr else None
 
         def view(x):
+            # (an explicit row-wise form, not `x @ R`: sender and receiver of a derived ghost plan evaluate this on row sets of
+            # different sizes and rely on bit-identical rows -- a BLAS product of a different shape may sum in another order,
+            # and one point within an ulp of a plan's width then gives mismatched all-to-all split sizes: ADVICE r04)
             if R is not None:
-                x = x @ R
+                x = (x[:, 0:1] * R[0] + x[:, 1:2] * R[1]) + x[:, 2:3] * R[2]
             return x / s - t
         d.view = view
         d.inflate = 1.0 / min([v for v in sc if v > 1e-5] + [1.0]) if any(v < 1.0 for v in sc) else 1.0

@@ -29,7 +29,7 @@ RESERVE_BYTES_PER_POINT = 40 * 1024
 
 def reserve_for_scene(reserve_gib, n_points, device):
     """The ``reserve_gib`` rule of Simulator / ShardedSimulator for a scene of ``n_points`` particles (fluid + boundary): "auto" =
-    RESERVE_BYTES_PER_POINT each, at most a quarter of the device, at least 0.25 GiB.  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
+    RESERVE_BYTES_PER_POINT each, at most an eighth of the device, at least 0.25 GiB.  Returns what ops.reserve_device_memory reports (0.0 when nothing was asked for)."""
     gib = reserve_gib
     if gib and device is not None and torch.device(device).type == "cuda":
         # torch's allocator serves requests up to 1 MB from 2 MB segments of their own ("small pool"): row splits, counts,
@@ -44,8 +44,9 @@ def reserve_for_scene(reserve_gib, n_points, device):
         _unique_first_occurrence(torch.arange(8, dtype=torch.int64, device=device) % 3)
     if gib == "auto":
         gib = n_points * RESERVE_BYTES_PER_POINT / 2 ** 30
-        gib = min(gib, torch.cuda.mem_get_info(device)[1] / 2 ** 30 / 4)  # (total device memory)
+        gib = min(gib, torch.cuda.mem_get_info(device)[1] / 2 ** 30 / 8)  # (total device memory)
         gib = max(gib, 0.25)  # (the 2-D scenes: their lists are a few MB, but grow with every particle that leaves the tank)
+        log.info("reserve_gib='auto': %.2f GiB of device memory go to the caching allocator's pool before the first step", gib)
     return ops.reserve_device_memory(float(gib), device) if gib else 0.0
 
 
@@ -54,7 +55,8 @@ class steady_steps:
     loop (the young generation is collected by hand every ``every`` steps).  A step of the 2-D models is ~5 ms of host work
     (40+ launches per layer stack); a generation-2 collection in the middle of one is what the rollouts' p99 showed
     (WBC-SPH, 3200 steps: p99 / median 1.2 - 1.55 with the collector running, 1.22 without, tools/long_rollout.py).
-    ``Simulator.run_rollout`` runs inside one."""
+    ``Simulator.run_rollout`` runs inside one.  The switch is process wide (other threads see the collector off as well) for
+    the duration of the ``with`` block."""
 
     def __init__(self, every=256):
         self.every, self.n = int(every), 0
@@ -66,9 +68,14 @@ class steady_steps:
         gc.disable()
         return self
 
-    def tick(self):
+    def tick(self, full=False):
+        """Once per step.  ``full``: a whole collection now (a step was repeated: the exception's traceback may hold device
+        tensors in a cycle); otherwise the young generation every ``every`` steps and everything every 16 x ``every`` -- cycles
+        that hold device buffers (closures of the neighbour lists, tracebacks) must not live until the rollout ends."""
         self.n += 1
-        if self.n % self.every == 0:
+        if full or self.n % (16 * self.every) == 0:
+            self.gc.collect()
+        elif self.n % self.every == 0:
             self.gc.collect(0)
 
     def __exit__(self, *exc):
@@ -79,12 +86,15 @@ class steady_steps:
 
 class Simulator:
     def __init__(self, model, dataset=None, name="Simulator", main_log_dir="./logs/", device="cuda", split="train",
-                 reserve_gib="auto", **kwargs):
-        """``reserve_gib`` (not in the reference; a ``pipeline:`` key like the others): device memory handed to torch's
-        caching allocator as one block before the first step (ops.reserve_device_memory), so that the multi-GB neighbour-list
-        buffers of a large scene -- and the bigger ones it grows into -- never wait for a hipMalloc in the middle of a rollout.
-        "auto" = RESERVE_BYTES_PER_POINT per particle (fluid + boundary) of the first scene, at most a quarter of the device;
-        0 / None = none."""
+                 reserve_gib=None, **kwargs):
+        """``reserve_gib`` (not in the reference; a ``pipeline:`` key like the others, OFF unless asked for): device memory handed
+        to torch's caching allocator as one block before the first step (ops.reserve_device_memory), so that the multi-GB
+        neighbour-list buffers of a large scene -- and the bigger ones it grows into -- never wait for a hipMalloc in the middle
+        of a rollout.  "auto" = RESERVE_BYTES_PER_POINT per particle (fluid + boundary) of the first scene, at most an EIGHTH of
+        the device (43 GiB would be the rule's figure for 1M particles: 36 GiB on a 288 GB part), logged when taken; a number =
+        that many GiB; 0 / None (the default) = none -- the library itself never allocates device memory (INTEGRATION.md
+        section 4), and a caller who did not ask does not lose a slice of the device to this module either.  bench.py asks for
+        "auto" and reports what it got (``scene_state.reserved_gib``)."""
         self.cfg = Config(dict(kwargs, name=name, main_log_dir=main_log_dir, device=device, split=split, reserve_gib=reserve_gib))
         self.name = name
         self.model = model
@@ -156,6 +166,7 @@ class Simulator:
             for _ in range(timesteps - 1):
                 torch.cuda.synchronize(self.device)
                 start = time.time()
+                repeated = self.repeated_steps
                 for i in range(len(inputs)):
                     self._slot0 = i  # each scene keeps its own buffer-size estimates
                     inputs[i] = self.run_inference(inputs[i:i + 1])[0]
@@ -164,7 +175,7 @@ class Simulator:
                 timing.append(time.time() - start)
                 for i in range(len(inputs)):
                     results[i].append(inputs[i])
-                steady.tick()
+                steady.tick(full=self.repeated_steps != repeated)
         self.timing = timing
         if timing:
             log.info("Average runtime: %.05f" % (np.mean(timing) / len(inputs)))

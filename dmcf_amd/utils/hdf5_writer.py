@@ -11,6 +11,7 @@ version 1.  No chunking, no compression, no free-space management: everything is
 ``tests/test_hdf5_writer.py`` reads the files back with the HDF5 C library itself (libhdf5 through ctypes, where the image has
 it) and with an independent walk of the structures.
 """
+import os
 import struct
 
 import numpy as np
@@ -79,23 +80,36 @@ def _attribute(name, value):
 
 
 class _Layout:
-    """Byte image of the file, appended to in 8-byte aligned pieces."""
+    """The file, written as it is laid out: 8-byte aligned pieces appended straight to the (temporary) file -- a rollout's
+    pred / gt arrays are tens of GB at 1M particles, and a byte image of the whole file in memory next to them (round 4) was
+    three times that."""
 
-    def __init__(self):
-        self.buf = bytearray()
+    def __init__(self, f):
+        self.f, self.size = f, 0
 
     def reserve(self, n):
-        self.buf += b"\0" * (-len(self.buf) % 8)
-        at = len(self.buf)
-        self.buf += b"\0" * n
+        pad = -self.size % 8
+        at = self.size + pad
+        self.f.seek(self.size)
+        self.f.write(b"\0" * (pad + n))
+        self.size = at + n
         return at
 
     def put(self, at, b):
-        self.buf[at:at + len(b)] = b
+        self.f.seek(at)
+        self.f.write(b)
 
     def add(self, b):
-        at = self.reserve(len(b))
-        self.put(at, b)
+        """``b``: bytes or a C-contiguous numpy array (written from its own buffer, no copy)."""
+        n = b.nbytes if isinstance(b, np.ndarray) else len(b)
+        pad = -self.size % 8
+        at = self.size + pad
+        self.f.seek(self.size)
+        if pad:
+            self.f.write(b"\0" * pad)
+        if n:
+            self.f.write(memoryview(b).cast("B") if isinstance(b, np.ndarray) else b)
+        self.size = at + n
         return at
 
 
@@ -132,33 +146,41 @@ def _group(lay, entries):
 
 
 def write_hdf5(path, group, datasets):
-    """``datasets``: [(name, array, {attribute name: str | array})] -> file ``path`` with ONE group ``group`` holding them."""
-    lay = _Layout()
-    lay.reserve(96)  # the superblock, written last (it holds the end-of-file address)
-    members = []
-    for name, arr, attrs in datasets:
-        arr = np.ascontiguousarray(arr)
-        if arr.dtype.kind == "f" and arr.dtype.itemsize not in (4, 8):
-            arr = arr.astype(np.float32)
-        raw = arr.tobytes()
-        data_at = lay.add(raw) if raw else UNDEF
-        msgs = [
-            _message(0x0001, _dataspace(arr.shape)),
-            _message(0x0003, _datatype(arr.dtype), flags=1),  # (constant message, as the library marks it)
-            _message(0x0005, struct.pack("<BBBB", 2, 2, 2, 0)),  # fill value v2: late allocation, written if set, undefined
-            _message(0x0008, struct.pack("<BBQQ", 3, 1, data_at, len(raw))),  # layout v3, contiguous
-        ]
-        msgs += [_attribute(k, v) for k, v in attrs.items()]
-        members.append((name, lay.add(_object_header(msgs)), False, None))
-    g_header, g_btree, g_heap = _group(lay, members)
-    r_header, r_btree, r_heap = _group(lay, [(group, g_header, True, (g_btree, g_heap))])
-    eof = len(lay.buf) + (-len(lay.buf) % 8)
-    lay.buf += b"\0" * (eof - len(lay.buf))
-    sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0)
-    sb += struct.pack("<HHI", LEAF_K, INTERNAL_K, 0)
-    sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
-    sb += struct.pack("<QQII", 0, r_header, 1, 0) + struct.pack("<QQ", r_btree, r_heap)  # root group symbol table entry
-    assert len(sb) == 96
-    lay.put(0, sb)
-    with open(path, "wb") as f:
-        f.write(bytes(lay.buf))
+    """``datasets``: [(name, array, {attribute name: str | array})] -> file ``path`` with ONE group ``group`` holding them.
+    Written to ``path + ".tmp"`` and renamed when complete: a crash in the middle leaves no truncated .hdf5 behind."""
+    tmp = path + ".tmp"
+    try:
+        with open(tmp, "wb") as f:
+            lay = _Layout(f)
+            lay.reserve(96)  # the superblock, written last (it holds the end-of-file address)
+            members = []
+            for name, arr, attrs in datasets:
+                arr = np.ascontiguousarray(arr)
+                if arr.dtype.kind == "f" and arr.dtype.itemsize not in (4, 8):
+                    arr = arr.astype(np.float32)
+                nbytes = arr.nbytes
+                data_at = lay.add(arr) if nbytes else UNDEF
+                msgs = [
+                    _message(0x0001, _dataspace(arr.shape)),
+                    _message(0x0003, _datatype(arr.dtype), flags=1),  # (constant message, as the library marks it)
+                    _message(0x0005, struct.pack("<BBBB", 2, 2, 2, 0)),  # fill value v2: late allocation, written if set, undefined
+                    _message(0x0008, struct.pack("<BBQQ", 3, 1, data_at, nbytes)),  # layout v3, contiguous
+                ]
+                msgs += [_attribute(k, v) for k, v in attrs.items()]
+                members.append((name, lay.add(_object_header(msgs)), False, None))
+            g_header, g_btree, g_heap = _group(lay, members)
+            r_header, r_btree, r_heap = _group(lay, [(group, g_header, True, (g_btree, g_heap))])
+            eof = lay.size + (-lay.size % 8)
+            if eof > lay.size:
+                lay.reserve(0)
+            sb = b"\x89HDF\r\n\x1a\n" + struct.pack("<BBBBBBBB", 0, 0, 0, 0, 0, 8, 8, 0)
+            sb += struct.pack("<HHI", LEAF_K, INTERNAL_K, 0)
+            sb += struct.pack("<QQQQ", 0, UNDEF, eof, UNDEF)
+            sb += struct.pack("<QQII", 0, r_header, 1, 0) + struct.pack("<QQ", r_btree, r_heap)  # root group symbol table entry
+            assert len(sb) == 96 and lay.size == eof
+            lay.put(0, sb)
+        os.replace(tmp, path)
+    except BaseException:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+        raise

@@ -156,7 +156,8 @@ enum dmcf_window {
     /* a_p = w(q), q = neighbors_value[p] / radius^2, neighbors_value = squared distances
      * (utils/convolutions.py:359-362, 375-379; formulas utils/tools/losses.py:8-44).
      * neighbors_value == NULL: the squared distance is re-formed from the two positions, with the operations and the order
-     * dmcf_frs_search uses for the distances it returns -- bit-identical results, and the list needs no distance array. */
+     * dmcf_frs_write / dmcf_frs_search_padded use for the distances they return -- bit-identical results, and the list needs
+     * no distance array. */
     DMCF_WINDOW_POLY6 = 2,
     DMCF_WINDOW_CUBIC = 3,
     DMCF_WINDOW_LINEAR = 4,
@@ -213,7 +214,10 @@ typedef struct dmcf_cconv_args {
                                   models/hrnet.py:86 with inp_scale = out_scale = 0), 2 = rows of hundreds or more (any wider
                                   radius).  With 2, layers of 17 .. 32 input channels and 4 x 4 x 4 filters take the
                                   pair-per-instruction kernel ("cconv_pair_kernel..."), which needs long rows to pay for
-                                  its per-point merge. */
+                                  its per-point merge; with 1, layers of 24 .. 32 input channels and at most 32 output
+                                  channels take the wave-specialised kernel ("cconv_ws_kernel...": that splat in producer
+                                  waves, the contraction in consumer waves of a persistent workgroup), which pays when a
+                                  row's contraction is as much work as its splat. */
 } dmcf_cconv_args;
 
 size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* args);

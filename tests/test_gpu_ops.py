@@ -875,7 +875,8 @@ def test_farthest_point_sample_matches_oracle(oracle, dev, kind, n, m):
 
 def test_row_length_hint_picks_the_kernel_for_wide_layers(oracle, dev):
     """include/dmcf_hip.h, row_length_hint: layers of 17 .. 32 input channels take the pair-per-instruction kernel when the caller
-    says their rows are long, the plane-sorted one otherwise; both agree with the oracle (and narrower layers ignore the hint)."""
+    says their rows are long, the wave-specialised one (24 .. 32 channels) when it says they are short, the plane-sorted one
+    otherwise; all agree with the oracle (and narrower layers ignore the hint)."""
     from dmcf_amd import ops
     radius = 0.3
     inp, out, feat, filt = _conv_inputs(oracle, 23, 3000, 700, 24, 8, (4, 4, 4), radius)
@@ -885,8 +886,8 @@ def test_row_length_hint_picks_the_kernel_for_wide_layers(oracle, dev):
     call = lambda **kw: ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
                                           nns.neighbors_row_splits, window="poly6", **kw)
     names = {h: call(row_length_hint=h, name_only=True) for h in (0, 1, 2)}
-    assert names[0].startswith("cconv_z3_kernel") and names[1].startswith("cconv_z3_kernel") and names[2].startswith("cconv_pair_kernel")
-    for h in (0, 2):
+    assert names[0].startswith("cconv_z3_kernel") and names[1].startswith("cconv_ws_kernel") and names[2].startswith("cconv_pair_kernel")
+    for h in (0, 1, 2):
         _close(call(row_length_hint=h).cpu().numpy(), ref)
     f16 = _t(filt[..., :16, :], dev)
     assert ops.cconv_forward(f16, _t(out, dev), 2 * radius, _t(inp, dev), _t(feat[:, :16].copy(), dev), nns.neighbors_index,

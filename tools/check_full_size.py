@@ -17,7 +17,7 @@ dev = torch.device("cuda:0")
 cfg = configs.LIQUID3D
 w = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
 model = getattr(models, cfg["name"])(**cfg); tc.load_into_model(model, w, device=dev)
-sim = Simulator(model, device="cuda:0")
+sim = Simulator(model, device="cuda:0", reserve_gib="auto")
 state = scenes.model_inputs(scenes.box_scene(side), device=dev)
 for _ in range(before):
     state = sim.step([state])[0]

@@ -19,7 +19,7 @@ w = dict(np.load(os.path.join(ROOT, "tests/golden/liquid3d_weights.npz")))
 cfg = configs.LIQUID3D
 model = getattr(models, cfg["name"])(**cfg)
 tc.load_into_model(model, w, device=dev)
-sim = Simulator(model, device="cuda")
+sim = Simulator(model, device="cuda", reserve_gib="auto")
 state = scenes.model_inputs(scenes.box_scene(side), device=dev)
 for _ in range(steps):
     state = sim.step([state])[0]

@@ -23,7 +23,7 @@ def main():
     cfg, w, scene, grav = long_rollout.setup(name)
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, w, device=dev)
-    sim = Simulator(model, device="cuda")
+    sim = Simulator(model, device="cuda", reserve_gib="auto")
     state = scenes.model_inputs(scene, device=dev, grav=grav)
     med = []
     for t in range(steps):

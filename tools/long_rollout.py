@@ -53,7 +53,7 @@ def main():
     cfg, w, scene, grav = setup(args.name)
     model = getattr(models, cfg["name"])(**cfg)
     tc.load_into_model(model, w, device=dev)
-    sim = Simulator(model, device="cuda")
+    sim = Simulator(model, device="cuda", reserve_gib="auto")
     ref = ModelRef(cfg, w)
     state = scenes.model_inputs(scene, device=dev, grav=grav)
     n = state[0].shape[0]

@@ -12,7 +12,7 @@ dev = torch.device("cuda:0")
 cfg = configs.LIQUID3D
 model = getattr(models, cfg["name"])(**cfg)
 tc.load_into_model(model, dict(np.load(os.path.join(ROOT, "tests/golden/liquid3d_weights.npz"))), device=dev)
-sim = Simulator(model, device="cuda:0")
+sim = Simulator(model, device="cuda:0", reserve_gib="auto")
 state = scenes.model_inputs(scenes.box_scene(side), device=dev)
 for s in range(7):
     torch.cuda.synchronize(); t0 = time.perf_counter()
