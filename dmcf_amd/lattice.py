@@ -30,6 +30,20 @@ MAX_X_OVER_EXTENT = float(os.environ.get("DMCF_LATTICE_MAX_RATIO", "32"))
 MAX_VOLUME_FLOATS = 1 << 28
 # ... and sparser than one point per MAX_CELLS_PER_POINT cells the zero-filled volume costs more than the list it replaces
 MAX_CELLS_PER_POINT = 32
+# Stray particles blow a lattice's bounding box up: the dense volume over it grows with the box and every stray lattice point sits
+# alone in a 16-cell tile that walks the whole stencil.  Below CORE_MIN_FILL (points per cell of the box) a lattice is split: the
+# CORE -- per axis the run of slabs around the fullest one that hold at least CORE_SLAB_FRACTION of its points -- keeps the stencil
+# form on a volume that covers the core only, the points outside it (LatticeInfo.core) go through the neighbour-list form, whose
+# work follows the neighbours they actually have.  The default threshold is where the form used to give up altogether (one point
+# per MAX_CELLS_PER_POINT cells: the dissolved dam break of config 4, 575k lattice points around 148k particles): there the split
+# replaces four neighbour-list layers over ALL points.  Between that and a compact scene the split was measured and LOSES
+# (round 5, the bench's 1M box while ~15 % of its fluid leaks through the shell, fill 0.3 - 0.6: the four lattice layers go
+# 2.6 -> 9.9 ms per step unsplit; split, the lattice launches stay at 2.6 -> 4.4 ms but the stray sets' searches -- a new size
+# class every other step, each an exact two-pass search with a host round trip -- and their launches cost more than that:
+# 69 - 78 ms per step against 60): DMCF_LATTICE_CORE_FILL=0.6 reproduces it.
+CORE_MIN_FILL = float(os.environ.get("DMCF_LATTICE_CORE_FILL", str(1.0 / 32)))
+CORE_SLAB_FRACTION = 0.125
+_FAR = 3.0e4  # a coordinate no scene point has (the padding rows of an estimated stray set)
 
 
 def _registry():
@@ -44,6 +58,48 @@ def clear():
     """Forget this thread's lattices (the per-step neighbour cache calls it when a step ends: the positions of the next
     step are new tensors)."""
     _registry().clear()
+
+
+def _cores():
+    """(rollout, voxel) -> dict(box = (lo, hi) cells, cap = stray rows) the PREVIOUS step's histogram chose (LatticeInfo.core)."""
+    r = getattr(_TLS, "cores", None)
+    if r is None:
+        r = _TLS.cores = {}
+    return r
+
+
+def _pick_core(minp, dims, hists):
+    """Per axis the run of slabs around the fullest one that hold at least CORE_SLAB_FRACTION of its points (gaps of up to two
+    thinner slabs are bridged; a far slab that happens to be well filled -- a second body of fluid -- does NOT stretch the box
+    over the empty space between: it is served as strays)."""
+    lo, hi = [], []
+    for k in range(3):
+        h = hists[k]
+        m = max(h) if h else 0
+        if m <= 0:
+            lo.append(minp[k]); hi.append(minp[k] + dims[k])
+            continue
+        thr = CORE_SLAB_FRACTION * m
+        peak = h.index(m)
+        a = b = peak
+        gap = 0
+        i = peak - 1
+        while i >= 0 and gap <= 2:
+            if h[i] >= thr:
+                a, gap = i, 0
+            else:
+                gap += 1
+            i -= 1
+        gap = 0
+        i = peak + 1
+        while i < len(h) and gap <= 2:
+            if h[i] >= thr:
+                b, gap = i, 0
+            else:
+                gap += 1
+            i += 1
+        lo.append(minp[k] + a); hi.append(minp[k] + b + 1)
+    return lo, hi
 
 
 class LatticeInfo:
@@ -66,6 +122,8 @@ class LatticeInfo:
         self._lin = None
         self._vlin = {}
         self._table = None
+        self._core = None
+        self._tables = {}
 
     def cells(self):
         """int32 [n, 3] (x, y, z): the integer lattice coordinates (exact: |gpos - center| / voxel is within 1e-4 of them)."""
@@ -91,6 +149,115 @@ class LatticeInfo:
         if own:
             self._lin = lin
         return lin
+
+    def core(self):
+        """(min, dims, stray rows int64 [m] | None, stray positions [m, 3] | None, valid float32 [m, 1] | None): the box of cells
+        the stencil form serves and the points outside it (None: the whole lattice is the core -- the usual case: a compact
+        scene).  Inside a rollout step (estimated sizes, utils/convolutions.neighbor_cache(estimate=True)) the box and the
+        capacity m of the stray set are what the PREVIOUS step reported -- any box gives exact results, what lies outside is
+        convolved through a neighbour list -- so nothing here waits for the device; rows past the actual count repeat row 0
+        with ``valid`` = 0, and a capacity outgrown repeats the step.  Otherwise two host round trips choose both exactly."""
+        if self._core is not None:
+            return self._core
+        n = self.gpos.shape[0]
+        dx, dy, dz = self.dims
+        whole = (list(self.minp), list(self.dims), None, None, None)
+        if n / float(dx * dy * dz) >= CORE_MIN_FILL or os.environ.get("DMCF_LATTICE_CORE", "1") == "0":
+            self._core = whole
+            return whole
+        from .utils.convolutions import _CACHE
+        dev = self.gpos.device
+        c = self.cells()
+        minp, dims = list(self.minp), list(self.dims)
+        lo_box = torch.tensor(minp, dtype=torch.int32, device=dev)
+        rel = (c - lo_box).long()
+        hist = torch.cat([torch.bincount(rel[:, k], minlength=dims[k])[: dims[k]] for k in range(3)])
+        key = (_CACHE.key, self.voxel)
+
+        def split(h):
+            return [h[: dx], h[dx: dx + dy], h[dx + dy:]]
+
+        def next_entry(h):
+            """the next step's box and capacity from this step's histogram: strays <= sum over the axes of the points outside the
+            box's range on that axis (doubled, + 64k: a spray grows by tens of per cent per step; the padding rows sit far from
+            every point and cost a search and a convolution with empty rows)"""
+            hs = split(h)
+            lo, hi = _pick_core(minp, dims, hs)
+            bound = sum(n - sum(hs[k][lo[k] - minp[k]: hi[k] - minp[k]]) for k in range(3))
+            return dict(box=(lo, hi), cap=int(2 * bound + 65536))
+
+        est = _cores().get(key) if (_CACHE.depth > 0 and _CACHE.use_hints) else None
+        if est is None:
+            est = next_entry(hist.tolist())  # (exact: this step's own histogram; one round trip)
+            exact = True
+        else:
+            exact = False
+        lo = [max(est["box"][0][k], minp[k]) for k in range(3)]
+        hi = [min(est["box"][1][k], minp[k] + dims[k]) for k in range(3)]
+        if any(hi[k] <= lo[k] for k in range(3)):
+            lo, hi = minp, [minp[k] + dims[k] for k in range(3)]
+        lo_t = torch.tensor(lo, dtype=torch.int32, device=dev)
+        hi_t = torch.tensor(hi, dtype=torch.int32, device=dev)
+        outside = ~((c >= lo_t) & (c < hi_t)).all(dim=1)
+        count = outside.sum().reshape(1)
+        if exact:
+            m = int(count.item())
+            _cores()[key] = est  # (serves the next step of this rollout as its estimate)
+            valid = None
+        else:
+            m = min(est["cap"], n)
+            cap = m
+
+            def report(vals):
+                _cores()[key] = next_entry(vals[1:])
+                return vals[0] > cap
+            _CACHE.report(torch.cat([count, hist]), report)
+        if m == 0:
+            idx = pos = valid = None
+        else:
+            idx = torch.nonzero_static(outside, size=m, fill_value=-1).flatten()
+            if not exact:
+                valid = (idx >= 0).to(torch.float32).unsqueeze(1)
+                idx = idx.clamp(min=0)
+            pos = self.gpos.index_select(0, idx).contiguous()
+            if valid is not None:  # the padding rows: far from every point (empty rows)
+                pos = torch.where(valid > 0, pos, torch.full_like(pos, _FAR))
+        self._core = (lo, [hi[k] - lo[k] for k in range(3)], idx, pos, valid)
+        return self._core
+
+    def table_in(self, minp, dims):
+        """int32 [dz, dy, dx] over the given box of cells: the index of the point in each cell, -1 where there is none; points
+        outside the box are left out."""
+        key = (tuple(minp), tuple(dims))
+        t = self._tables.get(key)
+        if t is None:
+            dx, dy, dz = dims
+            c = self.cells().long()
+            lo = torch.tensor(list(minp), device=c.device)
+            hi = lo + torch.tensor(list(dims), device=c.device)
+            ok = ((c >= lo) & (c < hi)).all(dim=1)
+            lin = ((c[:, 2] - minp[2]) * dy + (c[:, 1] - minp[1])) * dx + (c[:, 0] - minp[0])
+            lin = torch.where(ok, lin, torch.full_like(lin, dz * dy * dx))  # (a spare slot past the end takes the others)
+            t = torch.full((dz * dy * dx + 1,), -1, dtype=torch.int32, device=c.device)
+            t[lin] = torch.where(ok, torch.arange(c.shape[0], dtype=torch.int32, device=c.device), torch.full((1,), -1, dtype=torch.int32, device=c.device))
+            t = self._tables[key] = t[:-1].view(dz, dy, dx)
+        return t
+
+    def volume_in(self, features, minp, dims):
+        """As :meth:`volume` over a box that need NOT hold every point: the points outside it are left out."""
+        key = ("in", tuple(minp), tuple(dims))
+        lin = self._vlin.get(key)
+        dx, dy, dz = dims
+        if lin is None:
+            c = self.cells().long()
+            lo = torch.tensor(list(minp), device=c.device)
+            hi = lo + torch.tensor(list(dims), device=c.device)
+            ok = ((c >= lo) & (c < hi)).all(dim=1)
+            lin = ((c[:, 2] - minp[2]) * dy + (c[:, 1] - minp[1])) * dx + (c[:, 0] - minp[0])
+            lin = self._vlin[key] = torch.where(ok, lin, torch.full_like(lin, dz * dy * dx))
+        v = features.new_zeros((dz * dy * dx + 1, features.shape[1]))
+        v[lin] = features
+        return v[:-1].view(dz, dy, dx, features.shape[1])
 
     def table(self):
         """int32 [dz, dy, dx]: index of the point in each cell of the box, -1 where there is none."""
@@ -174,14 +341,22 @@ class LatticePair:
             return hit[1]
         a, b = self.inp, self.out
         radius = 0.5 * float(extent)
+        omin, odim = b.core()[:2]  # the output cells this form serves (the whole lattice unless strays blew its box up)
+        cropped = self.cropped = (omin, odim) != (list(b.minp), list(b.dims)) or a.core()[2] is not None
         if self.ratio >= 1:
             step = int(self.ratio)
-            vmin, vdim = ops.lattice_volume_box(b.minp, b.dims, step, ops.lattice_reach(a.voxel, radius, dev), a.minp, a.dims)
+            if cropped:  # the volume covers what the core's stencils reach, whatever lies outside is left out of it
+                vmin, vdim = ops.lattice_volume_box(omin, odim, step, ops.lattice_reach(a.voxel, radius, dev))
+            else:
+                vmin, vdim = ops.lattice_volume_box(b.minp, b.dims, step, ops.lattice_reach(a.voxel, radius, dev), a.minp, a.dims)
             res = (vmin, vdim, None)
         else:
-            lo = [b.minp[k] for k in range(3)]
-            hi = [b.minp[k] + b.dims[k] - 1 for k in range(3)]
-            launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
+            lo = [omin[k] for k in range(3)]
+            hi = [omin[k] + odim[k] - 1 for k in range(3)]
+            if cropped:
+                launches, vlo, vhi = [], [1 << 30] * 3, [-(1 << 30)] * 3
+            else:
+                launches, vlo, vhi = [], list(a.minp), [a.minp[k] + a.dims[k] - 1 for k in range(3)]
             for pz in (0, 1):
                 for py in (0, 1):
                     for px in (0, 1):
@@ -211,14 +386,25 @@ class LatticePair:
         """The launch of dmcf_lattice_conv_forward for this pair (outputs on the finer lattice: one
         dmcf_lattice_conv_forward_batch grid of the eight parity classes)."""
         a, b = self.inp, self.out
-        fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
         vmin, vdim, parts = self.plan(ops, extent, inp_features.device)
-        vol = a.volume(inp_features, vmin, vdim)
+        if self.cropped:
+            omin, odim = b.core()[:2]
+            vol, table, tmin = a.volume_in(inp_features, vmin, vdim), b.table_in(omin, odim), omin
+            fill = min(1.0, a.gpos.shape[0] / float(max(vdim[0] * vdim[1] * vdim[2], 1)))
+        else:
+            vol, table, tmin = a.volume(inp_features, vmin, vdim), b.table(), b.minp
+            fill = a.gpos.shape[0] / float(a.dims[0] * a.dims[1] * a.dims[2])
         if parts is None:
-            return ops.lattice_conv(kernel, vol, vmin, b.table(), b.minp, n_out, a.voxel, extent, inp_step=int(self.ratio),
+            return ops.lattice_conv(kernel, vol, vmin, table, tmin, n_out, a.voxel, extent, inp_step=int(self.ratio),
                                     fill=fill, **kw)
-        return ops.lattice_conv(kernel, vol, vmin, b.table(), b.minp, n_out, a.voxel, extent, inp_step=1, out_stride=2,
+        return ops.lattice_conv(kernel, vol, vmin, table, tmin, n_out, a.voxel, extent, inp_step=1, out_stride=2,
                                 parts=parts, fill=fill, **kw)
+
+    def strays(self):
+        """(row indices, positions, validity | None) of the output points outside the core (they take the neighbour-list form), or
+        None."""
+        _, _, idx, pos, valid = self.out.core()
+        return None if idx is None else (idx, pos, valid)
 
 
 def pair(inp_positions, out_positions, extent=None):

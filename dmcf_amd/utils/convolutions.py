@@ -54,6 +54,7 @@ class _NeighborCache:
         self.use_hints = False
         self.nth = {}  # searches of each class so far in this step (the second half of a list's key in expect / uses / caps)
         self.pending = []
+        self.reports = []  # (int64 device tensor, callback(list) -> outgrown?) read with the step's one synchronisation (report())
         self.lists = {}
         self.tables = {}
         self.keepalive = []
@@ -74,8 +75,18 @@ class _NeighborCache:
         if self.depth == 0:
             self.nth = {}
             self.pending = []
+            self.reports = []
         self.depth += 1
         return self
+
+    def report(self, values, callback):
+        """Device numbers somebody wants on the host when the step ends (int64 tensor; read in the step's single synchronisation,
+        no round trip of their own): ``callback(list of ints)`` returns True if they show an estimated capacity outgrown -- the
+        step is then repeated like one with an outgrown neighbour list.  Outside a step: read at once."""
+        if self.depth == 0:
+            return bool(callback(values.flatten().tolist()))
+        self.reports.append((values.flatten().long(), callback))
+        return False
 
     def __exit__(self, exc_type, exc, tb):
         self.depth -= 1
@@ -93,6 +104,16 @@ class _NeighborCache:
             self.lists.clear()
             self.tables.clear()
             self.keepalive.clear()
+            reports, self.reports = self.reports, []
+            outgrown = False
+            if exc_type is None and reports:
+                flat = torch.cat([v for v, _ in reports]).tolist()
+                at = 0
+                for v, cb in reports:
+                    outgrown = bool(cb(flat[at: at + v.shape[0]])) or outgrown
+                    at += v.shape[0]
+            if exc_type is None and outgrown and not pending:
+                raise ops.NeighborCapacityExceeded("an estimated capacity was outgrown; repeat the step")
             if exc_type is None and pending:
                 # one synchronisation per step: validate the estimated capacities, refresh the estimates (the longest row and
                 # the number of pairs of every list)
@@ -122,7 +143,7 @@ class _NeighborCache:
                 self.totals.update(tot)
                 if over or self.use_hints:  # (the repeat of a step runs without estimates: it keeps the record of what was outgrown)
                     self.last_overflow = over
-                if over:
+                if over or outgrown:
                     raise ops.NeighborCapacityExceeded("a neighbour list outgrew its estimated capacity; repeat the step")
         return False
 
@@ -489,6 +510,25 @@ class ContinuousConv(torch.nn.Module):
                     align_corners=self.align_corners, coordinate_mapping=self.coordinate_mapping,
                     interpolation=self.interpolation, bias=self._epilogue_bias(fuse_bias, extra_bias),
                     out=acc, accumulate=acc is not None)
+                stray = lat.strays()
+                if stray is not None:
+                    # output points outside the lattice's core (stray particles' cells, dmcf_amd/lattice.py): the same layer
+                    # through a neighbour list over ALL input points, added to their rows of the result (rows the stencil form
+                    # does not write: zero, or the value to accumulate to).  The row set has an estimated capacity inside a
+                    # rollout: ``valid`` zeroes the padding rows
+                    idx_s, pos_s, valid = stray
+                    radius = float(np.float32(0.5) * np.float32(extent))
+                    nns = _CACHE.search(self.fixed_radius_search, inp_positions, pos_s, radius, distances=False)
+                    ni, nrs, raw_dist = nns.raw()
+                    res = ops.cconv_forward(
+                        self.kernel, pos_s, extent, inp_positions, inp_features, ni, nrs, neighbors_value=raw_dist,
+                        window=self.window_function.name, window_fac=self.window_function.fac, align_corners=self.align_corners,
+                        coordinate_mapping=self.coordinate_mapping, interpolation=self.interpolation,
+                        bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=nns.total_ref,
+                        neighbors_row_count=getattr(nns, "row_count", None), row_length_hint=1)
+                    if valid is not None:
+                        res = res * valid
+                    out_features.index_add_(0, idx_s, res)
                 self._conv_values, self._conv_output = None, (None if _CACHE.depth > 0 else out_features)
                 return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             radius = float(np.float32(0.5) * np.float32(extent))  # :353

@@ -947,6 +947,7 @@ def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
     lattice) against the oracle and against the neighbour-list kernels on the same points, through the bookkeeping of
     dmcf_amd/lattice.py the layer uses."""
     from dmcf_amd import lattice, ops
+    lattice._cores().clear()
     rng = np.random.default_rng(21)
     h = 0.05
     center = rng.uniform(-0.5, 0.5, size=3)
@@ -992,6 +993,91 @@ def test_lattice_conv_matches_neighbour_list_form(oracle, dev, case):
                           nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6",
                           bias=_t(bias, dev)).cpu().numpy()
     _close(y, z.astype(np.float64))
+
+
+@pytest.mark.parametrize("case", ["same", "fine_to_coarse", "coarse_to_fine"])
+def test_lattice_core_and_strays_equal_the_neighbour_list_layer(dev, monkeypatch, case):
+    """A lattice whose bounding box stray points blow up (dmcf_amd/lattice.py, CORE_MIN_FILL): the stencil form serves the
+    core on a volume that covers the core only, the stray output points take the neighbour-list form, and together they equal
+    the neighbour-list layer on every row -- through ContinuousConv, with a bias, also accumulating into a given tensor; the
+    volume no longer grows with the strays' distance."""
+    from dmcf_amd import lattice, ops
+    from dmcf_amd.utils.convolutions import ContinuousConv, neighbor_cache
+    from dmcf_amd.utils.tools.losses import get_window_func
+    monkeypatch.setattr(lattice, "CORE_MIN_FILL", 0.6)  # (the default, 1 / 32, needs a far larger box than this test's)
+    rng = np.random.default_rng(31)
+    h = 0.05
+    center = rng.uniform(-0.2, 0.2, size=3).astype(np.float32)
+
+    def cloud(dims, occupancy, step, far):
+        cells, _ = _lattice(rng, dims, occupancy, h, center, step=step)
+        # droplets far from the block (some next to it: their stencils reach into the core), 2 x 2 x 2 cells each
+        seeds = np.concatenate([rng.integers(-far, far, size=(40, 3)), np.array(dims)[None] + rng.integers(0, 3, size=(6, 3))]).astype(np.int32)
+        drops = (seeds[:, None, :] + np.stack(np.meshgrid([0, 1], [0, 1], [0, 1], indexing="ij"), -1).reshape(1, 8, 3)).reshape(-1, 3)
+        cells = np.unique(np.concatenate([cells, drops.astype(np.int32)]), axis=0)
+        cells = cells[rng.permutation(cells.shape[0])]
+        pos = cells.astype(np.float32) * (np.float32(h) * np.float32(step)) + center
+        return cells, pos.astype(np.float32)
+
+    if case == "same":
+        cin, cout, radius, istep, ostep = 8, 16, 0.2, 1, 1
+        icell, ipos = cloud((14, 12, 13), 0.9, 1, 60)
+        ocell, opos = icell, ipos
+    elif case == "fine_to_coarse":
+        cin, cout, radius, istep, ostep = 8, 8, 0.4, 1, 2
+        icell, ipos = cloud((20, 18, 16), 0.9, 1, 60)
+        ocell, opos = cloud((10, 9, 8), 0.9, 2, 30)
+    else:
+        cin, cout, radius, istep, ostep = 4, 16, 0.4, 2, 1
+        icell, ipos = cloud((10, 9, 8), 0.9, 2, 30)
+        ocell, opos = cloud((20, 18, 16), 0.9, 1, 60)
+    cen = _t(center, dev)
+    P, Q = _t(ipos, dev), (None if case == "same" else _t(opos, dev))
+    Q = P if Q is None else Q
+
+    feat = _t(rng.normal(size=(ipos.shape[0], cin)).astype(np.float32), dev)
+    conv = ContinuousConv(cout, kernel_size=[4, 4, 4], activation=None, use_bias=True, window_function=get_window_func("poly6"),
+                          coordinate_mapping="ball_to_cube_volume_preserving", normalize=False, use_dense_layer_for_center=False).to(dev)
+    conv.build(cin, dev)
+    with torch.no_grad():
+        conv.bias.copy_(_t(rng.normal(size=cout).astype(np.float32), dev))
+    base = _t(rng.normal(size=(opos.shape[0], cout)).astype(np.float32), dev)
+    results = {}
+    # "1": exact (two host round trips choose the core and count the strays); "est" twice: inside a rollout the second step takes
+    # box and capacity from what the first reported (no round trip; padded stray rows); "0": the neighbour-list layer
+    for form in ("1", "est", "est", "0"):
+        monkeypatch.setenv("DMCF_LATTICE_CONV", "0" if form == "0" else "1")
+        register_keep = form == "est" and "est" in results
+        lattice.clear()
+        if not register_keep:
+            lattice._cores().clear()
+        for t, cells, step in ((P, icell, istep), (Q, ocell, ostep)):
+            lo = cells.min(axis=0) - 1
+            lattice.register(t, cen, [h * step] * 3, "test", lo, cells.max(axis=0) - lo + 2, center_host=center)
+        ops.timer = ops.LaunchTimer()
+        with neighbor_cache(estimate=form == "est", key="core-test"):
+            y = conv(feat, P, Q, 2 * radius)
+            acc = base.clone()
+            conv.accumulate_into = acc
+            z = conv(feat, P, Q, 2 * radius)
+            core = lattice.lookup(Q).core() if form != "0" else None
+        recs, ops.timer = ops.timer.results(), None
+        lat = [m for k, m, _ in recs if k == "cconv" and m.get("lattice")]
+        if form != "0":
+            assert len(lat) == 2 and core[2] is not None  # the form ran, and there were strays
+            assert lat[0]["volume_bytes"] < 4 * cin * 4 * (icell.shape[0] + 40 ** 3)  # a core-sized volume, not the box of the strays
+            if register_keep:
+                assert core[4] is not None and float(core[4].sum()) < core[4].shape[0]  # estimated capacity: padded rows
+        else:
+            assert not lat
+        if form in results:
+            assert np.array_equal(results[form][0], y.cpu().numpy())  # (the estimated step gives the exact step's bits)
+        results[form] = (y.cpu().numpy(), z.cpu().numpy())
+    assert np.abs(results["est"][0] - results["1"][0]).max() <= 1e-6 * np.abs(results["1"][0]).max()
+    scale = np.abs(results["0"][0]).max()
+    assert np.abs(results["1"][0] - results["0"][0]).max() <= 1e-5 * scale
+    assert np.abs(results["1"][1] - results["0"][1]).max() <= 1e-5 * max(scale, np.abs(results["0"][1]).max())
+    assert z is acc or torch.equal(z, acc)
 
 
 def test_reserve_device_memory(dev):

@@ -62,3 +62,14 @@ def test_pair_rules(monkeypatch):
     # collapsed axes (2-D scenes) are not registered
     lattice.register(coarse, center, [0.1, 0.1, 0.0], "A", [0, 0, 0], [4, 4, 1])
     assert lattice.lookup(coarse) is None
+
+
+def test_core_box_follows_the_dense_slabs():
+    """lattice._pick_core: per axis the run of slabs around the fullest one that hold at least CORE_SLAB_FRACTION of its points;
+    stray cells far out do not widen it -- not even a well filled slab beyond a gap --, an empty histogram keeps the whole box."""
+    from dmcf_amd import lattice
+    hx = [0, 1, 0, 0, 90, 100, 95, 80, 3, 0, 0, 1]
+    hy = [2, 50, 60, 2, 55, 1, 0, 0, 0, 40]
+    hz = [0, 0, 0]
+    lo, hi = lattice._pick_core([-4, 10, 0], [12, 10, 3], [hx, hy, hz])
+    assert lo == [0, 11, 0] and hi == [4, 15, 3]
