@@ -572,7 +572,8 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
         float* packed = (float*)workspace;
         const int64_t total = (int64_t)cfg.packed_floats;
         const unsigned g = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
+        if (!(a->flags & DMCF_FLAG_FILTER_PACKED))  // (else the workspace still holds it: dmcf_hip.h)
+            hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
                            p.cin, p.cout, cfg.CC, cfg.PS, cfg.nchunks, cfg.nblocks, cfg.NT,
                            (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
         p.Wp = packed;

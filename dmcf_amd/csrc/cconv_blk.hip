@@ -436,7 +436,8 @@ int cconv_blk_launch(CconvParams p, const dmcf_cconv_args* a, void* workspace, h
     {
         const int64_t total = (int64_t)cconv_blk_packed_floats(p.cin, p.cout);
         const unsigned g = (unsigned)((total + 255) / 256);
-        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, 4, 4, 4, p.cin,
+        if (!(a->flags & DMCF_FLAG_FILTER_PACKED))  // (else the workspace still holds it: dmcf_hip.h)
+            hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, 4, 4, 4, p.cin,
                            p.cout, BCH, 16 * BCH, nchunks, nblocks, NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0,
                            a->sym_axis);
     }

@@ -645,7 +645,8 @@ int cconv_cls_pack(const dmcf_cconv_args* a, float* packed, hipStream_t stream) 
     const int nchunks = (cin + CCH - 1) / CCH, NT = (cout + 15) / 16;
     const int64_t total = (int64_t)cconv_cls_packed_floats(cin, cout);
     const unsigned g = (unsigned)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_filter_cls, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, cin, cout, nchunks,
+    if (!(a->flags & DMCF_FLAG_FILTER_PACKED))  // (else the workspace still holds it: dmcf_hip.h)
+        hipLaunchKernelGGL(pack_filter_cls, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, cin, cout, nchunks,
                        NT, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
     return nchunks;
 }

@@ -315,7 +315,8 @@ int cconv_direct_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy,
     f32x4* image = (f32x4*)workspace;
     {
         const unsigned g = (unsigned)((dp.image_f4 + 255) / 256);
-        hipLaunchKernelGGL(pack_direct, dim3(g < 1024u ? g : 1024u), dim3(256), 0, stream, a->filters, image, dz, dy, dx, p.cin,
+        if (!(a->flags & DMCF_FLAG_FILTER_PACKED))  // (else the workspace still holds it: dmcf_hip.h)
+            hipLaunchKernelGGL(pack_direct, dim3(g < 1024u ? g : 1024u), dim3(256), 0, stream, a->filters, image, dz, dy, dx, p.cin,
                            p.cout, dp.sxp, (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
     }
     p.Wp = (const float*)image;

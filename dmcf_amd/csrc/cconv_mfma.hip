@@ -353,7 +353,8 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
         const int64_t total = (int64_t)cfg.packed_floats;
         const unsigned g = (unsigned)((total + 255) / 256);
         // same packer as the LDS path with 16 channels per chunk and an unpadded plane stride
-        hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
+        if (!(a->flags & DMCF_FLAG_FILTER_PACKED))  // (else the workspace still holds it: dmcf_hip.h)
+            hipLaunchKernelGGL(pack_filter, dim3(g < 2048u ? g : 2048u), dim3(256), 0, stream, a->filters, packed, dz, dy, dx,
                            p.cin, p.cout, MCH, dy * dx * MCH, cfg.nchunks, cfg.nblocks, cfg.NT,
                            (a->flags & DMCF_FLAG_SYMMETRIC) ? 1 : 0, a->sym_axis);
     }

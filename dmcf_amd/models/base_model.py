@@ -1,11 +1,13 @@
 """BaseModel -- mirror of the reference's ``models/base_model.py:10-107``: the five-stage ``call``."""
 import torch
 
+from ..utils.convolutions import PlainAttributes
+
 from .. import ops
 from ..utils.config import Config
 
 
-class Dense(torch.nn.Module):
+class Dense(PlainAttributes, torch.nn.Module):
     """tf.keras.layers.Dense(units, activation=None): lazily built ``kernel`` [in, units] (glorot
     uniform) and ``bias`` [units] (zeros); dmcf_dense_forward for the shapes it takes (a row per thread), else torch's GEMM."""
 
@@ -48,7 +50,7 @@ class Dense(torch.nn.Module):
         return x @ self.kernel
 
 
-class BaseModel(torch.nn.Module):
+class BaseModel(PlainAttributes, torch.nn.Module):
     """models/base_model.py:10-29.  ``model(data, training=False)`` runs
     transform -> preprocess -> forward -> postprocess -> inv_transform."""
 

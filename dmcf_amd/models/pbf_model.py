@@ -161,7 +161,7 @@ class PBFNet(BaseModel):
         """Semi-implicit Euler (pbf_model.py:234-240)."""
         dt = self.timestep
         if acc1 is None:
-            acc1 = torch.tensor([0.0, self.grav, 0.0], dtype=torch.float32, device=pos1.device)
+            acc1 = ops.const_tensor([0.0, self.grav, 0.0], torch.float32, pos1.device)
         vel2 = vel1 + dt * acc1
         pos2 = pos1 + dt * vel2
         return pos2, vel2
@@ -177,18 +177,18 @@ class PBFNet(BaseModel):
         pos, vel, acc, feats, box, bfeats = data
         dev = pos.device
         if "translate" in self.transformation:  # pbf_model.py:255-259
-            translate = torch.tensor(self.transformation["translate"], dtype=torch.float32, device=dev)
+            translate = ops.const_tensor(self.transformation["translate"], torch.float32, dev)
             pos = pos + translate
             box = box + translate
         if "scale" in self.transformation:  # :261-267
-            scale = torch.tensor(self.transformation["scale"], dtype=torch.float32, device=dev)
+            scale = ops.const_tensor(self.transformation["scale"], torch.float32, dev)
             pos = pos * scale
             box = box * scale
             vel = vel * scale
             if acc is not None:
                 acc = acc * scale
         if "grav_eqvar" in self.transformation:  # :269-278
-            grav_eqvar = torch.tensor(self.transformation["grav_eqvar"], dtype=torch.float32, device=dev)
+            grav_eqvar = ops.const_tensor(self.transformation["grav_eqvar"], torch.float32, dev)
             self.R = align_vector(grav_eqvar, acc[0])
             pos, vel, acc, box, bfeats = (x @ self.R for x in (pos, vel, acc, box, bfeats))
         return [pos, vel, acc, feats, box, bfeats]
@@ -201,11 +201,11 @@ class PBFNet(BaseModel):
             pos = pos @ R
             vel = vel @ R
         if "scale" in self.transformation:  # :291-294
-            scale = torch.tensor(self.transformation["scale"], dtype=torch.float32, device=dev).clamp(min=1e-5)
+            scale = ops.const_tensor([max(float(v), 1e-5) for v in self.transformation["scale"]], torch.float32, dev)
             pos = pos / scale
             vel = vel / scale
         if "translate" in self.transformation:  # :296-299
-            pos = pos - torch.tensor(self.transformation["translate"], dtype=torch.float32, device=dev)
+            pos = pos - ops.const_tensor(self.transformation["translate"], torch.float32, dev)
         return pos, vel
 
     def preprocess(self, data, training=True, vel_corr=None, tape=None, **kwargs):
@@ -228,8 +228,9 @@ class PBFNet(BaseModel):
         lo = mn - filter_extent[-1]
         hi = mx + filter_extent[-1]
         fltr = ((box >= lo) & (box <= hi)).all(dim=1)
-        box = box[fltr]
-        bfeats = bfeats[fltr]
+        keep = fltr.nonzero().flatten()  # (ONE host round trip for the count, not one per masked tensor)
+        box = box.index_select(0, keep)
+        bfeats = bfeats.index_select(0, keep)
 
         fluid_feats = [torch.ones_like(pos[:, :1])]  # :338-347
         if self.use_vel:
@@ -418,7 +419,7 @@ class PBFNet(BaseModel):
             out = out.repeat(1, 3)
         elif out.shape[-1] == 2:
             out = torch.cat([out, out[:, :1]], dim=-1)
-        out_scale = torch.tensor(self.out_scale, dtype=torch.float32, device=pos.device)
+        out_scale = ops.const_tensor(self.out_scale, torch.float32, pos.device)
         self.net_output = out
         self.pos_correction = out_scale * out[:pcnt]  # :474
         self.obs = out_scale * out[pcnt:]

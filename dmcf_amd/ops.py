@@ -158,7 +158,7 @@ MAPPINGS = {"ball_to_cube_radial": 0, "ball_to_cube_volume_preserving": 1, "iden
 INTERPOLATIONS = {"linear": 0, "linear_border": 1, "nearest_neighbor": 2}
 WINDOWS = {None: 0, "explicit": 1, "poly6": 2, "cubic": 3, "linear": 4, "peak": 5, "cubic_grad": 6}
 
-FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE, FLAG_SKIP_SELF = 1, 2, 4, 8, 16
+FLAG_ALIGN_CORNERS, FLAG_NORMALIZE, FLAG_SYMMETRIC, FLAG_ACCUMULATE, FLAG_SKIP_SELF, FLAG_FILTER_PACKED = 1, 2, 4, 8, 16, 32
 
 
 class LaunchTimer:
@@ -306,6 +306,22 @@ FRS_IGNORE_QUERY_POINT, FRS_OPEN3D_CORNER_VOXELS, FRS_OPEN3D_VOXEL_WALK = 1, 2, 
 # The two emulations exist so that a capture of the real library (tools/capture_golden.py) can be matched bit for bit
 # whichever way it falls; they cost a fixup pass per search and break the lists' symmetry exactly where the library does.
 SEARCH_SETS = {"distance": 0, "open3d": FRS_OPEN3D_VOXEL_WALK, "open3d_corners": FRS_OPEN3D_CORNER_VOXELS}
+
+
+_CONSTS = {}
+
+
+def const_tensor(values, dtype, device):
+    """A small constant tensor on the device, built once per (values, dtype, device): ``torch.tensor(list, device=...)`` is a
+    blocking host -> device copy every time -- three of them per step were a third of the synchronising calls of a 2-D model's
+    step (tools/profile_small.py).  The result is shared: do not write to it."""
+    key = (tuple(float(v) for v in values), dtype, str(device))
+    t = _CONSTS.get(key)
+    if t is None:
+        if len(_CONSTS) > 256:
+            _CONSTS.clear()
+        t = _CONSTS[key] = torch.tensor(list(values), dtype=dtype, device=device)
+    return t
 
 
 def search_set():
@@ -673,7 +689,7 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
                   align_corners=True, coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear",
                   normalize=False, symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False,
                   n_pairs_ref=None, neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False,
-                  row_length_hint=0):
+                  row_length_hint=0, packed_cache=None):
     """One call of dmcf_cconv_forward.  ``row_length_hint``: 0 unknown / 1 tens / 2 hundreds of neighbours per row -- what the
     caller knows about the LAYER from its configuration (include/dmcf_hip.h).  ``skip_self``: DMCF_FLAG_SKIP_SELF (the list holds the query points, the layer ignores them; only the direct kernel).  ``name_only``: no launch, returns the name of the kernel these arguments dispatch to.  ``filter_tile_mask``: see ``block_diagonal_tile_mask`` (0 = no hint).  ``neighbors_row_count``: int32 [n_out] for padded lists (PaddedNeighborList).  ``window``: None | 'explicit' (neighbors_value = importance) |
     'poly6' | 'cubic' | 'linear' | 'peak' | 'cubic_grad' (neighbors_value = squared distances).
@@ -704,7 +720,23 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         _lib.check(L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96), "dmcf_cconv_kernel_name")
         return name.value.decode()
     nbytes = L.dmcf_cconv_workspace_bytes(ctypes.byref(a))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+    ws = None
+    if packed_cache is not None:
+        # ``packed_cache``: a dict the calling LAYER owns.  It keeps the workspace of the layer's last call; while the filter
+        # tensor (storage, version), its interpretation and the kernel the dispatch picks are the same, the packed filter in it
+        # is still valid and is not formed again (DMCF_FLAG_FILTER_PACKED: one launch less per layer and step)
+        name = ctypes.create_string_buffer(96)
+        L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96)
+        key = (filters.data_ptr(), filters._version, tuple(filters.shape), bool(symmetric), int(sym_axis), name.value, int(nbytes),
+               str(filters.device))
+        if packed_cache.get("key") == key:
+            ws = packed_cache["ws"]
+            a.flags |= FLAG_FILTER_PACKED
+        else:
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+            packed_cache["key"], packed_cache["ws"] = key, ws
+    if ws is None:
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
     t0 = timer.begin() if timer is not None else None
     _lib.check(L.dmcf_cconv_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_cconv_forward")
     if timer is not None:
@@ -820,50 +852,64 @@ class GridTooSparse(RuntimeError):
     the caller uses the sort-based device formulation instead."""
 
 
-def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, return_box=False):
-    """Lattice points of ``grid_pos`` (utils/tools/losses.py:136-181) via dmcf_grid_pos_bounds/_count/_write.
-    ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean).
-    ``return_box``: -> (points, (minp, dims) | None): the integer box of cells of THIS call (None for an empty result)."""
+def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=None):
+    """``grid_pos`` (utils/tools/losses.py:136-181) for SEVERAL voxel sizes over the same positions -- the coarse levels of one step
+    (losses.py:266-272) -- via dmcf_grid_pos_bounds/_count/_write with TWO host round trips for all of them (cells of every level,
+    then points of every level) instead of two per level.  -> [(points, (minp, dims) | None), ...]; raises GridTooSparse if any
+    level's box is too sparse for the dense cell table (the caller then takes the levels one at a time)."""
     import numpy as np
     L = _lib.lib()
     pos = _dev_f32(pos, "pos", 3)
     n = pos.shape[0]
-    vs = (ctypes.c_float * 3)(*[float(v) for v in np.asarray(voxel_size, dtype=np.float32).reshape(3)])
-    cen = None
-    if center is not None:
-        cen = _dev_f32(center.reshape(3), "center")
+    cen = _dev_f32(center.reshape(3), "center") if center is not None else None
+    cflag = 1 if centralize else 0
     ws_bytes = L.dmcf_grid_pos_workspace_bytes(n)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
-    common = (1 if centralize else 0,)
-    _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, common[0], _ptr(cen) if cen is not None else None, int(pad),
-                                      float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
-    hdr = ws[0:64].cpu()  # header.minp, dims, cells, (total,) centre (host round trip 1 of 2)
-    center_host = hdr[40:52].view(torch.float32).tolist()
-    minp, dims = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
-    cells = int(hdr[24:32].view(torch.int64).item())
-    if cells < 0:
-        raise _lib.DmcfError("grid_pos: positions are not finite")
-    if cells > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
-        raise GridTooSparse(f"{cells} lattice cells in the bounding box")
-    table = torch.empty(max(cells, 1), dtype=torch.int32, device=pos.device)
-    _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes, _ptr(table),
-                                     cells, _stream()), "dmcf_grid_pos_count")
-    total = int(ws[32:40].view(torch.int64).item())  # header.total (host round trip 2 of 2)
-    out = torch.empty((total, 3), dtype=torch.float32, device=pos.device)
-    if total:
-        _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, vs, common[0], int(pad), float(hyst), _ptr(ws), ws_bytes,
-                                         _ptr(table), cells, _ptr(out), total, _stream()), "dmcf_grid_pos_write")
-        if centralize and center is None:
-            # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
-            # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
-            from . import lattice
-            # (the entry keeps ``pos`` alive: its address + version identify the family for as long as the entry exists)
-            lattice.register(out, ws[40:52].view(torch.float32).clone(), [float(v) for v in vs],
-                             ("mean", pos.data_ptr(), pos.shape[0], pos._version), minp, dims, keep=pos,
-                             center_host=center_host)
-    if return_box:
-        return out, ((minp, dims) if total else None)
-    return out
+    levels = []
+    for v in voxel_sizes:
+        vs = (ctypes.c_float * 3)(*[float(x) for x in np.asarray(v, dtype=np.float32).reshape(3)])
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=pos.device)
+        _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, cflag, _ptr(cen) if cen is not None else None, int(pad),
+                                          float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
+        levels.append(dict(vs=vs, ws=ws))
+    hdrs = torch.stack([lv["ws"][0:64] for lv in levels]).cpu()  # (host round trip 1 of 2: every level's header)
+    for lv, hdr in zip(levels, hdrs):
+        lv["center_host"] = hdr[40:52].view(torch.float32).tolist()
+        lv["minp"], lv["dims"] = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
+        cells = lv["cells"] = int(hdr[24:32].view(torch.int64).item())
+        if cells < 0:
+            raise _lib.DmcfError("grid_pos: positions are not finite")
+        if cells > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
+            raise GridTooSparse(f"{cells} lattice cells in the bounding box")
+    for lv in levels:
+        lv["table"] = torch.empty(max(lv["cells"], 1), dtype=torch.int32, device=pos.device)
+        _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, lv["vs"], cflag, int(pad), float(hyst), _ptr(lv["ws"]), ws_bytes,
+                                         _ptr(lv["table"]), lv["cells"], _stream()), "dmcf_grid_pos_count")
+    totals = torch.stack([lv["ws"][32:40] for lv in levels]).cpu()  # (host round trip 2 of 2: every level's point count)
+    res = []
+    for lv, tot in zip(levels, totals):
+        total = int(tot.view(torch.int64).item())
+        out = torch.empty((total, 3), dtype=torch.float32, device=pos.device)
+        if total:
+            _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, lv["vs"], cflag, int(pad), float(hyst), _ptr(lv["ws"]), ws_bytes,
+                                             _ptr(lv["table"]), lv["cells"], _ptr(out), total, _stream()), "dmcf_grid_pos_write")
+            if centralize and center is None:
+                # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
+                # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
+                from . import lattice
+                # (the entry keeps ``pos`` alive: its address + version identify the family for as long as the entry exists)
+                lattice.register(out, lv["ws"][40:52].view(torch.float32).clone(), [float(v) for v in lv["vs"]],
+                                 ("mean", pos.data_ptr(), pos.shape[0], pos._version), lv["minp"], lv["dims"], keep=pos,
+                                 center_host=lv["center_host"])
+        res.append((out, (lv["minp"], lv["dims"]) if total else None))
+    return res
+
+
+def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, return_box=False):
+    """Lattice points of ``grid_pos`` (utils/tools/losses.py:136-181) via dmcf_grid_pos_bounds/_count/_write.
+    ``voxel_size``: 3 host floats; ``center``: optional [3] GPU tensor (lattice origin instead of the mean).
+    ``return_box``: -> (points, (minp, dims) | None): the integer box of cells of THIS call (None for an empty result)."""
+    out, box = grid_pos_many(pos, [voxel_size], centralize, pad, hyst, center)[0]
+    return (out, box) if return_box else out
 
 
 def window_sum(points, queries, radius, window=None, ignore_query_point=False, hash_table=None):

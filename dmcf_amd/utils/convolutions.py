@@ -366,7 +366,22 @@ def _init_tensor(name, shape, device):
 _ACTIVATIONS = {None: None, "linear": None, "relu": torch.relu, "tanh": torch.tanh}
 
 
-class ContinuousConv(torch.nn.Module):
+class PlainAttributes:
+    """Mix-in for the modules of this package: attributes that are neither parameters, buffers nor sub-modules go straight to the
+    instance dictionary.  torch.nn.Module.__setattr__ walks its registries and type checks for every assignment -- a layer sets
+    a dozen bookkeeping attributes per call (the reference's ``.nns``, ``._conv_values``, ...), 300 assignments per step of a 2-D
+    model: a fifth of that step's host time (tools/profile_small.py)."""
+
+    def __setattr__(self, name, value):
+        d = self.__dict__
+        if (isinstance(value, (torch.nn.Parameter, torch.nn.Module)) or "_parameters" not in d or name in d["_parameters"]
+                or name in d["_buffers"] or name in d["_modules"] or hasattr(type(self), name)):
+            super().__setattr__(name, value)  # (registries; properties and other class-level descriptors keep their setters)
+        else:
+            d[name] = value
+
+
+class ContinuousConv(PlainAttributes, torch.nn.Module):
     r"""Continuous convolution of Ummenhofer & Koltun (ICLR 2020) with DMCF's antisymmetric option:
 
         (f*g)(x) = 1/psi(x) * sum_{i in N(x,R)} a(x_i, x) f_i g(Lambda(x_i - x))
@@ -427,6 +442,7 @@ class ContinuousConv(torch.nn.Module):
         self.row_length_hint = 0
         self.accumulate_into = None  # one-shot, see forward
         self.extra_bias = None
+        self._packed = {}  # the workspace of the last dmcf_cconv_forward and what its packed filter was made from (ops.cconv_forward)
 
     # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
     def build(self, in_channels, device=None):
@@ -593,7 +609,8 @@ class ContinuousConv(torch.nn.Module):
             interpolation=self.interpolation, normalize=self.normalize, symmetric=symmetric, sym_axis=self.sym_axis,
             bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=n_pairs_ref,
             neighbors_row_count=row_count, skip_self=skip_self, row_length_hint=self.row_length_hint,
-            out=acc, accumulate=acc is not None)
+            out=acc, accumulate=acc is not None,
+            packed_cache=self._packed if os.environ.get("DMCF_CACHE_PACKED_FILTERS", "1") != "0" else None)
         if self._direct_kernel is None and in_step and self.radius_search_ignore_query_points:
             # (asked once per layer: the dispatch looks at the layer, never at the list)
             self._direct_kernel = ops.cconv_forward(
@@ -673,7 +690,7 @@ class ContinuousConv(torch.nn.Module):
         return (None, self.filters)
 
 
-class PointSampling(torch.nn.Module):
+class PointSampling(PlainAttributes, torch.nn.Module):
     """Mirror of the reference's ``PointSampling`` (utils/convolutions.py:888-1061): resamples features from one
     point set to another -- a ContinuousConv with a fixed 1x1x1 identity filter, optional window and
     normalisation by the summed window values.  Used by ``dens_norm`` to carry the density to the coarse

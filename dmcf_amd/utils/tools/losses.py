@@ -128,15 +128,30 @@ def get_dilated_pos(pos, strides, voxel_size=None, centralize=False, pad=0, hyst
     HRNet's cross-scale Dense branch uses."""
     from ... import ops
     pcnt, dilated_pos, idx = [], [], []
+    lattices = {}
+    if voxel_size is not None:
+        vs = voxel_size.detach().cpu().numpy() if isinstance(voxel_size, torch.Tensor) else voxel_size
+        coarse = [s for s in strides if s != 1]
+        if pos.is_cuda and len(coarse) > 1:
+            # every coarse level is built from the SAME positions: their kernels are enqueued together and the host waits twice
+            # for all of them, not twice per level (a step of the 2-D models is paced by its host round trips)
+            try:
+                res = ops.grid_pos_many(pos, [np.asarray(vs, dtype=np.float32) * np.float32(s) for s in coarse],
+                                        centralize=centralize, pad=pad, hyst=hyst)
+                lattices = {s: r[0] for s, r in zip(coarse, res)}
+            except ops.GridTooSparse:
+                lattices = {}  # (a level's box is too sparse for the dense cell table: one at a time, each in the form it needs)
     for stride in strides:
         if stride == 1:
             pcnt.append(pos.shape[0])
             dilated_pos.append(pos)
             idx.append(None)
         elif voxel_size is not None:
-            vs = voxel_size.detach().cpu().numpy() if isinstance(voxel_size, torch.Tensor) else voxel_size
-            v_scale = np.asarray(vs, dtype=np.float32) * np.float32(stride)  # :266
-            dilated_pos.append(grid_pos(pos, v_scale, centralize=centralize, pad=pad, hyst=hyst))
+            if stride in lattices:
+                dilated_pos.append(lattices[stride])
+            else:
+                v_scale = np.asarray(vs, dtype=np.float32) * np.float32(stride)  # :266
+                dilated_pos.append(grid_pos(pos, v_scale, centralize=centralize, pad=pad, hyst=hyst))
             pcnt.append(dilated_pos[-1].shape[0])
         else:
             sample_cnt = max(pos.shape[0] // stride, 1)  # :275

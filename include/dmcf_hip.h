@@ -168,6 +168,12 @@ enum dmcf_window {
 #define DMCF_FLAG_NORMALIZE 2
 #define DMCF_FLAG_SYMMETRIC 4  /* ASCC: filters is the stored half kernel, see above */
 #define DMCF_FLAG_ACCUMULATE 8 /* out += result instead of out = result (add_merge, models/hrnet.py:115-116) */
+#define DMCF_FLAG_FILTER_PACKED 32 /* the caller's promise that `workspace` still holds what the previous dmcf_cconv_forward with
+                                      the SAME filters (values included), filter_dims, flags & (SYMMETRIC | sym_axis) and kernel
+                                      choice (dmcf_cconv_kernel_name returns the same string for both calls) left there: the
+                                      filter is not packed again (one launch less per layer; inference weights do not change from
+                                      step to step, and a step of a 2,000-particle scene is paced by its launches).  The library
+                                      keeps no state: whoever sets the flag owns the workspace between the calls. */
 #define DMCF_FLAG_SKIP_SELF 16 /* pairs with neighbors_index[p] == the output row -- and pairs whose two positions are EQUAL, which
                                   is the test the search applies (ignore_query_point drops every point at the query position) --
                                   carry weight zero: a list searched WITH the query points serves a layer that ignores them (radius_search_ignore_query_points,

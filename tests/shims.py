@@ -21,7 +21,8 @@ def install(monkeypatch):
                       neighbors_value=None, window=None, window_fac=1.0, inp_importance=None, align_corners=True,
                       coordinate_mapping="ball_to_cube_volume_preserving", interpolation="linear", normalize=False,
                       symmetric=False, sym_axis=2, bias=None, out=None, accumulate=False, n_pairs_ref=None,
-                      neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False, row_length_hint=0):
+                      neighbors_row_count=None, filter_tile_mask=0, skip_self=False, name_only=False, row_length_hint=0,
+                      packed_cache=None):
         assert neighbors_row_count is None and not skip_self
         if name_only:
             return "cconv_oracle"  # (never "cconv_direct_kernel": the oracle backend does not share lists)

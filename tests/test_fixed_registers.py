@@ -1,5 +1,5 @@
 """Build-time contract of the splat kernels that keep their class tiles in FIXED registers (cconv_cls.hip: v92 .. v127,
-cconv_z3.hip: v80 .. v127, cconv_pair.hip: v116 .. v255 of 256): the compiler must stay below them -- that rests on how this toolchain reads
+cconv_z3.hip: v80 .. v127, cconv_pair.hip: v116 .. v255 of 256, cconv_ws.hip: v112 .. v255 of 256): the compiler must stay below them -- that rests on how this toolchain reads
 `amdgpu_num_vgpr` (half of the unified register file on gfx90a and later) -- and the kernel descriptors must still ask for all
 128 registers.  Cross-compiles the two files to assembly (no GPU needed) and reads it."""
 import os
@@ -55,7 +55,8 @@ def test_compiler_stays_below_the_tile_registers(tmp_path, name, first_tile, ext
     text = "\n".join(lines)
     counts = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", text)]
     assert counts.count(total) >= len(top)  # every splat kernel owns all its registers (tiles included)
-    first_mfma_tile = {"cconv_z3": "v[80:95]", "cconv_cls": "v[92:95]", "cconv_pair": "v[148:151]", "cconv_p16": "v[92:95]"}[name]
+    first_mfma_tile = {"cconv_z3": "v[80:95]", "cconv_cls": "v[92:95]", "cconv_pair": "v[148:151]", "cconv_ws": "v[148:151]",
+                       "cconv_p16": "v[92:95]"}[name]
     assert first_mfma_tile in text
-    if name in ("cconv_pair", "cconv_p16"):  # no spills: a reload inside the batch loop would wait for every prefetched load
+    if name in ("cconv_pair", "cconv_p16", "cconv_ws"):  # no spills: a reload inside the batch loop would wait for every prefetched load
         assert all(int(x) == 0 for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", text))

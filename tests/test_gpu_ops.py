@@ -1080,6 +1080,37 @@ def test_lattice_core_and_strays_equal_the_neighbour_list_layer(dev, monkeypatch
     assert z is acc or torch.equal(z, acc)
 
 
+def test_packed_filter_is_kept_between_calls_and_redone_when_the_weights_change(dev):
+    """DMCF_FLAG_FILTER_PACKED (include/dmcf_hip.h): a layer's second call reuses the packed filter its first call left in the
+    layer's workspace (same bits out), an in-place change of the weights is seen (its version is part of the key), and so is a
+    change of the kernel the dispatch picks."""
+    from dmcf_amd import ops
+    from dmcf_amd.utils.convolutions import ContinuousConv
+    from dmcf_amd.utils.tools.losses import get_window_func
+    g = torch.Generator().manual_seed(5)
+    pos = torch.rand(3000, 3, generator=g).to(dev)
+    feat = torch.randn(3000, 16, generator=g).to(dev)
+    conv = ContinuousConv(16, kernel_size=[4, 4, 4], activation=None, use_bias=False, window_function=get_window_func("poly6"),
+                          coordinate_mapping="ball_to_cube_volume_preserving", normalize=False).to(dev)
+    conv.build(16, dev)
+    y1 = conv(feat, pos, pos, 0.3)
+    key1, ws1 = conv._packed["key"], conv._packed["ws"]
+    y2 = conv(feat, pos, pos, 0.3)
+    assert conv._packed["key"] == key1 and conv._packed["ws"] is ws1 and torch.equal(y1, y2) and float(y1.abs().max()) > 0
+    with torch.no_grad():
+        conv.kernel.mul_(2.0)
+    y3 = conv(feat, pos, pos, 0.3)
+    assert conv._packed["key"] != key1 and torch.allclose(y3, 2 * y1, rtol=1e-6, atol=0)
+    os.environ["DMCF_CCONV_KERNEL"] = "blk"
+    try:
+        y4 = conv(feat, pos, pos, 0.3)
+    finally:
+        os.environ.pop("DMCF_CCONV_KERNEL")
+    assert conv._packed["key"][5] != key1[5] and torch.allclose(y4, y3, rtol=1e-4, atol=1e-5 * float(y3.abs().max()))
+    y5 = conv(feat, pos, pos, 0.3)
+    assert torch.equal(y5, y3)
+
+
 def test_reserve_device_memory(dev):
     """ops.reserve_device_memory makes the caching allocator's pool hold one free block of the requested size -- whatever the
     pool held before (this test runs after hundreds of others: the pool is many GB) -- and says what it took from the device; a

@@ -4,7 +4,9 @@ are threads of one process (dmcf_amd.parallel.LocalComm), every one runs the rea
 and per point set, owned points, ghosts of the set's widest plan and of the per-layer plans derived from it, and the rows /
 bytes of features exchanged per step, and the wall time of a step of all ranks divided by their number (the GPU time a
 rank's step costs, ghosts and exchanges included -- the ranks' kernels serialise on the one device).
-usage: python tools/ghost_fraction.py [side=100] [gx gy gz = 2 2 2] [steps=2]"""
+usage: python tools/ghost_fraction.py [side=100] [gx gy gz = 2 2 2] [steps=2] [weak | strong]
+``strong``: ONE box of side^3 fluid particles split over the gx * gy * gz ranks (blocks of side / g cells per axis: BASELINE.json's
+"1M particles @ 1/2/4/8 GPUs" read literally); ``weak`` (default): side^3 particles PER rank."""
 import json
 import os
 import sys
@@ -24,11 +26,15 @@ def main():
     side = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     grid = [int(x) for x in sys.argv[2:5]] if len(sys.argv) > 4 else [2, 2, 2]
     steps = int(sys.argv[5]) if len(sys.argv) > 5 else 2
+    strong = len(sys.argv) > 6 and sys.argv[6] == "strong"
     world = grid[0] * grid[1] * grid[2]
+    if strong:
+        assert all(side % g == 0 for g in grid), "strong: the box's side must be divisible by the ranks per axis"
+    block = [side // g for g in grid] if strong else [side] * 3  # lattice cells of a rank's block per axis
     torch.cuda.init()  # (before the rank threads make their first device calls concurrently)
     dev = torch.device("cuda:0")
     h = 0.05
-    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * side * h for g in grid], grid)
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * b * h for g, b in zip(grid, block)], grid)
     weights = dict(np.load(os.path.join(ROOT, "tests", "golden", "liquid3d_weights.npz")))
 
     def rank_fn(comm):
@@ -36,7 +42,7 @@ def main():
         model = getattr(models, cfg["name"])(**cfg)
         tc.load_into_model(model, weights, device=dev)
         sim = parallel.ShardedSimulator(model, comm, decomp)
-        state = parallel.shard_scene(scenes.box_block_scene(side, grid, comm.rank), decomp, comm.rank, dev, presharded=True)
+        state = parallel.shard_scene(scenes.box_block_scene(block, grid, comm.rank), decomp, comm.rank, dev, presharded=True)
         rows, times = [], []
         for _ in range(steps):
             before = sim.exchanged_rows
@@ -62,7 +68,7 @@ def main():
                     launch_inputs=launch)
 
     res = parallel.run_local_ranks(world, rank_fn)
-    out = dict(side=side, grid=grid, fluid_total=side ** 3 * world, ranks=res)
+    out = dict(side=side, grid=grid, scaling="strong" if strong else "weak", fluid_total=block[0] * block[1] * block[2] * world, ranks=res)
     print(json.dumps(out))
     last = max(r["step_seconds"][-1] for r in res)
     per_step = [max(r["step_seconds"][i] for r in res) for i in range(steps)]
