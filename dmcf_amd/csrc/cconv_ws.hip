@@ -48,9 +48,9 @@ constexpr int kWPts = WTM / kWProd; // points per producer
 constexpr int kWRow = 2048;         // floats per B row: [2 chunks of 16 channels][k' = (z * 4 + y) * 64 + channel * 4 + x]
 constexpr int kWRecG = 36;          // floats per record group: 8 products x 4 pairs, padded (bank = 4 g + 4 q + t)
 constexpr int kWRec = 16 * kWRecG;
-constexpr int kWWaveF = kWRec + 64 + 512; // per producer: records + index buffer + the ring's row table
+constexpr int kWWaveF = kWRec + 64 + 384; // per producer: records + index buffer + the ring's row tables (64 x (2 + 4))
 constexpr int kWMaxNT = 2;           // (the LDS: 128 KB of B tile + 18 KB of producer staging + 4 x 2 KB of sums per column tile)
-constexpr int kWRed = kWCons * WTM * 16 * kWMaxNT;  // partial sums of the consumers
+constexpr int kWRed = 2 * kWCons * WTM * 16 * kWMaxNT;  // partial sums of the consumers, two tiles' worth (see the consumers' loop)
 constexpr int kWCompilerVgprs = 56; // (the attribute counts HALF of the unified file: v0 .. v111)
 
 #define WS_FIXED_REGS                                                                                                      \
@@ -154,7 +154,7 @@ struct WsRing {
 __device__ __forceinline__ void ws_ld_idx(int sp, int r4, int o1, int o2, int o3, const float* Tab, __amdgpu_buffer_rsrc_t rI, const float* nval,
                                           int64_t rb0, int& j, float& nv, int& kk) {
     kk = (r4 + (sp >= o1 ? 1 : 0) + (sp >= o2 ? 1 : 0) + (sp >= o3 ? 1 : 0)) & 63;
-    const f32x2 ed = *(const f32x2*)(Tab + 8 * kk);
+    const f32x2 ed = *(const f32x2*)(Tab + 2 * kk);
     // (__builtin_bit_cast of a vector ELEMENT reads element 0 with this compiler: by value through __float_as_int)
     const int e = __float_as_int(ed.x), d = __float_as_int(ed.y);
     const bool ok = sp < e;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void ws_ld_pos(const float* inp_pos, int j, float& x,
 __device__ __forceinline__ WsRec ws_geom(int sp, int kk, const float* Tab, int window, const float* nval, const float* imp,
                                          float inv_r2, float window_fac, float inv_extent, int j, float nv, float x, float y, float z, bool& ok) {
     WsRec c;
-    const f32x4 o = *(const f32x4*)(Tab + 8 * kk + 4);
+    const f32x4 o = *(const f32x4*)(Tab + 128 + 4 * kk);
     ok = sp < __float_as_int(o.w);
     x -= o.x;
     y -= o.y;
@@ -250,8 +250,8 @@ __device__ __forceinline__ void ws_refill(WsKP kp0, int wi, int lane, int wave, 
     if (act) {
         const int e = start + nt;
         const int d = (int)(((uint32_t)(int)gap - (uint32_t)start) * 4u);
-        *(f32x4*)(Tab + 8 * lane) = (f32x4){__int_as_float(e), __int_as_float(d), 0.0f, 0.0f};
-        *(f32x4*)(Tab + 8 * lane + 4) = (f32x4){ox, oy, oz, __int_as_float(e)};
+        *(f32x2*)(Tab + 2 * lane) = (f32x2){__int_as_float(e), __int_as_float(d)};
+        *(f32x4*)(Tab + 128 + 4 * lane) = (f32x4){ox, oy, oz, __int_as_float(e)};
         ring.start = start;
         ring.end = e;
         ring.rblo = (int)rb0;
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         // =============================================== PRODUCER ===============================================
         float* Rec = smem + WTM * kWRow + wave * kWWaveF;  // [16 groups][kWRecG]: product q of pair 4 g + t at g * kWRecG + 4 q + t
         uint32_t* Jof = (uint32_t*)(Rec + kWRec);          // [64]: byte offset of the pair's feature row (kWOob: no pair)
-        float* Tab = Rec + kWRec + 64;                     // [64 rows (ring)][8]: {end, byte delta, -, -, x, y, z, end} of a row
+        float* Tab = Rec + kWRec + 64;                     // ring of 64 rows: [64][2] {end, byte delta}, then [64][4] {x, y, z, end}
         float* Fst = Bt + (kWPts * wave + kWPts - 1) * kWRow;  // [16 groups][32 channels (permuted)][4 pairs]: the LAST point's row
         // splat roles: this lane's channel (B operand, accumulator column) and plane offset z'
         const int ch = lane & 31, half = lane >> 5;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
 #include "cconv_pair_merge.inc"
                 ::: "memory", WS_FIXED_REGS);
             asm volatile(
-#include "cconv_pair_store.inc"
+#include "cconv_ws_store.inc"
                 :: [b] "v"(b) : "memory", WS_FIXED_REGS);
             asm volatile(
 #include "cconv_pair_zero.inc"
@@ -564,7 +564,9 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         const int cw = wave - kWProd;             // 0 .. 3
         const int ctid = tid - 64 * kWProd;       // 0 .. 255
         const int mi = lane & 15, mg = lane >> 4;
-        float* red = smem + WTM * kWRow + kWProd * kWWaveF;  // [kWCons][16][16 * NT]
+        float* const red0 = smem + WTM * kWRow + kWProd * kWWaveF;  // two buffers of [kWCons][16][16 * NT]
+        const int red_half = kWCons * WTM * 16 * kWMaxNT;
+        int tpar = 0;  // (tile parity: which buffer this tile's sums go to)
         const int NT = kp0->NT, ncol = 16 * NT;
         // This consumer's k' blocks: b = cw + 4 it of the 16 (z, y) x cin / 4 channel quads, b = zy * nqt + quad (it < cin).  What a
         // block needs -- the offset of its A fragments in a B row, the offset of its filter fragments in the packed filter -- is
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         }
         float prev[NTT];
         int64_t prev_pt0 = -1;
-        auto reduce_store = [&](WsKP kp) {
+        auto reduce_store = [&](WsKP kp, const float* red) {
             const int64_t n_out = kp->n_out;
             float* const out = kp->out;
 #pragma unroll
@@ -668,12 +670,14 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         WS_PULL1(8 * (G) + 4) WS_PULL1(8 * (G) + 5) WS_PULL1(8 * (G) + 6) WS_PULL1(8 * (G) + 7)                  \
     }
             WS_PULL8(0) WS_PULL8(1) WS_PULL8(2) WS_PULL8(3)
-            // ---- the previous tile's sums (every consumer wrote its part before the barrier above)
-            if (prev_pt0 >= 0) reduce_store(kp);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             WT(1)
-            WS_BARRIER();  // "free" (waits for the pull and for the reads of the sums)
+            WS_BARRIER();  // "free" (the pull has landed)
             WT(2)
+            // ---- the previous tile's sums: every consumer wrote its part before the "full" barrier above.  They sit in the buffer
+            // of the OTHER parity, which nobody writes before the next "full" barrier -- so this runs behind "free", off the
+            // producers' critical path (in front of it, it held them up for as long as the pull itself: tools/wtrace.py)
+            if (prev_pt0 >= 0) reduce_store(kp, red0 + (tpar ^ 1) * red_half);
             // ---- what the epilogue adds to, requested now (read behind the next barrier)
 #pragma unroll
             for (int r = 0; r < NTT; ++r) {
@@ -721,9 +725,10 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
             for (int n = 0; n < NTT; ++n) {
                 if (n < NT) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(cw * 16 + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
+                    for (int r = 0; r < 4; ++r) red0[tpar * red_half + (cw * 16 + 4 * mg + r) * ncol + n * 16 + mi] = acc[n][r];
                 }
             }
+            tpar ^= 1;
             WT(3)
         }
         WS_BARRIER();  // every consumer's sums of the last tile are in LDS
@@ -734,7 +739,7 @@ __global__ __launch_bounds__(kWThreads, 1) __attribute__((amdgpu_num_vgpr(kWComp
         }
 #endif
 #ifndef WS_DBG_NOCONS
-        reduce_store(kp0);
+        reduce_store(kp0, red0 + (tpar ^ 1) * red_half);
 #endif
     }
 }

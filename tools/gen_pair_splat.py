@@ -198,7 +198,23 @@ def generate_store(name, parked, outdir=None):
     write_inc(name, out, outdir)
 
 
-PRODUCT_FILES = ["cconv_pair_splat.inc", "cconv_pair_merge.inc", "cconv_pair_zero.inc", "cconv_pair_park.inc",
+def generate_ws_store(name, outdir=None):
+    """cconv_ws.hip: the merged tile -> the point's B row with EIGHT 16-byte stores instead of 32 4-byte ones: the 32 sums move
+    into the (idle) operand buffers v116 .. v147 first, [zz][y][x] -- a row's four x values are contiguous in k' -- (32 moves:
+    cheaper than the 24 LDS instructions they save; the producers of that kernel are alone on their SIMDs)."""
+    out = []
+    for zz in range(2):
+        for y in range(4):
+            for x in range(4):
+                out.append(f"v_mov_b32 v{PARK0 + 16 * zz + 4 * y + x}, v{home(2 * zz, y, x)}")
+    for zz in range(2):
+        for y in range(4):
+            r = PARK0 + 16 * zz + 4 * y
+            out.append(f"ds_write_b128 %[b], v[{r}:{r + 3}] offset:{1024 * zz + 256 * y}")
+    write_inc(name, out, outdir)
+
+
+PRODUCT_FILES = ["cconv_ws_store.inc", "cconv_pair_splat.inc", "cconv_pair_merge.inc", "cconv_pair_zero.inc", "cconv_pair_park.inc",
                  "cconv_pair_unpark.inc", "cconv_pair_store_parked.inc", "cconv_pair_store.inc"]
 
 
@@ -211,6 +227,7 @@ def write_product(outdir=None):
     generate_park("cconv_pair_unpark.inc", True, outdir)
     generate_store("cconv_pair_store_parked.inc", True, outdir)
     generate_store("cconv_pair_store.inc", False, outdir)
+    generate_ws_store("cconv_ws_store.inc", outdir)
 
 
 if __name__ == "__main__":

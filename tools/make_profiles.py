@@ -64,15 +64,28 @@ def pmc(src, tag, P):
             if ": pairs" in l:
                 name = l.split()[0]
                 mb[name] = (float(l.split("pairs")[1].split("M")[0]) * 1e6, float(l.split("M")[1].split("ms")[0]))
-    case_of = dict(pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC")
+    case_of = dict(pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC",
+                   ws_L14="L14", ws_L2="L2")
+    # (forced kernels: their time is in microbench_short.log, not in the default-dispatch table)
+    forced = {}
+    if os.path.exists(f"{src}/microbench_short.log"):
+        k = None
+        for l in open(f"{src}/microbench_short.log"):
+            if l.startswith("== DMCF_CCONV_KERNEL="):
+                k = l.strip().split("=")[-1]
+            elif ": pairs" in l and k:
+                forced[(k, l.split()[0])] = (float(l.split("pairs")[1].split("M")[0]) * 1e6, float(l.split("M")[1].split("ms")[0]))
     lines = [f"# SQ counters of every kernel above 3 % of the 1M step ({tag})\n",
              "`tools/pmc_kernel.sh`: three separate `rocprofv3 --kernel-trace --pmc` passes per kernel (no other trace domain), on the micro-benchmark "
              "case that exercises the kernel (`tools/microbench.py`, 1 + 5 launches; the search: `tools/bench_search.py`, the lattice form: "
             "`tools/bench_lattice.py`, pairs and ms averaged over the lists / layers the kernel ran on).  Derived per launch: "
              "SQ_INSTS_* / launches / pairs = wave instructions per neighbour pair; busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) resp. "
-             "SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of a launch (1024 SIMDs x 2.4 GHz x its time).\n",
-             "| kernel | case | pairs | ms | VALU / pair | SALU / pair | LDS / pair | VMEM / pair | matrix instr / pair | VALU busy | matrix busy | waves per SIMD | LDS bank-conflict cycles / LDS cycles |",
-             "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
+             "SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of a launch = 1024 SIMDs x the launch's OWN clock cycles: GRBM_GUI_ACTIVE of a "
+             "fourth pass, per XCD (round 4 assumed 2.4 GHz x the launch time and read 110 % for the search: the part clocks lower under "
+             "that kernel; the column `GHz` is cycles / time).  VALU busy + matrix busy is what the verdict asks for: the two pipes of a "
+             "SIMD do not overlap on this part (DESIGN section 4.2), so their sum is the fraction of SIMD time that issues arithmetic.\n",
+             "| kernel | case | pairs | ms | GHz | VALU / pair | SALU / pair | LDS / pair | VMEM / pair | matrix instr / pair | VALU busy | matrix busy | VALU + matrix | waves per SIMD | LDS bank-conflict cycles / LDS cycles |",
+             "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     raw = {}
     # the search (tools/bench_search.py: 1 + 5 padded launches per list) and the lattice form (tools/bench_lattice.py: 1 + 5
     # launches per layer): pairs / ms per launch averaged over the lists / layers the kernel ran on
@@ -93,21 +106,34 @@ def pmc(src, tag, P):
         for k, v in res.items():
             n = max(v.get("launches", 1), 1)
             case = case_of.get(label)
-            if case and case in mb:
+            if case and (label.split("_")[0], case) in forced:
+                pairs, ms = forced[(label.split("_")[0], case)]
+            elif case and case in mb:
                 pairs, ms = mb[case]
             elif k.split("::")[-1] in special:
                 case, pairs, ms = special[k.split("::")[-1]]
             else:
                 pairs, ms = None, None
             if pairs:
-                cyc = SIMDS * CLK * ms * 1e-3
+                # the launch's own clock: GRBM_GUI_ACTIVE is summed over the 8 XCDs (a figure outside 1 .. 3 GHz means it is
+                # not: then the counter is taken as it is; without the counter 2.4 GHz is assumed and said so)
+                gui = v.get("GRBM_GUI_ACTIVE", 0.0) / n
+                clk = None
+                for div in (8.0, 1.0, 32.0):
+                    c = gui / div / (ms * 1e-3)
+                    if 1.0e9 <= c <= 3.0e9:
+                        clk = c
+                        break
+                ghz = f"{clk / 1e9:.2f}" if clk else "2.4 (assumed)"
+                cyc = SIMDS * (clk or CLK) * ms * 1e-3
                 per = lambda c: v.get(c, 0.0) / n / pairs
-                lines.append(f"| `{k.split('::')[-1]}` | {case} | {pairs / 1e6:.1f}M | {ms:.2f} | {per('SQ_INSTS_VALU'):.2f} | {per('SQ_INSTS_SALU'):.2f} | "
+                valu, mat = 100 * v.get('SQ_ACTIVE_INST_VALU', 0) * 4 / n / cyc, 100 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / n / cyc
+                lines.append(f"| `{k.split('::')[-1]}` | {case} | {pairs / 1e6:.1f}M | {ms:.2f} | {ghz} | {per('SQ_INSTS_VALU'):.2f} | {per('SQ_INSTS_SALU'):.2f} | "
                              f"{per('SQ_INSTS_LDS'):.2f} | {per('SQ_INSTS_VMEM'):.3f} | {per('SQ_INSTS_MFMA'):.2f} | "
-                             f"{100 * v.get('SQ_ACTIVE_INST_VALU', 0) * 4 / n / cyc:.0f} % | {100 * v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / n / cyc:.0f} % | "
+                             f"{valu:.0f} % | {mat:.0f} % | {valu + mat:.0f} % | "
                              f"{v.get('SQ_WAVE_CYCLES', 0) * 4 / n / cyc:.2f} | {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f} |")
             else:
-                lines.append(f"| `{k.split('::')[-1]}` | {label} | | | | | | | | | | | {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f} |")
+                lines.append(f"| `{k.split('::')[-1]}` | {label} | | | | | | | | | | | | | {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f} |")
     lines.append("\nRaw sums:\n\n```json\n" + json.dumps(raw, indent=1) + "\n```")
     open(f"{P}/{tag}_kernel_pmc.md", "w").write("\n".join(lines) + "\n")
 
@@ -159,6 +185,68 @@ def ghosts(src, tag, P):
         open(f"{P}/{tag}_ghost_fraction.md", "w").write("\n".join(out) + "\n")
 
 
+def wave_specialisation(src, tag, P):
+    if not os.path.exists(f"{src}/microbench_short.log"):
+        return
+    out = [f"# Wave specialisation on the short-row layers ({tag}; `cconv_ws.hip`, DESIGN section 4.2 splat H)\n",
+           "The four layers at the network's base radius (s0 -> s0, R = 0.1, ~33 pairs per row, 1.12M outputs) under every kernel that serves "
+           "them (`DMCF_CCONV_KERNEL=... ONLY=L14,L2,L5,IN python tools/microbench.py`; ws = producers / consumers in a persistent "
+           "workgroup, z3 = splat E, cls = splat D, pair = splat F with one set of waves):\n", "```", open(f"{src}/microbench_short.log").read().rstrip(), "```\n"]
+    if os.path.exists(f"{src}/wtrace.log"):
+        out += ["Where a producer's and a consumer's clocks go (`make -C dmcf_amd/csrc ws_trace`, `tools/wtrace.py`: cycle stamps at the phase "
+                "boundaries, first producer / consumer of every 16th workgroup; the stamps cost ~5 %):\n", "```", open(f"{src}/wtrace.log").read().rstrip(), "```"]
+    open(f"{P}/{tag}_wave_specialisation.md", "w").write("\n".join(out) + "\n")
+
+
+def small_configs(src, tag, P):
+    out = [f"# The small configurations: where a step's time goes ({tag}, `tools/profile_small.py <rollout> 100` after 20 warm-up steps)\n",
+           "BASELINE.json configs 2 / 3 / 4 are paced by the HOST, not the GPU: per step the eager time, the synchronising calls torch "
+           "reports, the host profile (cProfile, tottime) and -- from `rocprofv3 --kernel-trace --stats` of the same command (220 steps "
+           "+ set-up) -- the kernels.\n"]
+    for r in ("waterramps", "wbcsph", "liquid3d_dam"):
+        if not os.path.exists(f"{src}/small_{r}.log"):
+            continue
+        log = [l.rstrip()[:150] for l in open(f"{src}/small_{r}.log") if "amdgpu.ids" not in l and "UserWarning" not in l and "_cuda_set_sync" not in l]
+        out += [f"## {r}\n", "```", "\n".join(log[:45]), "```\n"]
+        ks = f"{src}/small_kernel_stats_{r}.md"
+        if os.path.exists(ks):
+            t = open(ks).read().splitlines()
+            out += ["\n".join(t[:22]), "", t[-1], ""]
+    open(f"{P}/{tag}_small_configs.md", "w").write("\n".join(out) + "\n")
+
+
+def virtual_ranks(src, tag, P):
+    def row(prefix, grid, blocks):
+        n = grid.replace(" ", "")
+        st, lg = f"{src}/{prefix}_stats_{n}.md", f"{src}/{prefix}_{n}.log"
+        if not (os.path.exists(st) and os.path.exists(lg)):
+            return None
+        tot = [l for l in open(st) if l.startswith("total kernel time")][0].split()
+        ms, disp = float(tot[3]), int(tot[6])
+        ranks = eval(grid.replace(" ", "*"))
+        steps = [l for l in open(lg) if l.startswith("steps (all")]
+        wall = steps[0].split("per rank:")[1].split(";")[0].strip() if steps else ""
+        trips = steps[0].split("host round trips per step and rank:")[1].strip() if steps else ""
+        return f"| {blocks} | {ranks} | {ms / ranks:.1f} | {ms / ranks / 4:.1f} | {disp / ranks / 4:.0f} | {wall} | {trips} |"
+    head = ["| blocks | ranks | kernel ms per rank (4 steps) | per step | dispatches per rank and step | wall ms per rank, steps 1 - 4 | host round trips per rank and step (this communicator) |",
+            "|---|---:|---:|---:|---:|---|---:|"]
+    out = [f"# Kernel time and dispatches per virtual rank ({tag}, `tools/ghost_fraction.py 100 gx gy gz 4 [strong]` under `rocprofv3 --kernel-trace --stats`)\n",
+           "N virtual ranks = N threads of ONE process on ONE MI355X, each with the real kernels on its own block (LocalComm instead of RCCL: every "
+           "exchange is a device copy).  The ranks' kernels serialise on the one device, so the SUM of kernel durations / N is what a rank's step "
+           "costs its GPU -- ghost rows, plan building and exchange copies included.  Four steps (the first one with the exact searches).\n",
+           "## weak scaling: 100^3 particles PER rank\n"] + head
+    for g, b in (("1 1 1", "1x1x1"), ("2 1 1", "2x1x1"), ("2 2 1", "2x2x1"), ("2 2 2", "2x2x2")):
+        r = row("vranks", g, b)
+        if r:
+            out.append(r)
+    out += ["\n## strong scaling: ONE box of 100^3 particles split over the ranks (BASELINE.json's \"1M particles @ 1/2/4/8 GPUs\" read literally)\n"] + head
+    for g, b in (("1 1 1", "1x1x1"), ("2 1 1", "2x1x1 (50 x 100 x 100 per rank)"), ("2 2 1", "2x2x1 (50 x 50 x 100)"), ("2 2 2", "2x2x2 (50^3)")):
+        r = row("vranks" if g == "1 1 1" else "sranks", g, b)
+        if r:
+            out.append(r)
+    open(f"{P}/{tag}_virtual_rank_kernel_time.md", "w").write("\n".join(out) + "\n")
+
+
 def main(src, tag):
     P = os.path.join(ROOT, "profiles")
     b, d = last_json(f"{src}/bench.log"), last_json(f"{src}/bench_driver.log")
@@ -168,6 +256,9 @@ def main(src, tag):
     rollouts(src, tag, P)
     microbench(src, tag, P)
     ghosts(src, tag, P)
+    wave_specialisation(src, tag, P)
+    small_configs(src, tag, P)
+    virtual_ranks(src, tag, P)
     print("wrote", [f for f in sorted(os.listdir(P)) if f.startswith(tag)])
 
 

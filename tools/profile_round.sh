@@ -22,20 +22,37 @@ bash tools/pmc_kernel.sh $P cls1_L8 cconv_cls -- env ONLY=L8 python tools/microb
 bash tools/pmc_kernel.sh $P cls2_L5 cconv_cls -- env ONLY=L5 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P cls2n_L6 cconv_cls -- env ONLY=L6 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P cls4_LP cconv_cls -- env ONLY=LP python tools/microbench.py >> $OUT/pmc.txt 2>&1
-bash tools/pmc_kernel.sh $P z3_L14 cconv_z3 -- env ONLY=L14 python tools/microbench.py >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P z3_L14 cconv_z3 -- env DMCF_CCONV_KERNEL=z3 ONLY=L14 python tools/microbench.py >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P ws_L14 cconv_ws -- env ONLY=L14 python tools/microbench.py >> $OUT/pmc.txt 2>&1
+bash tools/pmc_kernel.sh $P ws_L2 cconv_ws -- env ONLY=L2 python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P direct_ASCC cconv_direct -- env ONLY=ASCC python tools/microbench.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P frs frs_query_padded -- python tools/bench_search.py >> $OUT/pmc.txt 2>&1
 bash tools/pmc_kernel.sh $P lat lat_conv_kernel -- python tools/bench_lattice.py >> $OUT/pmc.txt 2>&1
 python tools/bench_search.py > $OUT/search.log 2>&1
 python tools/bench_lattice.py > $OUT/lattice.log 2>&1
 timeout 600 python tools/microbench.py > $OUT/microbench.log 2>&1
+# the short-row layers under every kernel that serves them (round 5: wave specialisation), and the producers' / consumers' stamps
+for k in ws z3 cls pair; do echo "== DMCF_CCONV_KERNEL=$k" >> $OUT/microbench_short.log; DMCF_CCONV_KERNEL=$k ONLY=L14,L2,L5,IN timeout 300 python tools/microbench.py 2>&1 | grep pairs >> $OUT/microbench_short.log; done
+cp dmcf_amd/libdmcf_hip.so /tmp/product.so; cp variants/WTRACE.so dmcf_amd/libdmcf_hip.so
+for L in L14 L2 L5 IN; do DMCF_CCONV_KERNEL=ws ONLY=$L timeout 200 python tools/wtrace.py 2>&1 | grep -v amdgpu.ids >> $OUT/wtrace.log; done
+cp /tmp/product.so dmcf_amd/libdmcf_hip.so
+# the small configurations: host profile + synchronisations, and a kernel trace of 100 steady steps each
+for r in waterramps wbcsph liquid3d_dam; do timeout 300 python tools/profile_small.py $r 100 > $OUT/small_$r.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $OUT/sprof_$r -o p -- python tools/profile_small.py $r 100 > /dev/null 2>&1
+  python tools/rocpd_stats.py $(ls $OUT/sprof_$r/*.db | head -1) $OUT/small_kernel_stats_$r.md > /dev/null; rm -rf $OUT/sprof_$r
+done
 for r in "liquid3d_dam 200" "waterramps 600" "wbcsph 3200"; do set -- $r; timeout 900 python tools/long_rollout.py $1 $2 --out $OUT/rollout_$1.json >> $OUT/rollouts.log 2>&1; done
 timeout 900 python tools/ghost_fraction.py 100 2 2 2 4 > $OUT/ghost_weak.json 2> $OUT/ghost_weak.log
-timeout 900 python tools/ghost_fraction.py 50 2 2 2 4 > $OUT/ghost_strong.json 2> $OUT/ghost_strong.log
+timeout 900 python tools/ghost_fraction.py 100 2 2 2 4 strong > $OUT/ghost_strong.json 2> $OUT/ghost_strong.log
 # kernel time per virtual rank (rocprofv3 kernel trace of 4 steps) for 1 / 2 / 4 / 8 ranks: the input of DESIGN section 6's scaling model
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for g in "1 1 1" "2 1 1" "2 2 1" "2 2 2"; do n=$(echo $g | tr -d " ")
   rocprofv3 --kernel-trace --stats -d $OUT/vprof_$n -o p -- python tools/ghost_fraction.py 100 $g 4 > /dev/null 2> $OUT/vranks_$n.log
   python tools/rocpd_stats.py $(ls $OUT/vprof_$n/*.db | head -1) $OUT/vranks_stats_$n.md > /dev/null; rm -rf $OUT/vprof_$n
+done
+# ... and for ONE box of 100^3 particles split over 2 / 4 / 8 ranks (strong scaling)
+for g in "2 1 1" "2 2 1" "2 2 2"; do n=$(echo $g | tr -d " ")
+  rocprofv3 --kernel-trace --stats -d $OUT/sprof_$n -o p -- python tools/ghost_fraction.py 100 $g 4 strong > /dev/null 2> $OUT/sranks_$n.log
+  python tools/rocpd_stats.py $(ls $OUT/sprof_$n/*.db | head -1) $OUT/sranks_stats_$n.md > /dev/null; rm -rf $OUT/sprof_$n
 done
 tail -1 $OUT/bench.log | cut -c1-300; tail -1 $OUT/bench_driver.log | cut -c1-200
