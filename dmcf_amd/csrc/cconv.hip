@@ -506,7 +506,9 @@ size_t dmcf_cconv_workspace_bytes(const dmcf_cconv_args* a) {
     full_dims(a, dz, dy, dx);
     const LaunchCfg cfg = make_cfg(dx, dy, dz, a->filter_dims[3], a->filter_dims[4]);
     size_t floats = cfg.packed_floats;
-    const size_t mf = cconv_mfma_packed_floats(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
+    size_t mf = cconv_mfma_packed_floats(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]);
+    if (cconv_mfma_eligible(dz * dy * dx, a->filter_dims[3], a->filter_dims[4]))  // (+ the chunks' partial sums of a small launch)
+        mf = align_up(mf, 64) + cconv_mfma_partial_floats(dz * dy * dx, a->filter_dims[3], a->filter_dims[4], a->n_out);
     if (floats < mf) floats = mf;
     const size_t bf = cconv_blk_packed_floats(a->filter_dims[3], a->filter_dims[4]);
     if (floats < bf) floats = bf;
@@ -526,6 +528,8 @@ int dmcf_cconv_forward(const dmcf_cconv_args* a, void* workspace, size_t workspa
     if (workspace_bytes < dmcf_cconv_workspace_bytes(a)) return DMCF_EWORKSPACE;
 
     CconvParams p;
+    p.partial = nullptr;
+    p.csplit = 0;
     int dz, dy, dx;
     full_dims(a, dz, dy, dx);
     p.cin = a->filter_dims[3];

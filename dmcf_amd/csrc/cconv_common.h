@@ -36,6 +36,8 @@ struct CconvParams {
     int bfloats;   // floats reserved for B / the reduction buffer (whichever is larger)
     int ntiles, tiles_per_xcd;
     int KT;        // matrix-core splat only: number of 16-cell tiles (ceil(K/16))
+    float* partial;  // matrix-core splat, small launches: [nchunks][n_out][cout] partial sums, one channel chunk per workgroup row
+    int csplit;      // ... 1: blockIdx.y = the workgroup's chunk (cconv_mfma.hip, kSplitMaxOut)
 };
 
 // ---- per-pair math (float restatement of Open3D's CoordinateTransformation.h, see oracle/dmcf_oracle.c).
@@ -231,6 +233,7 @@ __global__ void pack_filter(const float* __restrict__ src, float* __restrict__ d
 // cconv_mfma.hip
 bool cconv_mfma_eligible(int K, int cin, int cout);
 size_t cconv_mfma_packed_floats(int K, int cin, int cout);
+size_t cconv_mfma_partial_floats(int K, int cin, int cout, int64_t n_out);  // (0: the launch does not split its chunks)
 int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, int dx, void* workspace, hipStream_t stream);
 
 

@@ -79,7 +79,9 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
 #pragma unroll
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
-    for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+    // (small launches: one channel chunk per workgroup, blockIdx.y -- see cconv_mfma_launch)
+    const int chunk_lo = p.csplit ? (int)blockIdx.y : 0, chunk_hi = p.csplit ? (int)blockIdx.y + 1 : p.nchunks;
+    for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         const int c0 = chunk * MCH;
         const bool ch_ok = c0 + mi < cin;
         // ---------------- splat on the matrix cores: two points per wave ----------------
@@ -298,6 +300,10 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < kMWaves; ++w) v += red[((size_t)w * MTM + ptt) * ncol + o];
+        if (p.csplit) {  // this chunk's share: cconv_mfma_sum_chunks adds the chunks in order, the bias and the value to accumulate to
+            p.partial[((size_t)chunk_lo * p.n_out + ii) * cout + o] = v;
+            continue;
+        }
         if (p.flags & DMCF_FLAG_NORMALIZE) {
             const float nv = norm[ptt];
             if (nv != 0.0f) v /= nv;
@@ -308,6 +314,27 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
         *dst = v;
     }
 }
+
+// out = (+=) sum over the chunks of their partial sums, in chunk order, + bias
+__global__ void cconv_mfma_sum_chunks(const float* __restrict__ partial, int nchunks, int64_t n_out, int cout, const float* __restrict__ bias,
+                                      float* __restrict__ out, int accumulate) {
+    const int64_t total = n_out * cout;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        for (int c = 0; c < nchunks; ++c) v += partial[(size_t)c * total + e];
+        if (bias) v += bias[e % cout];
+        if (accumulate) v += out[e];
+        out[e] = v;
+    }
+}
+
+// A launch of a few thousand output points is a few hundred workgroups, each of which walks its rows once per 16-channel chunk --
+// dependent round trips, one chunk after the other: 92 us per launch for the 2,401-point 2-D scenes whatever the work (rocprofv3,
+// profiles/r05_small_configs.md), times the 27 - 43 layers of a step.  With DMCF_MFMA_SPLIT=1 and at most kSplitMaxOut outputs
+// every chunk gets its own workgroup (grid.y) and the chunks' partial sums meet in a small second kernel: the same products, the
+// chunks added in order.  OPT-IN, because measured it is a wash: those steps are paced by the host, and the second launch costs it
+// what the shorter kernel saves the GPU (WBC-SPH architecture 5.37 -> 5.17 ms per step, WaterRamps 3.15 -> 3.45).
+constexpr int64_t kSplitMaxOut = 16384;
 
 struct MfmaCfg {
     int KT, KCp, nblocks, NT, nchunks;
@@ -345,6 +372,13 @@ bool cconv_mfma_eligible(int K, int cin, int cout) {
 
 size_t cconv_mfma_packed_floats(int K, int cin, int cout) { return mfma_cfg(K, cin, cout).packed_floats; }
 
+size_t cconv_mfma_partial_floats(int K, int cin, int cout, int64_t n_out) {
+    const int nchunks = (cin + MCH - 1) / MCH;
+    const char* e = getenv("DMCF_MFMA_SPLIT");
+    if (nchunks < 2 || n_out > kSplitMaxOut || !e || e[0] != '1') return 0;
+    return (size_t)nchunks * (size_t)n_out * (size_t)cout;
+}
+
 int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, int dx, void* workspace,
                       hipStream_t stream) {
     const MfmaCfg cfg = mfma_cfg(p.K, p.cin, p.cout);
@@ -370,6 +404,9 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
     p.ntiles = (int)ntiles;
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
+    const size_t partial = (a->flags & DMCF_FLAG_NORMALIZE) ? 0 : cconv_mfma_partial_floats(p.K, p.cin, p.cout, p.n_out);
+    p.csplit = partial ? 1 : 0;
+    p.partial = partial ? packed + align_up(cfg.packed_floats, 64) : nullptr;
     const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
                            a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
     const bool plane16 = !generic && dx * dy == 16;
@@ -395,10 +432,15 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
         return DMCF_ELAUNCH;
     }
     void* kargs[] = {(void*)&p};
-    e = hipLaunchKernel(fn, dim3(grid), dim3(kMThreads), kargs, cfg.lds, stream);
+    e = hipLaunchKernel(fn, dim3(grid, p.csplit ? (unsigned)p.nchunks : 1u), dim3(kMThreads), kargs, cfg.lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return DMCF_ELAUNCH;
+    }
+    if (p.csplit) {
+        const int64_t total = p.n_out * p.cout;
+        hipLaunchKernelGGL(cconv_mfma_sum_chunks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.partial, p.nchunks, p.n_out,
+                           p.cout, p.bias, p.out, (p.flags & DMCF_FLAG_ACCUMULATE) ? 1 : 0);
     }
     return check_launch();
 }
