@@ -773,8 +773,8 @@ bool cconv_ws_eligible(const dmcf_cconv_args* a, int dz, int dy, int dx) {
     if (a->n_inp >= (1 << 24) || a->n_inp * (int64_t)cin * 4 >= ((int64_t)1 << 31)) return false;
     if (e) return true;
     // short rows (the layers at the network's base radius) whose contraction is at least as much work as their splat: the 32 -> 32
-    // layer takes 2.96 ms here against 3.35 with splat E, 24 -> 16 2.36 against 2.56; 16 -> 32 and 8 -> 16 lose (2.45 / 2.07 against
-    // 1.83 / 1.30: the producers are alone on their SIMDs and every phase of theirs runs at its latency) -- profiles/r05_microbench.md
+    // layer takes 2.92 ms here against 3.39 with splat E, 24 -> 16 2.30 against 2.62; 16 -> 32 and 8 -> 16 lose (2.31 / 1.91 against
+    // 1.84 / 1.28: the producers are alone on their SIMDs and every phase of theirs runs at its latency) -- profiles/r05_microbench.md
     return a->row_length_hint == 1 && cin >= 24;
 }
 

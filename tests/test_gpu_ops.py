@@ -1111,6 +1111,31 @@ def test_packed_filter_is_kept_between_calls_and_redone_when_the_weights_change(
     assert torch.equal(y5, y3)
 
 
+@pytest.mark.parametrize("cin,cout,ks,dim", [(24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2), (40, 24, (4, 4, 4), 3)])
+def test_matrix_core_splat_with_one_chunk_per_workgroup(oracle, dev, monkeypatch, cin, cout, ks, dim):
+    """DMCF_MFMA_SPLIT=1 (cconv_mfma.hip): a small launch gives every 16-channel chunk its own workgroup and sums the chunks'
+    partial results in a second kernel -- against the oracle, with bias + accumulate, and against the one-pass form."""
+    from dmcf_amd import ops
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "mfma")
+    radius = 0.3 if dim == 3 else 0.12
+    inp, out, feat, filt = _conv_inputs(oracle, 78, 900, 600, cin, cout, ks, radius, dim)
+    rng = np.random.default_rng(3)
+    bias = rng.normal(size=cout).astype(np.float32)
+    nns = ops.fixed_radius_search(_t(inp, dev), _t(out, dev), radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in nns)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2), f64=True)
+    res = {}
+    for split in ("1", "0"):
+        monkeypatch.setenv("DMCF_MFMA_SPLIT", split)
+        acc = torch.full((out.shape[0], cout), 0.25, device=dev)
+        ops.cconv_forward(_t(filt, dev), _t(out, dev), 2 * radius, _t(inp, dev), _t(feat, dev), nns.neighbors_index,
+                          nns.neighbors_row_splits, neighbors_value=nns.neighbors_distance, window="poly6", bias=_t(bias, dev),
+                          out=acc, accumulate=True)
+        res[split] = acc.cpu().numpy()
+        _close(res[split], ref + bias + 0.25)
+    assert np.abs(res["1"] - res["0"]).max() <= 2e-6 * np.abs(res["0"]).max()
+
+
 def test_reserve_device_memory(dev):
     """ops.reserve_device_memory makes the caching allocator's pool hold one free block of the requested size -- whatever the
     pool held before (this test runs after hundreds of others: the pool is many GB) -- and says what it took from the device; a

@@ -82,9 +82,13 @@ def pmc(src, tag, P):
              "SQ_INSTS_* / launches / pairs = wave instructions per neighbour pair; busy = SQ_ACTIVE_INST_VALU x 4 (quad-cycles) resp. "
              "SQ_VALU_MFMA_BUSY_CYCLES over the SIMD-cycles of a launch = 1024 SIMDs x the launch's OWN clock cycles: GRBM_GUI_ACTIVE of a "
              "fourth pass, per XCD (round 4 assumed 2.4 GHz x the launch time and read 110 % for the search: the part clocks lower under "
-             "that kernel; the column `GHz` is cycles / time).  VALU busy + matrix busy is what the verdict asks for: the two pipes of a "
-             "SIMD do not overlap on this part (DESIGN section 4.2), so their sum is the fraction of SIMD time that issues arithmetic.\n",
-             "| kernel | case | pairs | ms | GHz | VALU / pair | SALU / pair | LDS / pair | VMEM / pair | matrix instr / pair | VALU busy | matrix busy | VALU + matrix | waves per SIMD | LDS bank-conflict cycles / LDS cycles |",
+             "that kernel; the column `GHz` is cycles / time -- and the search STILL reads 113 % at its measured 2.34 GHz: SQ_ACTIVE_INST_VALU "
+             "sums, over the waves of a SIMD, the cycles each wave has a vector instruction in flight, and with 7 waves per SIMD those overlap "
+             "in the pipeline.  So `VALU active` is an occupancy of the vector pipe by waves, not a utilisation: it bounds nothing above "
+             "~2 waves per SIMD; the instruction counts per pair are the figures to go by there).  For the splat kernels (2 - 4 waves per SIMD) "
+             "VALU active + matrix busy is what the verdict asks for: the two pipes of a SIMD do not overlap on this part (DESIGN section "
+             "4.2), so their sum is the fraction of SIMD time that issues arithmetic.\n",
+             "| kernel | case | pairs | ms | GHz | VALU / pair | SALU / pair | LDS / pair | VMEM / pair | matrix instr / pair | VALU active | matrix busy | VALU + matrix | waves per SIMD | LDS bank-conflict cycles / LDS cycles |",
              "|---|---|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|---:|"]
     raw = {}
     # the search (tools/bench_search.py: 1 + 5 padded launches per list) and the lattice form (tools/bench_lattice.py: 1 + 5
