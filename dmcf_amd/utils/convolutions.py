@@ -489,7 +489,8 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
         # one-shot requests of the caller (models/hrnet.py): add the result to this tensor in the kernel's epilogue
         # (DMCF_FLAG_ACCUMULATE) instead of returning a new one, and add this vector to the layer's bias
         acc, extra_bias = self.accumulate_into, self.extra_bias
-        self.accumulate_into = self.extra_bias = None
+        d = self.__dict__  # (bookkeeping attributes written straight to the instance dictionary: PlainAttributes would put them there too)
+        d["accumulate_into"] = d["extra_bias"] = None
         if acc is not None and (self.use_dense_layer_for_center or self.activation is not None or not acc.is_contiguous()
                                 or tuple(acc.shape) != (out_positions.shape[0], self.filters) or acc.dtype != torch.float32):
             # not expressible in the epilogue: the plain call, then the sums (the extra bias OUTSIDE the layer's activation)
@@ -516,10 +517,10 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
             if lat is not None:
                 # both point sets are grid_pos lattices of this step: no search, no per-pair geometry
                 # (dmcf_lattice_conv_forward; DMCF_LATTICE_CONV=0 keeps the neighbour-list form)
-                self.nns = None
+                d["nns"] = None
                 fuse_bias = self.use_bias and not self.use_dense_layer_for_center
-                self._n_out_last = out_positions.shape[0]
-                self._pairs_last = 0  # no pair list in this form
+                d["_n_out_last"] = out_positions.shape[0]
+                d["_pairs_last"] = 0  # no pair list in this form
                 out_features = lat.conv(
                     ops, self.kernel, inp_features, out_positions.shape[0], extent,
                     window=self.window_function.name, window_fac=self.window_function.fac,
@@ -545,18 +546,18 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                     if valid is not None:
                         res = res * valid
                     out_features.index_add_(0, idx_s, res)
-                self._conv_values, self._conv_output = None, (None if _CACHE.depth > 0 else out_features)
+                d["_conv_values"], d["_conv_output"] = None, (None if _CACHE.depth > 0 else out_features)
                 return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             radius = float(np.float32(0.5) * np.float32(extent))  # :353
             if fixed_radius_search_hash_table is not None:
-                self.nns = self.fixed_radius_search(inp_positions, out_positions, radius,
+                d["nns"] = self.fixed_radius_search(inp_positions, out_positions, radius,
                                                     hash_table=fixed_radius_search_hash_table)
             else:
                 shared = None
                 if self._shares_list():
                     shared = _CACHE.with_query_points(self.fixed_radius_search, inp_positions, out_positions, radius)
                 skip_self = shared is not None
-                self.nns = shared if skip_self else _CACHE.search(
+                d["nns"] = shared if skip_self else _CACHE.search(
                     self.fixed_radius_search, inp_positions, out_positions, radius,
                     distances=not isinstance(self.window_function, WindowFunction))
             # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
@@ -574,8 +575,8 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                         neighbors_row_splits, row_count = self.nns.csr_row_splits, None
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
         # stats (convolutions.py:385-388) are formed lazily (property _avg_neighbors): no host sync here
-        self._n_out_last = out_positions.shape[0]
-        self._pairs_last = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
+        d["_n_out_last"] = out_positions.shape[0]
+        d["_pairs_last"] = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
 
         kernel = self.kernel
         symmetric = self.symmetric
@@ -589,7 +590,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
         # step (neighbor_cache scope) that would pin every layer's neighbour list (GBs each) and activations into the
         # next step: there only the small entries are kept.
         in_step = _CACHE.depth > 0
-        self._conv_values = {
+        d["_conv_values"] = {
             "filters": kernel, "out_positions": out_positions, "extents": extent, "offset": self.offset,
             "inp_positions": inp_positions, "inp_features": None if in_step else inp_features,
             "inp_importance": inp_importance,
@@ -624,7 +625,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                 # list's buffers back after the number of consumers it saw in the previous step)
                 _CACHE.with_query_points(self.fixed_radius_search, inp_positions, out_positions,
                                          float(np.float32(0.5) * np.float32(extent)))
-        self._conv_output = None if in_step else out_features
+        d["_conv_output"] = None if in_step else out_features
         return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
 
     def _epilogue_bias(self, fuse_bias, extra_bias):

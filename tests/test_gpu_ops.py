@@ -1136,6 +1136,52 @@ def test_matrix_core_splat_with_one_chunk_per_workgroup(oracle, dev, monkeypatch
     assert np.abs(res["1"] - res["0"]).max() <= 2e-6 * np.abs(res["0"]).max()
 
 
+@pytest.mark.parametrize("n_out,cin,cout", [(1, 32, 32), (17, 24, 16), (250, 32, 8), (4097, 28, 32), (40000, 32, 32), (70001, 24, 16)])
+def test_wave_specialised_kernel_on_ragged_lists(dev, monkeypatch, n_out, cin, cout):
+    """cconv_ws.hip on hand-made lists: rows from empty to several batches in random order (a producer's stream packs four rows
+    into shared batches, a tile starts a batch, the row ring is refilled every 8 tiles -- 40000 and 70001 outputs give a workgroup
+    more than 8 tiles), a number of outputs that is no multiple of the tile, padded and CSR form of the same list: the same bits,
+    and the sums of splat D within rounding."""
+    from dmcf_amd import ops
+    g = torch.Generator().manual_seed(n_out)
+    n_inp = 5000
+    inp = torch.rand(n_inp, 3, generator=g)
+    out = torch.rand(n_out, 3, generator=g)
+    feat = torch.randn(n_inp, cin, generator=g)
+    W = torch.rand(4, 4, 4, cin, cout, generator=g) - 0.5
+    # row lengths: a third empty, most short, a few long (several batches)
+    u = torch.rand(n_out, generator=g)
+    counts = torch.where(u < 0.33, torch.zeros(n_out), torch.where(u < 0.95, torch.floor(u * 60), torch.floor(100 + u * 200))).long()
+    rs = torch.zeros(n_out + 1, dtype=torch.int64)
+    rs[1:] = torch.cumsum(counts, 0)
+    idx = torch.randint(0, n_inp, (int(rs[-1]),), generator=g, dtype=torch.int32)
+    # positions of the neighbours do not have to lie within the radius: the kernels take the list as it is (window of d^2 / R^2
+    # clamps); an extent that covers the unit cube keeps every pair inside the filter
+    dv = lambda t: t.to(dev)
+    args = (dv(W), dv(out), 4.0, dv(inp), dv(feat), dv(idx), dv(rs))
+    res = {}
+    for k in ("ws", "cls"):
+        monkeypatch.setenv("DMCF_CCONV_KERNEL", k)
+        assert ops.cconv_forward(*args, window="poly6", name_only=True).startswith("cconv_ws_kernel" if k == "ws" else "cconv_cls_kernel")
+        res[k] = ops.cconv_forward(*args, window="poly6")
+    torch.cuda.synchronize()
+    scale = float(res["cls"].abs().max())
+    assert scale > 0 or int(rs[-1]) == 0
+    assert float((res["ws"] - res["cls"]).abs().max()) <= 2e-6 * max(scale, 1e-30)
+    assert torch.equal(res["ws"][counts.to(dev) == 0], torch.zeros_like(res["ws"][counts.to(dev) == 0]))
+    # the same list with rows at a fixed stride (the single-pass search's form): identical bits
+    monkeypatch.setenv("DMCF_CCONV_KERNEL", "ws")
+    stride = int(counts.max()) + 3
+    pidx = torch.zeros(n_out * stride, dtype=torch.int32)
+    for i in torch.nonzero(counts).flatten().tolist()[:2000]:
+        pidx[i * stride: i * stride + int(counts[i])] = idx[int(rs[i]): int(rs[i + 1])]
+    if n_out <= 2000:
+        prs = torch.arange(n_out + 1, dtype=torch.int64) * stride
+        y = ops.cconv_forward(dv(W), dv(out), 4.0, dv(inp), dv(feat), dv(pidx), dv(prs), window="poly6",
+                              neighbors_row_count=dv(counts.to(torch.int32)))
+        assert torch.equal(y, res["ws"])
+
+
 def test_reserve_device_memory(dev):
     """ops.reserve_device_memory makes the caching allocator's pool hold one free block of the requested size -- whatever the
     pool held before (this test runs after hundreds of others: the pool is many GB) -- and says what it took from the device; a
