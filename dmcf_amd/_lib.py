@@ -88,6 +88,7 @@ SYMBOLS = [
     "dmcf_reduce_subarrays_sum", "dmcf_points_aabb_workspace_bytes", "dmcf_points_aabb", "dmcf_dense_forward",
     "dmcf_fps_workspace_bytes", "dmcf_farthest_point_sample", "dmcf_gather_point",
     "dmcf_grid_pos_workspace_bytes", "dmcf_grid_pos_bounds", "dmcf_grid_pos_count", "dmcf_grid_pos_write",
+    "dmcf_ghost_workspace_bytes", "dmcf_ghost_count", "dmcf_ghost_write",
 ]
 
 
@@ -148,6 +149,14 @@ def lib():
     L.dmcf_dense_forward.restype = c.c_int
     L.dmcf_dense_forward.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p, c.c_void_p,
                                      c.c_void_p]
+    L.dmcf_ghost_workspace_bytes.restype = c.c_size_t
+    L.dmcf_ghost_workspace_bytes.argtypes = [c.c_int64, c.c_int32, c.c_int32]
+    L.dmcf_ghost_count.restype = c.c_int
+    L.dmcf_ghost_count.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int32, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p,
+                                   c.c_size_t, c.c_void_p]
+    L.dmcf_ghost_write.restype = c.c_int
+    L.dmcf_ghost_write.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int32, c.c_void_p, c.c_int32, c.c_void_p, c.c_void_p,
+                                   c.c_void_p, c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_points_aabb_workspace_bytes.restype = c.c_size_t
     L.dmcf_points_aabb_workspace_bytes.argtypes = []
     L.dmcf_points_aabb.restype = c.c_int

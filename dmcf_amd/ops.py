@@ -914,6 +914,48 @@ def grid_pos(pos, voxel_size, centralize=False, pad=0, hyst=0.1, center=None, re
     return (out, box) if return_box else out
 
 
+class GhostSelection:
+    """A started ghost selection (dmcf_ghost_count has run): ``totals`` int64 [W, B] on the device = entries box b contributes to
+    the list of width w.  :meth:`write` produces the lists once their sizes are known on the host."""
+
+    def __init__(self, pos, boxes, widths2, ws, totals):
+        self.pos, self.boxes, self.widths2, self.ws, self.totals = pos, boxes, widths2, ws, totals
+
+    def write(self, sizes):
+        """``sizes``: entries of list(w) per width (host ints: the row sums of ``totals``, read by the caller -- or known from the
+        ranks that counted the same points).  -> [int64 tensor of list(w) for every w]: box-major, ascending point index."""
+        L = _lib.lib()
+        W, B = self.totals.shape
+        sizes = [int(v) for v in sizes]
+        starts = [0]
+        for v in sizes[:-1]:
+            starts.append(starts[-1] + v)
+        rows = torch.empty(max(sum(sizes), 1), dtype=torch.int64, device=self.pos.device)
+        c64 = ctypes.c_int64 * W
+        w2 = (ctypes.c_float * W)(*self.widths2)
+        _lib.check(L.dmcf_ghost_write(_ptr(self.pos), self.pos.shape[0], _ptr(self.boxes), B, w2, W, _ptr(rows), c64(*starts), c64(*sizes),
+                                      _ptr(self.ws), self.ws.numel(), _stream()), "dmcf_ghost_write")
+        return [rows[starts[w]: starts[w] + sizes[w]] for w in range(W)]
+
+
+def ghost_select(pos, boxes, widths2):
+    """dmcf_ghost_count: for every point of ``pos`` [n, 3] and every box of ``boxes`` [B, 6] (lo xyz, hi xyz; device float32) the
+    number of ``widths2`` (host floats, DESCENDING) its squared distance to the box does not exceed.  Returns a
+    :class:`GhostSelection`."""
+    L = _lib.lib()
+    pos = _dev_f32(pos, "pos", 3)
+    boxes = _dev_f32(boxes.reshape(-1, 6), "boxes", 6)
+    B, W = boxes.shape[0], len(widths2)
+    widths2 = [float(np.float32(v)) for v in widths2]
+    nbytes = L.dmcf_ghost_workspace_bytes(pos.shape[0], B, W)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=pos.device)
+    totals = torch.empty((W, B), dtype=torch.int64, device=pos.device)
+    w2 = (ctypes.c_float * W)(*widths2)
+    _lib.check(L.dmcf_ghost_count(_ptr(pos), pos.shape[0], _ptr(boxes), B, w2, W, _ptr(totals), _ptr(ws), nbytes, _stream()),
+               "dmcf_ghost_count")
+    return GhostSelection(pos, boxes, widths2, ws, totals)
+
+
 def window_sum(points, queries, radius, window=None, ignore_query_point=False, hash_table=None):
     """dmcf_frs_window_sum: out[q] = sum_{|p - q| <= R} window(|p - q|^2 / R^2) (``window``: a WINDOWS key; None counts
     the neighbours, 'explicit' sums the squared distances).  The fused form of ``compute_density``

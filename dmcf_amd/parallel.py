@@ -99,6 +99,13 @@ class Comm:
         recv = self.all_to_all(send, recv_counts=recv_counts)
         return lambda: recv
 
+    def exchange_counts(self, counts):
+        """``counts`` int64 [world, k] on the device, row r = what this rank announces to rank r.  Returns (the same numbers, the rows
+        the other ranks announced to this one) as nested host lists -- ONE device -> host read for both: the announcement is a
+        device-side collective, nothing has to be on the host before it."""
+        h = host(counts)
+        return h, h
+
     def exchange_rows_start(self, rows, send_counts, recv_counts):
         """The exchange of a ghost plan: ``rows`` [sum(send_counts), C] already in peer order (one gather by the plan's
         concatenated send list), both count lists known on the host.  Returns a function that waits and returns the received
@@ -151,6 +158,15 @@ class TorchDistComm(Comm):
         dist.all_to_all_single(out, inp, output_split_sizes=rc, input_split_sizes=sc, group=self.group)
         parts = torch.split(out.to(dev), rc, dim=0)
         return [p.reshape((p.shape[0],) + trailing) for p in parts]
+
+    def exchange_counts(self, counts):
+        world, k = counts.shape
+        x = counts.contiguous().to(torch.device("cpu") if self.stage else counts.device)
+        out = torch.empty_like(x)
+        self.dist.all_to_all_single(out, x, group=self.group)
+        both = host(torch.cat([x.reshape(-1), out.reshape(-1)]))
+        n = world * k
+        return ([both[r * k:(r + 1) * k] for r in range(world)], [both[n + r * k:n + (r + 1) * k] for r in range(world)])
 
     def all_to_all_start(self, send, recv_counts):
         """The payload exchange as an asynchronous collective (RCCL runs it on its own stream, next to whatever the compute
@@ -238,6 +254,13 @@ class LocalComm(Comm):
         recv = [hub.slots[r][self.rank].clone() for r in range(self.world)]
         hub.barrier.wait()
         return recv
+
+    def exchange_counts(self, counts):
+        world, k = counts.shape
+        recv = torch.stack(self.all_to_all([counts[r] for r in range(world)]))
+        both = host(torch.cat([counts.reshape(-1), recv.reshape(-1)]))
+        n = world * k
+        return ([both[r * k:(r + 1) * k] for r in range(world)], [both[n + r * k:n + (r + 1) * k] for r in range(world)])
 
 
 def run_local_ranks(world, fn):
@@ -382,6 +405,17 @@ def _bounds_tensor(decomp, ranks, device):
     return t
 
 
+def _boxes_tensor(decomp, ranks, device):
+    """float32 [len(ranks), 6]: lo x, y, z, hi x, y, z of the blocks of ``ranks`` (the layout dmcf_ghost_count takes)."""
+    t = _bounds_tensor(decomp, ranks, device)
+    cache = decomp.__dict__.setdefault("_boxes_cache", {})
+    key = (tuple(ranks), str(device))
+    b = cache.get(key)
+    if b is None:
+        b = cache[key] = torch.cat([t[:, :, 0], t[:, :, 1]], dim=1).contiguous()
+    return b
+
+
 def _gap2_all(pos, bounds):
     """Squared distances of every pos[i] to every block of ``bounds`` ([P, 3, 2]) -> [P, n]; per pair the arithmetic of _gap2."""
     g = torch.clamp(torch.maximum(bounds[:, None, :, 0] - pos[None], pos[None] - bounds[:, None, :, 1]), min=0.0)
@@ -457,6 +491,71 @@ class GhostPlan:
             self._derive_finish(host(torch.cat(counts)) if counts else [])
         if parent is None or world == 1:
             self._finish_ext(pos_owned)
+
+    @staticmethod
+    def build_fused(comm, decomp, pos_owned, widths):
+        """ALL ghost plans of one owned point set -- its widest and every narrower one the step will ask for -- with two
+        selection kernels per side (dmcf_ghost_count / dmcf_ghost_write, csrc/ghost.hip) and ONE host round trip, instead of
+        ~40 torch calls and two round trips for the widest plan plus ~10 calls per derived one.  Sender: the squared gaps of the
+        owned points to the peers' blocks against all widths at once; the per-width counts travel in one collective together with
+        what the peers announce (Comm.exchange_counts); receiver: the same kernels over the copies it received, against its own
+        block, give the narrower plans' positions inside the widest plan's ghosts.  Lists, orders and ghost sets are those of the
+        host form (wide plan + derived plans): DMCF_SHARD_CHECK=1 compares.  -> {round(width, 9): plan}."""
+        keys = sorted({round(float(w), 9) for w in widths}, reverse=True)
+        dev = pos_owned.device
+        world, rank = comm.world, comm.rank
+        view = getattr(decomp, "view", None)
+        inflate = float(getattr(decomp, "inflate", 1.0))
+        test_pos = view(pos_owned) if view is not None else pos_owned
+        empty = torch.zeros(0, dtype=torch.int64, device=dev)
+        plans = []
+        for w in keys:
+            p = GhostPlan.__new__(GhostPlan)
+            p.comm, p.decomp = comm, decomp
+            p.width = float(w) * (1.0 + 1e-5) + 1e-6
+            p.test_pos = test_pos
+            p.test_width = p.width * inflate
+            p.n_owned = pos_owned.shape[0]
+            p.send_idx = [empty] * world
+            p.recv_counts = [0] * world
+            p.parent = plans[0] if plans else None
+            p.in_parent = None
+            plans.append(p)
+        wide, W = plans[0], len(plans)
+        w2 = [p.test_width * p.test_width for p in plans]
+        peers = decomp.neighbours(rank, wide.test_width)
+        announce = torch.zeros((world, W), dtype=torch.int64, device=dev)
+        sel = None
+        if peers and wide.n_owned:
+            sel = ops.ghost_select(test_pos, _boxes_tensor(decomp, peers, dev), w2)
+            cache = decomp.__dict__.setdefault("_boxes_cache", {})
+            at = cache.get(("peers", tuple(peers), str(dev)))
+            if at is None:
+                at = cache[("peers", tuple(peers), str(dev))] = torch.tensor(peers, dtype=torch.int64, device=dev)
+            announce.index_copy_(0, at, sel.totals.t().contiguous())
+        sent, announced = comm.exchange_counts(announce)  # (the one host round trip)
+        if sel is not None:
+            lists = sel.write([sum(int(sent[r][wi]) for r in peers) for wi in range(W)])
+            for wi, p in enumerate(plans):
+                off = 0
+                for r in peers:
+                    c = int(sent[r][wi])
+                    p.send_idx[r] = lists[wi][off:off + c]
+                    off += c
+        for wi, p in enumerate(plans):
+            p.recv_counts = [int(announced[r][wi]) for r in range(world)]
+        recv = comm.all_to_all([pos_owned[i] for i in wide.send_idx], recv_counts=wide.recv_counts)
+        g = wide.ghost_pos = torch.cat(recv, dim=0)
+        if W > 1:
+            if g.shape[0]:
+                gsel = ops.ghost_select(view(g) if view is not None else g, _boxes_tensor(decomp, [rank], dev), w2)
+                glists = gsel.write([sum(p.recv_counts) for p in plans])
+            for wi, p in enumerate(plans[1:], 1):
+                p.in_parent = glists[wi] if g.shape[0] else empty
+                p.ghost_pos = g[p.in_parent] if g.shape[0] else g
+        for p in plans:
+            p._finish_ext(pos_owned)
+        return dict(zip(keys, plans))
 
     def _finish_ext(self, pos_owned):
         self.pos_ext = torch.cat([pos_owned, self.ghost_pos], dim=0).contiguous() if self.comm.world > 1 else pos_owned
@@ -610,6 +709,7 @@ class ShardedSimulator:
         # transformation (translate / scale / grav_eqvar, pbf_model.py:252-301) -- a copy per simulator, its view is set per step
         self._mdecomp = copy.copy(decomp)
         self._mdecomp.__dict__.pop("_bounds_cache", None)
+        self._mdecomp.__dict__.pop("_boxes_cache", None)
         if m.dens_feats or m.pres_feats or m.dens_norm or m.use_pre_adv or m.use_feats:
             raise NotImplementedError("dens_feats / pres_feats / dens_norm / use_pre_adv / use_feats in the sharded path")
         if not m.use_bnds and type(m).__name__ == "SymNet":
@@ -624,6 +724,9 @@ class ShardedSimulator:
         (built when the set is registered, at the largest radius of the network)."""
         key = (name, round(float(width), 9))
         plan = self._plans.get(key)
+        if plan is not None and key in getattr(self, "_unregistered", ()):
+            self._unregistered.discard(key)
+            self._register_lattice(name, plan)
         if plan is None:
             wide = self._wide[name]
             if float(width) * (1.0 + 1e-5) + 1e-6 > wide.width:
@@ -642,6 +745,27 @@ class ShardedSimulator:
         """Register an owned point set and build its widest ghost plan (the only one that communicates)."""
         self._sets[name] = pos
         self._name_of[id(pos)] = name
+        fused = os.environ.get("DMCF_SHARD_FUSED", "1")  # "0": the host form below; "force": also for CPU tensors (tests/shims.py)
+        if self.comm.world > 1 and (fused == "force" or (fused != "0" and pos.is_cuda)):
+            # every width the step will ask this set for is configuration: the layers' radii and, for the particles, the halos
+            # the lattices are built from -- all plans at once (GhostPlan.build_fused)
+            m = self.model
+            widths = [float(width)] + [float(np.float32(r)) for r in m.particle_radii
+                                       if float(r) * (1.0 + 1e-5) + 1e-6 <= float(width) * (1.0 + 1e-5) + 1e-6]
+            if name == "s0":
+                widths += [self._lattice_margin(st) for st in m.strides if st != 1]
+            plans = GhostPlan.build_fused(self.comm, self._mdecomp, pos, widths)
+            wide = plans[round(float(width), 9)]
+            for w, plan in plans.items():
+                self._plans[(name, w)] = plan
+                if os.environ.get("DMCF_SHARD_CHECK") == "1":
+                    direct = GhostPlan(self.comm, self._mdecomp, pos, w)
+                    if not torch.equal(direct.ghost_pos, plan.ghost_pos) or any(
+                            not torch.equal(a, b) for a, b in zip(direct.send_idx, plan.send_idx)):
+                        raise RuntimeError("a fused ghost plan differs from the directly built one")
+            self._wide[name] = wide
+            self._unregistered = getattr(self, "_unregistered", set()) | {(name, w) for w, q in plans.items() if q is not wide}
+            return wide
         wide = GhostPlan(self.comm, self._mdecomp, pos, width)
         self._wide[name] = wide
         self._plans[(name, round(float(width), 9))] = wide
@@ -741,6 +865,7 @@ class ShardedSimulator:
         re-stated here."""
         m, comm = self.model, self.comm
         self._plans, self._sets, self._lattices, self._wide, self._name_of, self._shared, self._pending = {}, {}, {}, {}, {}, {}, {}
+        self._unregistered = set()
         pos0, vel0, acc = state["pos"], state["vel"], state.get("acc")
         gid = state["gid"]
         box_all, bfeats_all = state["box"], state["box_normals"]

@@ -322,6 +322,26 @@ int dmcf_points_aabb(const float* points, int64_t n, float* out, void* workspace
                      dmcf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Ghost selection of the block-sharded rollout (no reference counterpart: tum-pbs/DMCF has no distributed code -- SURVEY.md
+ * section 8e; the caller is dmcf_amd/parallel.py): which points lie within a halo width of which axis-aligned block, for
+ * several widths at once.
+ *   level(i, b) = number of w with gap2(points[i], boxes[b]) <= widths2[w]     (widths2: HOST array, DESCENDING, <= 8 entries)
+ *   list(w)     = for b = 0 .. n_boxes - 1 (<= 64): the i with level(i, b) > w, in ascending i
+ * gap2 = squared Euclidean distance to the box, per axis max(lo - x, x - hi, 0), un-fused float32; boxes [n_boxes][6] =
+ * lo x, y, z, hi x, y, z on the DEVICE, +-inf on open sides.
+ *   count : totals[w * n_boxes + b] = entries box b contributes to list(w) (DEVICE int64)
+ *   write : list(w) -> rows[list_start[w] ..) (DEVICE int64 point indices), at most list_capacity[w] entries (HOST arrays); must
+ *           follow a count with the same arguments and the same workspace.
+ * Workspace: dmcf_ghost_workspace_bytes(n, n_boxes, n_widths).
+ * ---------------------------------------------------------------------------------------------- */
+size_t dmcf_ghost_workspace_bytes(int64_t n, int32_t n_boxes, int32_t n_widths);
+int dmcf_ghost_count(const float* points, int64_t n, const float* boxes, int32_t n_boxes, const float* widths2, int32_t n_widths,
+                     int64_t* totals, void* workspace, size_t workspace_bytes, dmcf_stream_t stream);
+int dmcf_ghost_write(const float* points, int64_t n, const float* boxes, int32_t n_boxes, const float* widths2, int32_t n_widths,
+                     int64_t* rows, const int64_t* list_start, const int64_t* list_capacity, void* workspace, size_t workspace_bytes,
+                     dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * grid_pos(pos, voxel_size, centralize, pad, hyst) (utils/tools/losses.py:136-181; the coarse point sets of the
  * multi-scale models, called through get_dilated_pos :249-284): the corners of every voxel a particle touches
  * (with +-hyst hysteresis), de-duplicated in tf.unique order (first appearance in the candidate list), decoded to

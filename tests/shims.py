@@ -67,6 +67,18 @@ def install(monkeypatch):
     def gather_point(inp, idx):
         return inp[:, idx[0].long()]
 
+    class GhostSelection:  # ops.ghost_select in torch (what csrc/ghost.hip is tested against on the GPU)
+        def __init__(self, pos, boxes, widths2):
+            from dmcf_amd import parallel
+            gap2 = parallel._gap2_all(pos, torch.stack([boxes[:, :3], boxes[:, 3:]], dim=2))
+            self.hits = [torch.nonzero(gap2 <= float(np.float32(v))) for v in widths2]
+            self.totals = torch.stack([torch.bincount(h[:, 0], minlength=boxes.shape[0]) for h in self.hits])
+
+        def write(self, sizes):
+            assert [int(v) for v in sizes] == [int(h.shape[0]) for h in self.hits]
+            return [h[:, 1].contiguous() for h in self.hits]
+
+    monkeypatch.setattr(ops, "ghost_select", lambda pos, boxes, widths2: GhostSelection(pos, boxes.reshape(-1, 6), widths2))
     monkeypatch.setattr(ops, "farthest_point_sample", farthest_point_sample)
     monkeypatch.setattr(ops, "gather_point", gather_point)
     monkeypatch.setattr(ops, "window_sum", window_sum)

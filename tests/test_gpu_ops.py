@@ -1215,3 +1215,28 @@ def test_reserve_device_memory(dev):
     # (d) more than the device has
     assert ops.reserve_device_memory(1 << 20, dev) == -1.0  # a million GiB
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("n,n_boxes", [(1, 1), (777, 3), (50000, 7)])
+def test_ghost_select_equals_the_host_form(n, n_boxes):
+    """dmcf_ghost_count / dmcf_ghost_write against the torch form the sharded rollout used for every ghost plan
+    (parallel._gap2_all + nonzero): the same lists, box-major then ascending point index, for all widths at once."""
+    from dmcf_amd import ops, parallel
+    g = torch.Generator().manual_seed(n + n_boxes)
+    pos = (torch.rand(n, 3, generator=g) * 4 - 2).cuda()
+    lo = torch.rand(n_boxes, 3, generator=g) * 2 - 2
+    hi = lo + torch.rand(n_boxes, 3, generator=g) * 2
+    lo[0, 0], hi[-1, 2] = -float("inf"), float("inf")  # open sides, as the outer blocks of a decomposition have
+    boxes = torch.cat([lo, hi], dim=1).cuda()
+    widths = [1.5, 0.4, 0.4 * (1 - 1e-7), 0.05, 0.0]
+    w2 = [w * w for w in widths]
+    sel = ops.ghost_select(pos, boxes, w2)
+    gap2 = parallel._gap2_all(pos, torch.stack([boxes[:, :3], boxes[:, 3:]], dim=2))  # [B, n]
+    want = [torch.nonzero(gap2 <= v) for v in w2]
+    totals = sel.totals.cpu()
+    for wi, hit in enumerate(want):
+        assert torch.equal(totals[wi], torch.bincount(hit[:, 0], minlength=n_boxes).cpu())
+    lists = sel.write([int(h.shape[0]) for h in want])
+    for wi, hit in enumerate(want):
+        assert torch.equal(lists[wi], hit[:, 1]), wi
+    assert n < 100 or (0 < want[3].shape[0] < want[0].shape[0])

@@ -26,7 +26,7 @@ def _run_rank(comm, decomp, scene, steps, dev):
         state = sim.step(state)
         outs.append(sim.net_output.double().sum(0))
     return dict(gid=state["gid"].cpu().numpy(), pos=state["pos"].cpu().numpy(), vel=state["vel"].cpu().numpy(),
-                exchanged=sim.exchanged_rows, out_sum=torch.stack(outs).cpu().numpy(),
+                exchanged=sim.exchanged_rows, out_sum=torch.stack(outs).cpu().numpy(), host_syncs=sim.host_syncs_last_step,
                 out_abs=float(sim.net_output.double().abs().sum()))
 
 
@@ -92,6 +92,28 @@ def test_virtual_block_ranks_match_single_rank_on_gpu(grid, monkeypatch):
     _check(res, ref, n)
     ghosts = sum(p["exchanged"] for p in res)
     print(f"grid {grid}: {ghosts} ghost feature rows exchanged in 3 steps for {n} particles")
+
+
+def test_fused_ghost_selection_gives_the_plans_of_the_host_form(monkeypatch):
+    """The ghost plans of a step from csrc/ghost.hip (one count + one write per side and point set, all widths at once, the
+    counts in one collective) against the torch form (wide plan + derived plans): the same particles to the bit, and fewer
+    device -> host reads per step."""
+    from dmcf_amd import parallel
+    from tools import scenes
+    dev = torch.device("cuda:0")
+    grid = [2, 2, 1]
+    parts = [scenes.box_block_scene(12, grid, r, seed=5) for r in range(4)]
+    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [g * 12 * 0.05 for g in grid], grid)
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("DMCF_SHARD_FUSED", fused)
+        res[fused] = parallel.run_local_ranks(4, lambda c: _run_rank(c, decomp, scene, 3, dev))
+    for a, b in zip(res["1"], res["0"]):
+        assert np.array_equal(a["gid"], b["gid"]) and np.array_equal(a["pos"], b["pos"]) and np.array_equal(a["vel"], b["vel"])
+        assert a["exchanged"] == b["exchanged"]
+        assert a["host_syncs"] < b["host_syncs"], (a["host_syncs"], b["host_syncs"])
+    print("host reads per step, fused / host form:", res["1"][0]["host_syncs"], res["0"][0]["host_syncs"])
 
 
 def _proc_worker(rank, world, port, out_dir):

@@ -119,6 +119,18 @@ def test_virtual_block_ranks_equal_single_rank(monkeypatch, grid):
     assert {p["host_syncs"] for p in plain} == {13}, [p["host_syncs"] for p in plain]
     for a, b in zip(parts, plain):
         assert np.array_equal(a["pos"], b["pos"])
+    # The fused form (what a GPU step takes, csrc/ghost.hip; here with the torch stand-in of tests/shims.py): all plans of a
+    # point set at once, their counts in ONE read per set -- 1 migration + 5 sets + 1 lattice centre + 1 agreement = 8 --
+    # and the same particles to the bit
+    monkeypatch.setenv("DMCF_SHARD_FUSED", "force")
+    fused = parallel.run_local_ranks(decomp.world, lambda comm: _run_rank(comm, decomp, scene, 2))
+    assert {p["host_syncs"] for p in fused} == {8}, [p["host_syncs"] for p in fused]
+    for a, b in zip(fused, plain):
+        assert np.array_equal(a["pos"], b["pos"]) and a["launch_rows"] == b["launch_rows"] and a["exchanged"] == b["exchanged"]
+    monkeypatch.setenv("DMCF_SHARD_CHECK", "1")
+    parallel.run_local_ranks(decomp.world, lambda comm: _run_rank(comm, decomp, scene, 1))
+    monkeypatch.delenv("DMCF_SHARD_CHECK")
+    monkeypatch.delenv("DMCF_SHARD_FUSED")
     # ... and every launch reads the ghosts within ITS OWN radius, not the widest plan's (item 6c): the R = 0.1 layers of the
     # all-points set take fewer input rows than the widest plan holds
     for p in parts:
@@ -207,7 +219,9 @@ def test_single_rank_runner_equals_plain_model(monkeypatch):
     _close(part["pos"][order], pos.numpy())
 
 
-def _gloo_worker(rank, world, port, scene, steps, out_dir):
+def _gloo_worker(rank, world, port, scene, steps, out_dir, fused):
+    os.environ["DMCF_SHARD_FUSED"] = fused
+    os.environ["DMCF_SHARD_CHECK"] = "1"
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
@@ -228,15 +242,17 @@ def _gloo_worker(rank, world, port, scene, steps, out_dir):
         dist.destroy_process_group()
 
 
-def test_gloo_world2_equals_single_rank(monkeypatch, tmp_path):
-    """Two real processes over torch.distributed (gloo) -- the production communicator class."""
+@pytest.mark.parametrize("fused", ["0", "force"])
+def test_gloo_world2_equals_single_rank(monkeypatch, tmp_path, fused):
+    """Two real processes over torch.distributed (gloo) -- the production communicator class; with the ghost plans of the host
+    form and with the fused form's one-collective count exchange (TorchDistComm.exchange_counts)."""
     import torch.multiprocessing as mp
     import shims
     from dmcf_amd import parallel
     scene = _scene()
     n = scene["pos"].shape[0]
     port = 29500 + os.getpid() % 2000
-    mp.spawn(_gloo_worker, args=(2, port, scene, 2, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_gloo_worker, args=(2, port, scene, 2, str(tmp_path), fused), nprocs=2, join=True)
     parts = [dict(np.load(os.path.join(tmp_path, f"rank{r}.npz"))) for r in range(2)]
     pos, vel = _assemble(parts, n)
     shims.install(monkeypatch)
