@@ -15,6 +15,10 @@
 // gap2 is evaluated by this code on both sides, on bit-identical coordinates: sender and receiver decide identically.
 //
 // Two phases because the sizes are data: count -> (the caller reads the totals, or knows them from the peers) -> write.
+//
+// OWNERSHIP is the same selection with another test (one "width", widths2[0] < 0): level(i, b) = 1 when lo <= x < hi on every axis
+// -- BlockDecomposition.owner's half-open blocks -- so list(0) is the stable order by owner and totals[0] the rows per owner: the
+// migration of a step without its stable sort (one block sort + ~10 merge passes over all particles).
 #include "common.h"
 
 namespace dmcf {
@@ -43,7 +47,10 @@ __device__ __forceinline__ float ghost_gap2(float x, float y, float z, const flo
     return __fadd_rn(__fadd_rn(__fmul_rn(gx, gx), __fmul_rn(gy, gy)), __fmul_rn(gz, gz));
 }
 
-__device__ __forceinline__ int ghost_level(float g2, const GhostParams& p) {
+__device__ __forceinline__ int ghost_level(float x, float y, float z, const float* b, const GhostParams& p) {
+    if (p.w2[0] < 0.0f)  // ownership (a NaN or infinite coordinate has no owner: the caller compares the totals with n)
+        return (x >= b[0] && x < b[3] && y >= b[1] && y < b[4] && z >= b[2] && z < b[5]) ? 1 : 0;
+    const float g2 = ghost_gap2(x, y, z, b);
     int lv = 0;
 #pragma unroll
     for (int w = 0; w < kGhostMaxWidths; ++w)
@@ -61,7 +68,7 @@ __global__ __launch_bounds__(kGhostThreads) void ghost_count(const GhostParams p
     if (i < p.n) {
         const float x = p.pos[3 * i], y = p.pos[3 * i + 1], z = p.pos[3 * i + 2];
         for (int b = 0; b < p.B; ++b) {
-            const int lv = ghost_level(ghost_gap2(x, y, z, box + 6 * b), p);
+            const int lv = ghost_level(x, y, z, box + 6 * b, p);
             for (int w = 0; w < lv; ++w) atomicAdd(&cnt[b * p.W + w], 1u);
         }
     }
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(kGhostThreads) void ghost_write(const GhostParams p
         z = p.pos[3 * i + 2];
     }
     for (int b = 0; b < p.B; ++b) {
-        const int lv = i < p.n ? ghost_level(ghost_gap2(x, y, z, box + 6 * b), p) : 0;
+        const int lv = i < p.n ? ghost_level(x, y, z, box + 6 * b, p) : 0;
         // stable rank inside the workgroup, per width: lanes below in the wave + the waves below
         uint32_t below[kGhostMaxWidths];
 #pragma unroll
@@ -159,6 +166,7 @@ static bool ghost_params(GhostParams& p, const float* pos, int64_t n, const floa
     if (n > 0 && !pos) return false;
     for (int w = 0; w + 1 < n_widths; ++w)
         if (!(widths2[w] >= widths2[w + 1])) return false;  // descending: list(w + 1) is a subset of list(w)
+    if (!(widths2[n_widths - 1] >= 0.0f) && n_widths != 1) return false;  // (negative: ownership, alone)
     p.pos = pos;
     p.n = n;
     p.boxes = boxes;

@@ -940,7 +940,8 @@ class GhostSelection:
 
 def ghost_select(pos, boxes, widths2):
     """dmcf_ghost_count: for every point of ``pos`` [n, 3] and every box of ``boxes`` [B, 6] (lo xyz, hi xyz; device float32) the
-    number of ``widths2`` (host floats, DESCENDING) its squared distance to the box does not exceed.  Returns a
+    number of ``widths2`` (host floats, DESCENDING) its squared distance to the box does not exceed.  ``widths2`` = [-1.0] selects
+    OWNERSHIP instead (lo <= x < hi per axis): one list, the stable order of the points by owning box.  Returns a
     :class:`GhostSelection`."""
     L = _lib.lib()
     pos = _dev_f32(pos, "pos", 3)

@@ -255,9 +255,31 @@ class LocalComm(Comm):
         hub.barrier.wait()
         return recv
 
+    # (the two exchanges a step repeats stand in for ONE collective each: one gathering copy, not a copy per peer -- the
+    # dispatch counts of profiles/*virtual_rank_kernel_time.md are read as those of the RCCL path)
+    def exchange_rows_start(self, rows, send_counts, recv_counts):
+        hub = self.hub
+        starts = [0]
+        for c in send_counts:
+            starts.append(starts[-1] + int(c))
+        hub.slots[self.rank] = (rows, starts)
+        hub.barrier.wait()
+        parts = []
+        for r in range(self.world):
+            src, st = hub.slots[r]
+            if st[self.rank + 1] > st[self.rank]:
+                parts.append(src[st[self.rank]:st[self.rank + 1]])
+        out = torch.cat(parts, dim=0) if parts else rows[:0].clone()
+        hub.barrier.wait()
+        return lambda: out
+
     def exchange_counts(self, counts):
         world, k = counts.shape
-        recv = torch.stack(self.all_to_all([counts[r] for r in range(world)]))
+        hub = self.hub
+        hub.slots[self.rank] = counts
+        hub.barrier.wait()
+        recv = torch.stack([hub.slots[r][self.rank] for r in range(world)])
+        hub.barrier.wait()
         both = host(torch.cat([counts.reshape(-1), recv.reshape(-1)]))
         n = world * k
         return ([both[r * k:(r + 1) * k] for r in range(world)], [both[n + r * k:n + (r + 1) * k] for r in range(world)])
@@ -335,7 +357,10 @@ class BlockDecomposition:
         own = torch.zeros(pos.shape[0], dtype=torch.int64, device=pos.device)
         for k in range(3):
             if self.grid[k] > 1:
-                b = torch.tensor(self.cuts[k], dtype=pos.dtype, device=pos.device)
+                cache = self.__dict__.setdefault("_cuts_cache", {})
+                b = cache.get((k, pos.dtype, str(pos.device)))
+                if b is None:  # (a tensor from Python numbers is a blocking host -> device copy)
+                    b = cache[(k, pos.dtype, str(pos.device))] = torch.tensor(self.cuts[k], dtype=pos.dtype, device=pos.device)
                 i = torch.bucketize(pos[:, k].contiguous(), b, right=True)
             else:
                 i = 0
@@ -878,10 +903,21 @@ class ShardedSimulator:
         self.migrated_rows = 0
         if comm.world > 1:
             adv, _ = m.integrate_pos_vel(pos0, vel0, acc)
-            own = self.decomp.owner(adv)
             payload = torch.cat([pos0, vel0] + ([acc] if acc is not None else []), dim=1)
-            order = torch.argsort(own, stable=True)
-            counts = host(torch.bincount(own, minlength=comm.world))
+            fused = os.environ.get("DMCF_SHARD_FUSED", "1")
+            if fused == "force" or (fused != "0" and adv.is_cuda):
+                # the selection kernels with the ownership test (csrc/ghost.hip): rows per owner and the stable order by owner
+                sel = ops.ghost_select(adv, _boxes_tensor(self.decomp, list(range(comm.world)), adv.device), [-1.0])
+                counts = host(sel.totals[0])
+                if int(sum(counts)) != adv.shape[0]:
+                    raise RuntimeError(f"{adv.shape[0] - int(sum(counts))} particles with a non-finite position: no rank owns them")
+                order = sel.write([adv.shape[0]])[0]
+                if os.environ.get("DMCF_SHARD_CHECK") == "1":
+                    assert torch.equal(order, torch.argsort(self.decomp.owner(adv), stable=True))
+            else:
+                own = self.decomp.owner(adv)
+                order = torch.argsort(own, stable=True)
+                counts = host(torch.bincount(own, minlength=comm.world))
             self.migrated_rows = int(sum(counts)) - int(counts[comm.rank])
             self.migrated_rows_total += self.migrated_rows
             recv = comm.all_to_all(list(torch.split(payload[order], counts, dim=0)))

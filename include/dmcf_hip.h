@@ -332,6 +332,9 @@ int dmcf_points_aabb(const float* points, int64_t n, float* out, void* workspace
  *   count : totals[w * n_boxes + b] = entries box b contributes to list(w) (DEVICE int64)
  *   write : list(w) -> rows[list_start[w] ..) (DEVICE int64 point indices), at most list_capacity[w] entries (HOST arrays); must
  *           follow a count with the same arguments and the same workspace.
+ * OWNERSHIP: n_widths == 1 with widths2[0] < 0 replaces the test by "lo <= x < hi on every axis" (half-open blocks: a point has one
+ * owner); list(0) is then the stable order of the points by owning box and totals[b] the points box b owns.  A NaN or infinite
+ * coordinate is in no box: the totals then sum to less than n.
  * Workspace: dmcf_ghost_workspace_bytes(n, n_boxes, n_widths).
  * ---------------------------------------------------------------------------------------------- */
 size_t dmcf_ghost_workspace_bytes(int64_t n, int32_t n_boxes, int32_t n_widths);

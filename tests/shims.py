@@ -70,8 +70,12 @@ def install(monkeypatch):
     class GhostSelection:  # ops.ghost_select in torch (what csrc/ghost.hip is tested against on the GPU)
         def __init__(self, pos, boxes, widths2):
             from dmcf_amd import parallel
-            gap2 = parallel._gap2_all(pos, torch.stack([boxes[:, :3], boxes[:, 3:]], dim=2))
-            self.hits = [torch.nonzero(gap2 <= float(np.float32(v))) for v in widths2]
+            if widths2[0] < 0:  # ownership
+                inside = ((pos[None] >= boxes[:, None, :3]) & (pos[None] < boxes[:, None, 3:])).all(dim=2)
+                self.hits = [torch.nonzero(inside)]
+            else:
+                gap2 = parallel._gap2_all(pos, torch.stack([boxes[:, :3], boxes[:, 3:]], dim=2))
+                self.hits = [torch.nonzero(gap2 <= float(np.float32(v))) for v in widths2]
             self.totals = torch.stack([torch.bincount(h[:, 0], minlength=boxes.shape[0]) for h in self.hits])
 
         def write(self, sizes):

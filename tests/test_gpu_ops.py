@@ -1240,3 +1240,22 @@ def test_ghost_select_equals_the_host_form(n, n_boxes):
     for wi, hit in enumerate(want):
         assert torch.equal(lists[wi], hit[:, 1]), wi
     assert n < 100 or (0 < want[3].shape[0] < want[0].shape[0])
+
+
+def test_ghost_select_ownership_is_the_stable_order_by_owner():
+    """widths2 = [-1]: the half-open block test of BlockDecomposition.owner -- rows per owner and the stable argsort by owner
+    (what a sharded step's migration needs), points exactly on a cut plane included."""
+    from dmcf_amd import ops, parallel
+    decomp = parallel.BlockDecomposition.uniform([0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [2, 2, 2])
+    g = torch.Generator().manual_seed(3)
+    pos = torch.rand(100001, 3, generator=g) * 1.4 - 0.2
+    pos[::7, 0] = 0.5
+    pos[::11, 2] = 0.5
+    pos = pos.cuda()
+    boxes = parallel._boxes_tensor(decomp, list(range(8)), pos.device)
+    sel = ops.ghost_select(pos, boxes, [-1.0])
+    own = decomp.owner(pos)
+    assert torch.equal(sel.totals[0], torch.bincount(own, minlength=8))
+    assert torch.equal(sel.write([pos.shape[0]])[0], torch.argsort(own, stable=True))
+    pos[5, 1] = float("nan")
+    assert int(ops.ghost_select(pos, boxes, [-1.0]).totals.sum()) == pos.shape[0] - 1

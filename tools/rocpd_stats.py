@@ -3,7 +3,7 @@ import sqlite3
 import sys
 
 
-def main(path, out=None):
+def main(path, out=None, by_calls=None):
     db = sqlite3.connect(path)
     tables = [r[0] for r in db.execute("select name from sqlite_master where type='table'")]
     kd = next(t for t in tables if t.startswith("rocpd_kernel_dispatch"))
@@ -21,10 +21,14 @@ def main(path, out=None):
         lines.append(f"| `{short}` | {calls} | {tot / 1e6:.3f} | {avg / 1e3:.1f} | {mn / 1e3:.1f} | {mx / 1e3:.1f} | {100 * tot / total:.1f} |")
     lines.append(f"\ntotal kernel time {total / 1e6:.2f} ms over {sum(r[1] for r in rows)} dispatches ({len(rows)} distinct kernels)")
     text = "\n".join(lines)
+    if by_calls:  # every kernel, most launched first: where a step's dispatches are
+        with open(by_calls, "w") as f:
+            for name, calls, tot, avg, mn, mx in sorted(rows, key=lambda r: -r[1]):
+                f.write(f"{calls:7d} {tot / 1e6:10.3f} ms  {name[:160]}\n")
     if out:
         open(out, "w").write(text + "\n")
     print(text)
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None, sys.argv[3] if len(sys.argv) > 3 else None)
