@@ -10,7 +10,9 @@
 // per-pair geometry: a 3-D convolution.  The caller lays the input features out by lattice cell (a dense volume over the
 // input lattice's bounding box, zeros in empty cells), so the operand rows of a tile are contiguous memory:
 //   lat_build_filters   one thread per element of the per-offset matrices, packed in MFMA B-fragment order
-//   lat_conv_kernel     tile = 16 consecutive output cells along x (M of v_mfma_f32_16x16x4_f32), N = 16 output channels,
+//   lat_rows_*          the launch's output points in lattice order, compacted: (volume offset of the cell, output row) pairs
+//   lat_conv_kernel     tile = 16 consecutive ROWS of that list (M of v_mfma_f32_16x16x4_f32; in a filled region these are
+//                       16 consecutive cells along x, which is what the tile was until round 5), N = 16 output channels,
 //                       K = 4 stencil offsets of one input channel.  Per 4 offsets and tile one 16-byte load per lane and
 //                       4 input channels (the stencil slides along x: the rows are re-read from L1); the per-offset
 //                       matrices are staged through LDS in chunks and shared by the 4 waves x 2 tiles of a workgroup.  A
@@ -38,6 +40,103 @@ struct LatParams {
     float* out;
     int flags;
 };
+
+// The output rows of a launch (or of the parts of a batch), compacted.  Until round 5 a tile was 16 consecutive CELLS of the launch's
+// box: a box stretched by stray points (particles that left the scene carry lattice points with them) is mostly tiles with one point
+// or none, each walking the whole stencil -- the four lattice layers of the 1M box went 2.6 -> 9.9 ms per step over 20 steps while
+// their outputs grew by 30 %.  Now: count the occupied cells per 1024-cell block of the box, scan, write (offset, row) pairs in cell
+// order; the convolution walks tiles of 16 consecutive pairs, whatever cells they come from.
+typedef int lat_i32x2 __attribute__((ext_vector_type(2)));
+constexpr int kLatMaxParts = 8;
+constexpr int kLatRowsPerGroup = 128;  // rows of one workgroup (4 waves x kLatTW tiles x 16): a part's rows start at a multiple
+constexpr int kLatCellsPerBlock = 1024;
+struct LatBatch {
+    LatParams part[kLatMaxParts];
+    int64_t cfirst[kLatMaxParts + 1];  // first cell block of each part (lat_rows_count / _write)
+    int n;
+    uint32_t* blk;          // [cfirst[n] + 1]: occupied cells per block, then their exclusive scan
+    int64_t* start;         // [n + 1] (device): first row of each part in `rows`, a multiple of kLatRowsPerGroup
+    int64_t* count;         // [n] (device): rows of each part
+    lat_i32x2* rows;        // (byte offset of the row's cell in the volume at stencil offset 0, output row)
+    int64_t rows_capacity;
+};
+
+// cell c of a part's box (16-cell runs along x, then y, then z): its output row (or -1) and the volume offset of its cell
+__device__ __forceinline__ int lat_cell(const LatParams& p, int64_t c, int& rowb) {
+    const int64_t tile = c >> 4;
+    const int m = (int)(c & 15);
+    rowb = 0;
+    if (tile >= p.ntiles) return -1;
+    const int xb = (int)(tile % p.tiles_x);
+    const int ax = p.amin[0] + xb * 16 + m, ay = p.amin[1] + (int)(tile / p.tiles_x % p.adim[1]),
+              az = p.amin[2] + (int)(tile / ((int64_t)p.tiles_x * p.adim[1]));
+    const int ox = ax * p.out_stride + p.phase[0] - p.omin[0], oy = ay * p.out_stride + p.phase[1] - p.omin[1],
+              oz = az * p.out_stride + p.phase[2] - p.omin[2];
+    if (!(xb * 16 + m < p.adim[0] && (unsigned)ox < (unsigned)p.odim[0] && (unsigned)oy < (unsigned)p.odim[1] &&
+          (unsigned)oz < (unsigned)p.odim[2]))
+        return -1;
+    const int ix = ax * p.inp_step - p.imin[0], iy = ay * p.inp_step - p.imin[1], iz = az * p.inp_step - p.imin[2];
+    rowb = ((iz * p.idim[1] + iy) * p.idim[0] + ix) * p.cin * 4;
+    return p.otab[((int64_t)oz * p.odim[1] + oy) * p.odim[0] + ox];
+}
+
+__device__ __forceinline__ int lat_part_of_block(const LatBatch& b, int64_t block) {
+    int i = 0;
+    while (i + 1 < b.n && block >= b.cfirst[i + 1]) ++i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void lat_rows_count(const LatBatch b) {
+    __shared__ uint32_t wsum[4];
+    const int i = lat_part_of_block(b, blockIdx.x);
+    const int64_t c0 = ((int64_t)blockIdx.x - b.cfirst[i]) * kLatCellsPerBlock;
+    uint32_t mine = 0;
+    for (int r = 0; r < kLatCellsPerBlock / 256; ++r) {
+        int rowb;
+        mine += (uint32_t)__popcll(__ballot(lat_cell(b.part[i], c0 + r * 256 + threadIdx.x, rowb) >= 0));
+    }
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;  // (every lane of a wave holds the wave's count)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        b.blk[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (blockIdx.x == 0) b.blk[b.cfirst[b.n]] = 0;  // the scan's last entry = the total
+    }
+}
+
+// (after the exclusive scan of blk) where each part's rows begin, and how many it has
+__global__ void lat_rows_starts(const LatBatch b) {
+    if (threadIdx.x != 0) return;
+    int64_t s = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const int64_t n = (int64_t)b.blk[b.cfirst[i + 1]] - (int64_t)b.blk[b.cfirst[i]];
+        b.start[i] = s;
+        b.count[i] = n;
+        s += (n + kLatRowsPerGroup - 1) / kLatRowsPerGroup * kLatRowsPerGroup;
+    }
+    b.start[b.n] = s;
+}
+
+__global__ __launch_bounds__(256) void lat_rows_write(const LatBatch b) {
+    __shared__ uint32_t wsum[4];
+    const int i = lat_part_of_block(b, blockIdx.x);
+    const int64_t c0 = ((int64_t)blockIdx.x - b.cfirst[i]) * kLatCellsPerBlock;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int64_t at = b.start[i] + ((int64_t)b.blk[blockIdx.x] - (int64_t)b.blk[b.cfirst[i]]);
+    for (int r = 0; r < kLatCellsPerBlock / 256; ++r) {
+        int rowb;
+        const int oi = lat_cell(b.part[i], c0 + r * 256 + threadIdx.x, rowb);
+        const uint64_t mk = __ballot(oi >= 0);
+        if (lane == 0) wsum[wave] = (uint32_t)__popcll(mk);
+        __syncthreads();
+        if (oi >= 0) {
+            int64_t pos = at + __popcll(mk & ((1ull << lane) - 1ull));
+            for (int v = 0; v < wave; ++v) pos += wsum[v];
+            if (pos < b.rows_capacity) b.rows[pos] = (lat_i32x2){rowb, oi};
+        }
+        at += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+}
 
 __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict__ W, float* __restrict__ Wp,
                                                          const int32_t* __restrict__ stencil, int S, int KS, int NT, CconvParams p,
@@ -80,6 +179,7 @@ __global__ __launch_bounds__(256) void lat_build_filters(const float* __restrict
 constexpr int kLatTW = 2;   // 16-cell tiles per wave
 constexpr int kLatCH = 32;  // stencil offsets per LDS chunk of the per-offset matrices
 constexpr int kLatG = kLatCH / 4;
+static_assert(kLatRowsPerGroup == 4 * kLatTW * 16, "rows of a workgroup");
 
 // Workgroup = 4 waves x kLatTW tiles.  Every wave walks the whole stencil for its own tiles (no cross-wave reduction); the
 // per-offset matrices are staged through LDS in chunks of kLatCH offsets and shared by the waves.
@@ -89,42 +189,33 @@ constexpr int kLatG = kLatCH / 4;
 // load per lane, tile and offset -- four times the load instructions for the same bytes, and the coarse -> fine layer ran at
 // 4x its matrix time, bound by the rate of the address unit.)
 template <int NTT, int KST>
-__device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t group) {
+__device__ __forceinline__ void lat_conv_body(const LatParams& p, const lat_i32x2* __restrict__ rows, const int64_t first, const int64_t end) {
     __shared__ __attribute__((aligned(16))) float Ws[2][kLatCH * KST * NTT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int m = lane & 15, q = lane >> 4;
     constexpr int C = 4 * KST;
     int oidx[kLatTW];       // output point of this lane's row (lanes of one row agree), -1: none, -2: tile without points
-    int rowb[kLatTW];       // byte offset of (z, y, x = this row) in the volume for offset (0, 0, 0)
-    int ix[kLatTW], iy[kLatTW], iz[kLatTW];
+    int rowb[kLatTW];       // byte offset of the row's cell in the volume for offset (0, 0, 0)
     f32x4 acc[kLatTW][NTT];
     bool any = false;
 #pragma unroll
     for (int t = 0; t < kLatTW; ++t) {
-        const int64_t tile = (group * 4 + wave) * kLatTW + t;
+        const int64_t e = first + ((wave * kLatTW + t) << 4) + m;
         oidx[t] = -1;
-        ix[t] = p.amin[0] * p.inp_step - p.imin[0];  // (tiles past the end read the first tile's cells and write nothing)
-        iy[t] = p.amin[1] * p.inp_step - p.imin[1];
-        iz[t] = p.amin[2] * p.inp_step - p.imin[2];
-        if (tile < p.ntiles) {
-            const int xb = (int)(tile % p.tiles_x);
-            const int ax = p.amin[0] + xb * 16 + m, ay = p.amin[1] + (int)(tile / p.tiles_x % p.adim[1]),
-                      az = p.amin[2] + (int)(tile / ((int64_t)p.tiles_x * p.adim[1]));
-            const int ox = ax * p.out_stride + p.phase[0] - p.omin[0], oy = ay * p.out_stride + p.phase[1] - p.omin[1],
-                      oz = az * p.out_stride + p.phase[2] - p.omin[2];
-            if (xb * 16 + m < p.adim[0] && (unsigned)ox < (unsigned)p.odim[0] && (unsigned)oy < (unsigned)p.odim[1] &&
-                (unsigned)oz < (unsigned)p.odim[2])
-                oidx[t] = p.otab[((int64_t)oz * p.odim[1] + oy) * p.odim[0] + ox];
-            ix[t] = ax * p.inp_step - p.imin[0];
-            iy[t] = ay * p.inp_step - p.imin[1];  // wave uniform per tile
-            iz[t] = az * p.inp_step - p.imin[2];
+        // (rows past the end read the cells of the launch's first cell and write nothing)
+        rowb[t] = (((p.amin[2] * p.inp_step - p.imin[2]) * p.idim[1] + (p.amin[1] * p.inp_step - p.imin[1])) * p.idim[0] +
+                   (p.amin[0] * p.inp_step - p.imin[0])) * p.cin * 4;
+        if (e < end) {
+            const lat_i32x2 rw = rows[e];
+            rowb[t] = rw.x;
+            oidx[t] = rw.y;
         }
-        rowb[t] = ((iz[t] * p.idim[1] + iy[t]) * p.idim[0] + ix[t]) * p.cin * 4;
         if (__ballot(oidx[t] >= 0) == 0) oidx[t] = -2;  // nothing to compute in this tile (the whole wave agrees)
         any |= oidx[t] != -2;
 #pragma unroll
         for (int n = 0; n < NTT; ++n) acc[t][n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
     }
+    if (!__syncthreads_or(any ? 1 : 0)) return;  // (the padding at the end of the launch)
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     const int NG = (p.S + 3) / 4;
     // The matrices of chunk k + 1 are fetched into registers before the products of chunk k and stored to the other LDS
@@ -219,25 +310,16 @@ __device__ __forceinline__ void lat_conv_body(const LatParams& p, const int64_t 
     }
 }
 
+// One grid for all parts of a batch (a single launch is a batch of one; the eight parity classes of a coarse -> fine layer share
+// volume, filter shape and output, and each alone is too small to fill the chip): workgroup g serves rows [128 g, 128 g + 128) of
+// the list, which belong to ONE part -- the parts' first rows are multiples of 128.
 template <int NTT, int KST>
-__global__ __launch_bounds__(256) void lat_conv_kernel(const LatParams p) {
-    lat_conv_body<NTT, KST>(p, blockIdx.x);
-}
-
-// several launches that share volume, filter shape and output (the eight parity classes of a coarse -> fine layer) as one
-// grid: each is too small to fill the chip alone (1.5k workgroups walking ~270 offsets: 0.19 ms each, 8x their matrix time)
-constexpr int kLatMaxParts = 8;
-struct LatBatch {
-    LatParams part[kLatMaxParts];
-    int64_t first[kLatMaxParts + 1];  // first workgroup of each part
-    int n;
-};
-
-template <int NTT, int KST>
-__global__ __launch_bounds__(256) void lat_conv_batch_kernel(const LatBatch b) {
+__global__ __launch_bounds__(256) void lat_conv_kernel(const LatBatch b) {
+    const int64_t first = (int64_t)blockIdx.x * kLatRowsPerGroup;
+    if (first >= b.start[b.n]) return;
     int i = 0;
-    while (i + 1 < b.n && (int64_t)blockIdx.x >= b.first[i + 1]) ++i;
-    lat_conv_body<NTT, KST>(b.part[i], (int64_t)blockIdx.x - b.first[i]);
+    while (i + 1 < b.n && first >= b.start[i + 1]) ++i;
+    lat_conv_body<NTT, KST>(b.part[i], b.rows, first, b.start[i] + b.count[i]);
 }
 
 static size_t lat_packed_floats(const dmcf_lattice_conv_args* a) {
@@ -312,8 +394,84 @@ static int lat_prepare(const dmcf_lattice_conv_args* a, float* packed, hipStream
     p.tiles_x = (a->base_dims[0] + 15) / 16;
     p.ntiles = (int64_t)p.tiles_x * a->base_dims[1] * a->base_dims[2];
     p.bias = a->bias; p.out = a->out; p.flags = a->flags;
-    groups = (p.ntiles + 4 * kLatTW - 1) / (4 * kLatTW);
+    groups = (p.ntiles * 16 + kLatCellsPerBlock - 1) / kLatCellsPerBlock;  // cell blocks of the compaction
     return DMCF_OK;
+}
+
+// workspace of a batch: [packed matrices of every part][blk in][blk scanned][scan tmp][start, count][rows]
+struct LatLayout {
+    size_t off_blk, off_scan, off_tmp, tmp_bytes, off_start, off_rows, total;
+    int64_t nblk, rows_capacity;
+};
+
+static LatLayout lat_layout(const dmcf_lattice_conv_args* parts, int n_parts) {
+    LatLayout L;
+    size_t off = 256;
+    L.nblk = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        off += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
+        const int64_t cells = (int64_t)((parts[i].base_dims[0] + 15) / 16) * 16 * parts[i].base_dims[1] * parts[i].base_dims[2];
+        L.nblk += (cells + kLatCellsPerBlock - 1) / kLatCellsPerBlock;
+    }
+    L.off_blk = off;    off += align_up((size_t)(L.nblk + 1) * 4, 256);
+    L.off_scan = off;   off += align_up((size_t)(L.nblk + 1) * 4, 256);
+    L.tmp_bytes = scan_tmp_bytes(L.nblk + 1);
+    L.off_tmp = off;    off += align_up(L.tmp_bytes, 256);
+    L.off_start = off;  off += 256;
+    // every output point is a row of at most one part; each part's rows start at a multiple of 128
+    L.rows_capacity = (parts[0].n_out + kLatRowsPerGroup - 1) / kLatRowsPerGroup * kLatRowsPerGroup + (int64_t)kLatRowsPerGroup * n_parts;
+    L.off_rows = off;   off += align_up((size_t)L.rows_capacity * sizeof(lat_i32x2), 256);
+    L.total = off;
+    return L;
+}
+
+static int lat_launch(const dmcf_lattice_conv_args* parts, int n_parts, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    for (int i = 0; i < n_parts; ++i) {
+        const int rc = lat_validate(parts + i);
+        if (rc != DMCF_OK) return rc;
+        if (parts[i].filter_dims[3] != parts[0].filter_dims[3] || parts[i].filter_dims[4] != parts[0].filter_dims[4] ||
+            parts[i].n_out != parts[0].n_out || parts[i].out != parts[0].out)
+            return DMCF_EINVAL;  // one kernel instantiation and one output for the whole grid
+    }
+    if (parts[0].n_out == 0) return DMCF_OK;
+    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
+    const LatLayout L = lat_layout(parts, n_parts);
+    if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
+    if (L.nblk > 0x7ffffffe) return DMCF_EUNSUPPORTED;
+    LatBatch b;
+    b.n = n_parts;
+    char* ws = (char*)workspace;
+    char* wp = ws;
+    int64_t first = 0;
+    for (int i = 0; i < n_parts; ++i) {
+        int64_t blocks;
+        const int rc = lat_prepare(parts + i, (float*)wp, stream, b.part[i], blocks);
+        if (rc != DMCF_OK) return rc;
+        wp += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
+        b.cfirst[i] = first;
+        first += blocks;
+    }
+    for (int i = n_parts; i <= kLatMaxParts; ++i) b.cfirst[i] = first;
+    if (first != L.nblk) return DMCF_EINVAL;
+    uint32_t* blk_in = (uint32_t*)(ws + L.off_blk);
+    b.blk = blk_in;
+    b.start = (int64_t*)(ws + L.off_start);
+    b.count = b.start + kLatMaxParts + 1;
+    b.rows = (lat_i32x2*)(ws + L.off_rows);
+    b.rows_capacity = L.rows_capacity;
+    hipLaunchKernelGGL(lat_rows_count, dim3((unsigned)L.nblk), dim3(256), 0, stream, b);
+    const int rc = scan_exclusive_u32(blk_in, (uint32_t*)(ws + L.off_scan), L.nblk + 1, ws + L.off_tmp, L.tmp_bytes, stream);
+    if (rc != DMCF_OK) return rc;
+    b.blk = (uint32_t*)(ws + L.off_scan);
+    hipLaunchKernelGGL(lat_rows_starts, dim3(1), dim3(64), 0, stream, b);
+    hipLaunchKernelGGL(lat_rows_write, dim3((unsigned)L.nblk), dim3(256), 0, stream, b);
+    const dim3 grid((unsigned)(L.rows_capacity / kLatRowsPerGroup)), block(256);
+    const int KS = b.part[0].KS, NT = b.part[0].NT;
+    if (KS == 1 && NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 1>), grid, block, 0, stream, b);
+    else if (KS == 1) hipLaunchKernelGGL((lat_conv_kernel<2, 1>), grid, block, 0, stream, b);
+    else if (NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 2>), grid, block, 0, stream, b);
+    else hipLaunchKernelGGL((lat_conv_kernel<2, 2>), grid, block, 0, stream, b);
+    return check_launch();
 }
 
 }  // namespace dmcf
@@ -324,70 +482,25 @@ extern "C" {
 
 size_t dmcf_lattice_conv_workspace_bytes(const dmcf_lattice_conv_args* a) {
     if (lat_validate(a) != DMCF_OK) return 256;
-    return 256 + align_up(lat_packed_floats(a) * sizeof(float), 256);
+    return lat_layout(a, 1).total;
 }
 
 size_t dmcf_lattice_conv_batch_workspace_bytes(const dmcf_lattice_conv_args* parts, int32_t n_parts) {
-    size_t total = 256;
-    for (int i = 0; parts && i < n_parts; ++i)
-        if (lat_validate(parts + i) == DMCF_OK) total += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
-    return total;
+    if (!parts || n_parts < 1 || n_parts > kLatMaxParts) return 256;
+    for (int i = 0; i < n_parts; ++i)
+        if (lat_validate(parts + i) != DMCF_OK) return 256;
+    return lat_layout(parts, n_parts).total;
 }
 
 int dmcf_lattice_conv_forward(const dmcf_lattice_conv_args* a, void* workspace, size_t workspace_bytes, dmcf_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    int rc = lat_validate(a);
-    if (rc != DMCF_OK) return rc;
-    if (a->n_out == 0) return DMCF_OK;
-    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
-    if (workspace_bytes < dmcf_lattice_conv_workspace_bytes(a)) return DMCF_EWORKSPACE;
-    LatParams p;
-    int64_t groups;
-    rc = lat_prepare(a, (float*)workspace, stream, p, groups);
-    if (rc != DMCF_OK) return rc;
-    if (groups > 0x7fffffff) return DMCF_EUNSUPPORTED;
-    const dim3 grid((unsigned)groups), block(256);
-    if (p.KS == 1 && p.NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 1>), grid, block, 0, stream, p);
-    else if (p.KS == 1) hipLaunchKernelGGL((lat_conv_kernel<2, 1>), grid, block, 0, stream, p);
-    else if (p.NT == 1) hipLaunchKernelGGL((lat_conv_kernel<1, 2>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((lat_conv_kernel<2, 2>), grid, block, 0, stream, p);
-    return check_launch();
+    if (!a) return DMCF_EINVAL;
+    return lat_launch(a, 1, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 int dmcf_lattice_conv_forward_batch(const dmcf_lattice_conv_args* parts, int32_t n_parts, void* workspace, size_t workspace_bytes,
                                     dmcf_stream_t stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (!parts || n_parts < 1 || n_parts > kLatMaxParts) return DMCF_EINVAL;
-    for (int i = 0; i < n_parts; ++i) {
-        const int rc = lat_validate(parts + i);
-        if (rc != DMCF_OK) return rc;
-        if (parts[i].filter_dims[3] != parts[0].filter_dims[3] || parts[i].filter_dims[4] != parts[0].filter_dims[4])
-            return DMCF_EINVAL;  // one kernel instantiation for the whole grid
-    }
-    if (parts[0].n_out == 0) return DMCF_OK;
-    if (!workspace || ((uintptr_t)workspace & 255)) return DMCF_EINVAL;
-    if (workspace_bytes < dmcf_lattice_conv_batch_workspace_bytes(parts, n_parts)) return DMCF_EWORKSPACE;
-    LatBatch b;
-    b.n = n_parts;
-    char* ws = (char*)workspace;
-    int64_t first = 0;
-    for (int i = 0; i < n_parts; ++i) {
-        int64_t groups;
-        const int rc = lat_prepare(parts + i, (float*)ws, stream, b.part[i], groups);
-        if (rc != DMCF_OK) return rc;
-        ws += align_up(lat_packed_floats(parts + i) * sizeof(float), 256);
-        b.first[i] = first;
-        first += groups;
-    }
-    for (int i = n_parts; i <= kLatMaxParts; ++i) b.first[i] = first;
-    if (first > 0x7fffffff) return DMCF_EUNSUPPORTED;
-    const dim3 grid((unsigned)first), block(256);
-    const int KS = b.part[0].KS, NT = b.part[0].NT;
-    if (KS == 1 && NT == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<1, 1>), grid, block, 0, stream, b);
-    else if (KS == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<2, 1>), grid, block, 0, stream, b);
-    else if (NT == 1) hipLaunchKernelGGL((lat_conv_batch_kernel<1, 2>), grid, block, 0, stream, b);
-    else hipLaunchKernelGGL((lat_conv_batch_kernel<2, 2>), grid, block, 0, stream, b);
-    return check_launch();
+    return lat_launch(parts, n_parts, workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
 }  // extern "C"
