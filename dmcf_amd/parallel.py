@@ -771,7 +771,7 @@ class ShardedSimulator:
         self._sets[name] = pos
         self._name_of[id(pos)] = name
         fused = os.environ.get("DMCF_SHARD_FUSED", "1")  # "0": the host form below; "force": also for CPU tensors (tests/shims.py)
-        if self.comm.world > 1 and (fused == "force" or (fused != "0" and pos.is_cuda)):
+        if (self.comm.world > 1 or FORCE_COMM) and (fused == "force" or (fused != "0" and pos.is_cuda)):
             # every width the step will ask this set for is configuration: the layers' radii and, for the particles, the halos
             # the lattices are built from -- all plans at once (GhostPlan.build_fused)
             m = self.model
