@@ -145,8 +145,7 @@ __global__ __launch_bounds__(256) void frs_bbox(const float* __restrict__ pts, i
 
 // one thread: choose the cell edge (>= 1.001 R so that [q-R, q+R] spans at most 3 cells) and coarsen
 // it until the dense grid fits the cell table.  Coarser cells only add candidates, never lose any.
-__global__ void frs_finish_header(FrsHeader* h, int64_t table) {
-    if (threadIdx.x != 0) return;
+__device__ void frs_finish_header_one(FrsHeader* h, int64_t table) {
     float lo[3], ext[3];
     for (int a = 0; a < 3; ++a) {
         lo[a] = ord2f(h->bb_min[a]);
@@ -207,6 +206,10 @@ __global__ void frs_finish_header(FrsHeader* h, int64_t table) {
     h->ncells = d[0] * d[1] * d[2];
 }
 
+__global__ void frs_finish_header(FrsHeader* h, int64_t table) {
+    if (threadIdx.x == 0) frs_finish_header_one(h, table);
+}
+
 // cell coordinate along one axis; the SAME function is used for points and for the ends of a query's
 // range, so monotonicity of floor((x - o) * inv) guarantees every in-range point is visited.
 __device__ __forceinline__ int cell_coord(float x, float origin, float inv, int dim) {
@@ -255,6 +258,119 @@ __global__ __launch_bounds__(256) void frs_rank_and_place(const float* __restric
     uint32_t rank = 0;
     for (uint32_t s = b; s < e; ++s) rank += (tmp_idx[s] < (int32_t)i) ? 1u : 0u;
     sorted[b + rank] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int32_t)i));
+}
+
+// The whole build as ONE launch of one workgroup, for point sets of a few thousand (the 2-D scenes, BASELINE.json configs 2 / 3,
+// build six tables of 2 - 4k points per step): ten launches of one or a handful of workgroups each -- header, box, cell edge,
+// memset, histogram, three of the scan, scatter, rank -- cost their ~45 us of launch-to-launch latency, not their work.  Same
+// phases, same results (the box sums are added in another order: they only place the grid, which no result depends on).
+constexpr int kSmallThreads = 1024;
+constexpr int64_t kSmallBuildMax = 16384;  // points; the cell table then has at most 65536 entries
+__global__ __launch_bounds__(kSmallThreads) void frs_build_small(const float* __restrict__ pts, int64_t n, float radius,
+                                                                  FrsHeader* h, int64_t table, uint32_t* __restrict__ cell_start,
+                                                                  uint32_t* __restrict__ cell_fill, int32_t* __restrict__ point_cell,
+                                                                  int32_t* __restrict__ tmp_idx, float4* __restrict__ sorted) {
+    __shared__ float red[4][3][kSmallThreads / 64];
+    __shared__ uint32_t part[kSmallThreads];
+    const int tid = threadIdx.x, w = tid >> 6;
+    uint32_t* slot_of = (uint32_t*)sorted;  // (the places inside the cells wait in the sorted array's memory, written last)
+    // box, sums
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float sm[3] = {0.0f, 0.0f, 0.0f}, sq[3] = {0.0f, 0.0f, 0.0f};
+    for (int64_t i = tid; i < n; i += kSmallThreads) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float v = pts[3 * i + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+            if (isfinite(v)) {
+                sm[a] += v;
+                sq[a] += v * v;
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], d, kWave));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], d, kWave));
+            sm[a] += __shfl_xor(sm[a], d, kWave);
+            sq[a] += __shfl_xor(sq[a], d, kWave);
+        }
+        if (lane_id() == 0) {
+            red[0][a][w] = mn[a];
+            red[1][a][w] = mx[a];
+            red[2][a][w] = sm[a];
+            red[3][a][w] = sq[a];
+        }
+    }
+    for (int64_t e = tid; e <= table; e += kSmallThreads) cell_fill[e] = 0u;
+    __syncthreads();
+    if (tid == 0) {
+        h->radius = radius;
+        h->n_points = (int32_t)n;
+        for (int a = 0; a < 3; ++a) {
+            float lo = INFINITY, hi = -INFINITY;
+            double s1 = 0.0, s2 = 0.0;
+            for (int v = 0; v < kSmallThreads / 64; ++v) {
+                lo = fminf(lo, red[0][a][v]);
+                hi = fmaxf(hi, red[1][a][v]);
+                s1 += (double)red[2][a][v];
+                s2 += (double)red[3][a][v];
+            }
+            h->bb_min[a] = n > 0 ? f2ord(lo) : 0xffffffffu;
+            h->bb_max[a] = n > 0 ? f2ord(hi) : 0u;
+            h->sum[a] = s1;
+            h->sumsq[a] = s2;
+        }
+        frs_finish_header_one(h, table);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // histogram: each point keeps the counter's old value
+    for (int64_t i = tid; i < n; i += kSmallThreads) {
+        int c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            c[a] = cell_coord(pts[3 * i + a], h->origin[a], h->inv_cell[a], h->dims[a]);
+            c[a] = min(max(c[a], 0), h->dims[a] - 1);
+        }
+        const int32_t cell = (c[2] * h->dims[1] + c[1]) * h->dims[0] + c[0];
+        point_cell[i] = cell;
+        slot_of[i] = atomicAdd(&cell_fill[cell], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the table + 1 counters: a contiguous piece per thread, the pieces' sums scanned in LDS
+    const int64_t per = (table + 1 + kSmallThreads - 1) / kSmallThreads;
+    const int64_t e0 = min((int64_t)tid * per, table + 1), e1 = min(e0 + per, table + 1);
+    uint32_t mine = 0;
+    for (int64_t e = e0; e < e1; ++e) mine += cell_fill[e];
+    part[tid] = mine;
+    __syncthreads();
+    for (int d = 1; d < kSmallThreads; d <<= 1) {
+        const uint32_t add = tid >= d ? part[tid - d] : 0u;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[tid] - mine;
+    for (int64_t e = e0; e < e1; ++e) {
+        cell_start[e] = run;
+        run += cell_fill[e];
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < n; i += kSmallThreads) tmp_idx[cell_start[point_cell[i]] + slot_of[i]] = (int32_t)i;
+    __syncthreads();
+    // rank every point inside its cell by index: a deterministic sorted array
+    for (int64_t i = tid; i < n; i += kSmallThreads) {
+        const int32_t cell = point_cell[i];
+        const uint32_t b = cell_start[cell], e = cell_start[cell + 1];
+        uint32_t rank = 0;
+        for (uint32_t t = b; t < e; ++t) rank += (tmp_idx[t] < (int32_t)i) ? 1u : 0u;
+        // (slot_of aliases `sorted`: every place was read by the scatter above, before the barrier)
+        sorted[b + rank] = make_float4(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2], __int_as_float((int32_t)i));
+    }
 }
 
 #ifndef FRS_WIN
@@ -688,6 +804,11 @@ int dmcf_frs_build(const float* points, int64_t n, float radius, void* workspace
     int32_t* tmp_idx = (int32_t*)(ws + L.off_tmp_idx);
     float4* sorted = (float4*)(ws + L.off_sorted);
 
+    if (n <= kSmallBuildMax && !getenv("DMCF_FRS_NO_SMALL_BUILD")) {
+        hipLaunchKernelGGL(frs_build_small, dim3(1), dim3(kSmallThreads), 0, stream, points, n, radius, h, L.table, cell_start, cell_fill,
+                           point_cell, tmp_idx, sorted);
+        return check_launch();
+    }
     hipLaunchKernelGGL(frs_init_header, dim3(1), dim3(64), 0, stream, h, radius, (int32_t)n);
     if (n > 0) {
         const unsigned g = (unsigned)((n + 255) / 256);

@@ -1259,3 +1259,28 @@ def test_ghost_select_ownership_is_the_stable_order_by_owner():
     assert torch.equal(sel.write([pos.shape[0]])[0], torch.argsort(own, stable=True))
     pos[5, 1] = float("nan")
     assert int(ops.ghost_select(pos, boxes, [-1.0]).totals.sum()) == pos.shape[0] - 1
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 2401, 16384])
+def test_single_launch_table_build_equals_the_ten_launch_one(dev, monkeypatch, n):
+    """frs_build_small (one workgroup builds the whole table of a point set of up to 16384 points) against the general build:
+    the same lists in the same order, clustered and far points included."""
+    from dmcf_amd import ops
+    g = torch.Generator().manual_seed(n + 5)
+    pts = torch.rand(n, 3, generator=g)
+    if n > 10:
+        pts[: n // 3] = pts[: n // 3] * 0.05 + 0.4   # a clump: long rows
+        pts[-3:] += 40.0                               # points far beyond the bulk (binned into the border cells)
+    qs = torch.cat([pts[: max(n // 2, 0)], torch.rand(17, 3, generator=g)])
+    pts, qs = pts.to(dev), qs.to(dev)
+    res = {}
+    for small in (True, False):
+        if small:
+            monkeypatch.delenv("DMCF_FRS_NO_SMALL_BUILD", raising=False)
+        else:
+            monkeypatch.setenv("DMCF_FRS_NO_SMALL_BUILD", "1")
+        r = ops.fixed_radius_search(pts, qs, 0.11, return_distances=True)
+        res[small] = [t.cpu() for t in (r.neighbors_index, r.neighbors_row_splits, r.neighbors_distance)]
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
+    assert n < 100 or res[True][0].numel() > n
