@@ -16,6 +16,14 @@
 // registers (K/16 x 4 VGPRs) in exact fp32 (the MFMA is a k-ordered fmaf chain) and is written once per point to
 // the LDS tile the contraction reads -- the contraction itself is the one of cconv.hip.
 //
+// Filters of several 16-cell tiles that are not 4 x 4 planes (the 8 x 8 filters of the 2-D models: four tiles of two rows each)
+// would spend three quarters of their matrix instructions on tiles a pair does not touch -- its footprint is 2 x 2 cells.  ORDER:
+// every batch of 64 pairs is sorted by the tiles its footprint touches (lane = pair: a mask of <= 4 bits from the 8 corner cells,
+// a key "first tile, and whether a second one", 9 ballots for the ranks, 6 ds_permute for the records), so the 4 pairs of an
+// instruction mostly share their tiles, and an instruction is issued only for the tiles one of its 4 pairs touches (a wave-uniform
+// test on 4 ballots per batch): 1.5 - 2 of 4 on the 8 x 8 filters.  The sum of a cell is then formed in the sorted order:
+// deterministic, a different rounding than list order.
+//
 // One workgroup = 8 waves = a tile of 16 output points (two points per wave, one after the other), 16 channels
 // per pass, two workgroups per CU.  Interpolation modes map onto the same product: 'linear' stores clamped
 // coordinates, 'linear_border' unclamped ones (the hat vanishes outside the array by itself), 'nearest_neighbor'
@@ -42,13 +50,14 @@ __device__ __forceinline__ float hat(float d) { return fmaxf(0.0f, 1.0f - fabsf(
 struct PairRec {
     float x, y, z, a;  // generic: clamped filter coordinates + importance
     float w1, w2, w3;  // PLANE16: z = a*hat(z), a = unused, w1..w3 = a*hat(z-1..3)
+    unsigned long long need[kMaxKT];  // ORDER (wave uniform): the slots of the sorted batch that touch tile t
 };
 
 // GENERIC: runtime mapping / interpolation switches; PLANE16: sx*sy == 16 (the (x,y) hat product is shared by all
 // tiles, z = tile index); NTT: number of 16-channel output tiles the contraction accumulates (register budget);
 // KTT: number of 16-cell tiles when known at compile time (0 = runtime p.KT).
 template <bool GENERIC, bool PLANE16, int NTT, int KTT>
-__global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvParams p) {
+__global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,6 +69,9 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
     const int64_t pt0 = (int64_t)tile * MTM;
     const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
     const int mi = lane & 15, mg = lane >> 4;  // MFMA roles: A row (cell) / B column (channel); k index (pair)
+    constexpr bool ORDER = !GENERIC && !PLANE16 && (KTT == 0 || KTT > 1);  // see the header
+    const int dbg = p.csplit >> 8;
+    const bool order_on = ORDER && KT > 1 && dbg != 3;
 
     // filter cell of this lane in each 16-cell tile (cells beyond K are parked far away: weight 0)
     constexpr int NCT = PLANE16 ? 1 : kMaxKT;
@@ -80,7 +92,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     // (small launches: one channel chunk per workgroup, blockIdx.y -- see cconv_mfma_launch)
-    const int chunk_lo = p.csplit ? (int)blockIdx.y : 0, chunk_hi = p.csplit ? (int)blockIdx.y + 1 : p.nchunks;
+    const int chunk_lo = (p.csplit & 255) ? (int)blockIdx.y : 0, chunk_hi = (p.csplit & 255) ? (int)blockIdx.y + 1 : p.nchunks;
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         const int c0 = chunk * MCH;
         const bool ch_ok = c0 + mi < cin;
@@ -104,33 +116,37 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                 // Software pipeline per batch of 64 pairs: (index, d^2) loads run two batches ahead, position
                 // gathers one batch ahead, the feature loads of one half batch are in flight while the MFMAs of
                 // the other half batch issue.
+                // Every load of the batch loop is UNCONDITIONAL (clamped indices, stand-in pointers, values masked afterwards): a load
+                // inside a branch -- even a uniform one -- makes the compiler's s_waitcnt bookkeeping give up at the join and wait
+                // with vmcnt(0), i.e. for the loads just issued as well, and the software pipeline below degenerates into one memory
+                // round trip per quarter batch (measured on the 2-D scenes: 8,000 clocks per batch of 64 pairs, whatever the work).
+                const float* const nvp = p.nval ? p.nval : (const float*)p.idx;
+                const float* const impp = p.inp_imp ? p.inp_imp : p.inp_pos;
                 auto ld_idx = [&](int b, int& j, float& nv, bool& v) {
                     const int64_t q = rb + 64 * (int64_t)b + lane;
                     v = q < re;
-                    j = 0;
-                    nv = 0.0f;
-                    if (v) {
-                        j = p.idx[q];
-                        if (p.nval) nv = p.nval[q];
-                    }
+                    const int64_t qc = min(q, re - 1);  // (re > rb: the pipeline runs for non-empty rows only)
+                    const int jj = p.idx[qc];
+                    const float nn = nvp[qc];
+                    j = v ? jj : 0;
+                    nv = v ? nn : 0.0f;
                 };
                 auto ld_pos = [&](int j, bool v, float& x, float& y, float& z) {
-                    x = y = z = 0.0f;
-                    if (v) {
-                        x = p.inp_pos[3 * (int64_t)j];
-                        y = p.inp_pos[3 * (int64_t)j + 1];
-                        z = p.inp_pos[3 * (int64_t)j + 2];
-                    }
+                    x = p.inp_pos[3 * (int64_t)j];
+                    y = p.inp_pos[3 * (int64_t)j + 1];
+                    z = p.inp_pos[3 * (int64_t)j + 2];
                 };
                 auto geom = [&](int j, float nv, bool v, float x, float y, float z) -> PairRec {
                     float a = 0.0f;
-                    if (v) {
+                    const float iv = impp[j];
+                    {   // (lanes without a pair carry the geometry of point 0: their weight is zeroed below)
                         x -= ox;
                         y -= oy;
                         z -= oz;
                         a = window_value(p.window, p.nval ? nv : rel_dist2(x, y, z), p.inv_r2, p.window_fac);
+                        a = v ? a : 0.0f;
                         nsum += a;
-                        if (p.inp_imp) a *= p.inp_imp[j];
+                        if (p.inp_imp) a *= iv;
                         filter_coords<GENERIC>(x, y, z, p);
                         const float hx = (float)(p.sx - 1), hy = (float)(p.sy - 1), hz = (float)(p.sz - 1);
                         if (!GENERIC || p.interp == DMCF_INTERP_LINEAR) {  // coordinate clamping
@@ -149,6 +165,8 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                         }
                     }
                     PairRec r;
+#pragma unroll
+                    for (int mt = 0; mt < kMaxKT; ++mt) r.need[mt] = ~0ull;
                     r.x = x;
                     r.y = y;
                     if constexpr (PLANE16) {
@@ -169,7 +187,6 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                 // for the load right here): out-of-range slots read row 0 / channel 0 and are masked at use.
                 const int ch_safe = ch_ok ? c0 + mi : 0;
                 auto issue = [&](int bj, int np, int g0, float (&f)[4]) {
-                    if (4 * g0 >= np) return;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int q = 4 * (g0 + g) + mg;
@@ -198,12 +215,47 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                             const float z = __shfl(c.z, q, 64), a = __shfl(c.a, q, 64);  // a == 0 for slots beyond np
 #pragma unroll
                             for (int mt = 0; mt < kMaxKT; ++mt)
-                                if (mt < (KTT ? KTT : KT))
+                                if (mt < (KTT ? KTT : KT) && (!ORDER || ((c.need[mt] >> (4 * (g0 + g))) & 0xfull) != 0ull))
                                     bacc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                                         (hat(x - cxs[mt]) * hat(y - cys[mt])) * (hat(z - czs[mt]) * a), fv, bacc[mt], 0, 0, 0);
                         }
                     }
                 };
+                // ORDER: sort the batch by the tiles the pairs touch; need[t] = ballot of "slot touches tile t" in the sorted order
+                auto order = [&](PairRec& r, int& j, bool v) {
+                    if (!order_on) return;
+                    uint32_t tm = 0;
+                    if (v && r.a != 0.0f) {
+                        const int x0 = (int)r.x, y0 = (int)r.y, z0 = (int)r.z;  // (clamped to [0, size - 1]: never negative)
+                        const int x1 = min(x0 + 1, p.sx - 1), y1 = min(y0 + 1, p.sy - 1), z1 = min(z0 + 1, p.sz - 1);
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const int cell = (((c & 4) ? z1 : z0) * p.sy + ((c & 2) ? y1 : y0)) * p.sx + ((c & 1) ? x1 : x0);
+                            tm |= 1u << (cell >> 4);
+                        }
+                    }
+                    // key: 2 * (first tile) + (touches a later one too), pairs without a footprint last
+                    const int first = tm ? __builtin_ctz(tm) : 0;
+                    const int key = tm ? 2 * first + ((tm >> first) > 1u ? 1 : 0) : (v ? 7 : 8);  // (the last tile has no later one: 7 is free)
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    int rank = 0, base = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) {
+                        const unsigned long long bk = __ballot(key == k);
+                        if (key == k) rank = base + (int)__popcll(bk & below);
+                        base += (int)__popcll(bk);
+                    }
+                    const int dst = rank << 2;
+                    r.x = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.x)));
+                    r.y = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.y)));
+                    r.z = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.z)));
+                    r.a = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.a)));
+                    j = __builtin_amdgcn_ds_permute(dst, j);
+                    tm = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)tm);
+#pragma unroll
+                    for (int mt = 0; mt < kMaxKT; ++mt) r.need[mt] = dbg == 1 ? ~0ull : (dbg == 2 ? 0ull : __ballot((tm >> mt) & 1u));
+                };
+                if (nb > 0) {
                 int j0, j1;
                 float nv0, nv1, px, py, pz;
                 bool v0, v1;
@@ -211,6 +263,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                 ld_idx(1, j1, nv1, v1);
                 ld_pos(j0, v0, px, py, pz);
                 PairRec cur = geom(j0, nv0, v0, px, py, pz);
+                order(cur, j0, v0);
                 int curj = j0;
                 int np_cur = (int)min((int64_t)64, re - rb);
                 // three quarter-batch feature buffers rotate: a load has two quarters of MFMAs to land
@@ -227,7 +280,8 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                     run(cur, np_cur, 0, fA);
                     issue(curj, np_cur, 12, fA);
                     run(cur, np_cur, 4, fB);
-                    const PairRec nxt = geom(j1, nv1, v1, px, py, pz);
+                    PairRec nxt = geom(j1, nv1, v1, px, py, pz);
+                    order(nxt, j1, v1);
                     const int nxtj = j1;
                     const int np_nxt = (int)min((int64_t)64, max((int64_t)0, re - rb - 64 * (int64_t)(b + 1)));
                     issue(nxtj, np_nxt, 0, fB);
@@ -247,6 +301,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
                     nv1 = nv2;
                     v1 = v2;
                 }
+                }  // nb > 0
             }
             // D layout of 16x16x4: lane l, reg r -> row (cell in tile) 4*(l>>4)+r, column (channel) l&15
             float* Brow = Bt + (size_t)pt * KCp;
@@ -300,7 +355,7 @@ __global__ __launch_bounds__(kMThreads, 4) void cconv_mfma_kernel(const CconvPar
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < kMWaves; ++w) v += red[((size_t)w * MTM + ptt) * ncol + o];
-        if (p.csplit) {  // this chunk's share: cconv_mfma_sum_chunks adds the chunks in order, the bias and the value to accumulate to
+        if (p.csplit & 255) {  // this chunk's share: cconv_mfma_sum_chunks adds the chunks in order, the bias and the value to accumulate to
             p.partial[((size_t)chunk_lo * p.n_out + ii) * cout + o] = v;
             continue;
         }
@@ -405,7 +460,7 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     const size_t partial = (a->flags & DMCF_FLAG_NORMALIZE) ? 0 : cconv_mfma_partial_floats(p.K, p.cin, p.cout, p.n_out);
-    p.csplit = partial ? 1 : 0;
+    p.csplit = (partial ? 1 : 0) | ((getenv("DMCF_MFMA_DEBUG") ? atoi(getenv("DMCF_MFMA_DEBUG")) : 0) << 8);
     p.partial = partial ? packed + align_up(cfg.packed_floats, 64) : nullptr;
     const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
                            a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
@@ -432,12 +487,12 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
         return DMCF_ELAUNCH;
     }
     void* kargs[] = {(void*)&p};
-    e = hipLaunchKernel(fn, dim3(grid, p.csplit ? (unsigned)p.nchunks : 1u), dim3(kMThreads), kargs, cfg.lds, stream);
+    e = hipLaunchKernel(fn, dim3(grid, (p.csplit & 255) ? (unsigned)p.nchunks : 1u), dim3(kMThreads), kargs, cfg.lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return DMCF_ELAUNCH;
     }
-    if (p.csplit) {
+    if (p.csplit & 255) {
         const int64_t total = p.n_out * p.cout;
         hipLaunchKernelGGL(cconv_mfma_sum_chunks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.partial, p.nchunks, p.n_out,
                            p.cout, p.bias, p.out, (p.flags & DMCF_FLAG_ACCUMULATE) ? 1 : 0);
