@@ -21,7 +21,9 @@
 // every batch of 64 pairs is sorted by the tiles its footprint touches (lane = pair: a mask of <= 4 bits from the 8 corner cells,
 // a key "first tile, and whether a second one", 9 ballots for the ranks, 6 ds_permute for the records), so the 4 pairs of an
 // instruction mostly share their tiles, and an instruction is issued only for the tiles one of its 4 pairs touches (a wave-uniform
-// test on 4 ballots per batch): 1.5 - 2 of 4 on the 8 x 8 filters.  The sum of a cell is then formed in the sorted order:
+// test on 4 ballots per batch): 1.5 - 2 of 4 on the 8 x 8 filters.  With the batch's records staged in LDS in slot order and every
+// load of the batch loop unconditional (see below) the 2-D layers of the WBC-SPH scene went from 226 to 148 us per launch; what is
+// left is instruction issue: ~1,100 instructions per batch of 64 pairs around the matrix instructions (two waves per SIMD).  The sum of a cell is then formed in the sorted order:
 // deterministic, a different rounding than list order.
 //
 // One workgroup = 8 waves = a tile of 16 output points (two points per wave, one after the other), 16 channels
@@ -40,6 +42,7 @@ constexpr int MTM = 16;    // output points per workgroup (MFMA M of the contrac
 constexpr int MCH = 16;    // channels per pass (MFMA N of the splat)
 constexpr int kMaxKT = 4;  // 16-cell tiles: filters of up to 64 cells
 constexpr int kMMaxNT = 4;
+constexpr int kMStage = 2 * 64 * 16 + 2 * 64 * 4 + 64 * 4;  // bytes per wave: two batches of records {x, y, z, a} and indices, one of tile masks
 
 __device__ __forceinline__ float hat(float d) { return fmaxf(0.0f, 1.0f - fabsf(d)); }
 
@@ -64,14 +67,17 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
     const int KCp = p.KCp, cin = p.cin, cout = p.cout, KT = p.KT;
     float* Bt = smem;              // [MTM][KCp]
     float* norm = Bt + p.bfloats;  // [MTM]
+    char* const stg = (char*)(norm + MTM) + wave * kMStage;  // (!PLANE16) the batch's records in slot order, see `stage`
+    f32x4* const Rs = (f32x4*)stg;                 // [2][64] {x, y, z, a}
+    int* const Js = (int*)(stg + 2048);            // [2][64] neighbour index
+    uint32_t* const Ts = (uint32_t*)(stg + 2560);  // [64] tiles the slot's pair touches
     const int tile = (int)(blockIdx.x % 8) * p.tiles_per_xcd + (int)(blockIdx.x / 8);
     if (tile >= p.ntiles) return;
     const int64_t pt0 = (int64_t)tile * MTM;
     const bool symmetric = (p.flags & DMCF_FLAG_SYMMETRIC) != 0;
     const int mi = lane & 15, mg = lane >> 4;  // MFMA roles: A row (cell) / B column (channel); k index (pair)
     constexpr bool ORDER = !GENERIC && !PLANE16 && (KTT == 0 || KTT > 1);  // see the header
-    const int dbg = p.csplit >> 8;
-    const bool order_on = ORDER && KT > 1 && dbg != 3;
+    const bool order_on = ORDER && KT > 1;
 
     // filter cell of this lane in each 16-cell tile (cells beyond K are parked far away: weight 0)
     constexpr int NCT = PLANE16 ? 1 : kMaxKT;
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
     for (int n = 0; n < NTT; ++n) acc[n] = (f32x4){0.0f, 0.0f, 0.0f, 0.0f};
 
     // (small launches: one channel chunk per workgroup, blockIdx.y -- see cconv_mfma_launch)
-    const int chunk_lo = (p.csplit & 255) ? (int)blockIdx.y : 0, chunk_hi = (p.csplit & 255) ? (int)blockIdx.y + 1 : p.nchunks;
+    const int chunk_lo = p.csplit ? (int)blockIdx.y : 0, chunk_hi = p.csplit ? (int)blockIdx.y + 1 : p.nchunks;
     for (int chunk = chunk_lo; chunk < chunk_hi; ++chunk) {
         const int c0 = chunk * MCH;
         const bool ch_ok = c0 + mi < cin;
@@ -186,21 +192,24 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
                 // Branch free and never touched until the MFMAs consume them (a use would make the compiler wait
                 // for the load right here): out-of-range slots read row 0 / channel 0 and are masked at use.
                 const int ch_safe = ch_ok ? c0 + mi : 0;
-                auto issue = [&](int bj, int np, int g0, float (&f)[4]) {
+                auto issue = [&](int bj, int buf, int np, int g0, float (&f)[4]) {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int q = 4 * (g0 + g) + mg;
-                        const int jj = __shfl(bj, q, 64);  // 0 for slots beyond np
+                        // (!PLANE16: the staged index of slot q -- one broadcast read per 16 lanes instead of a ds_bpermute)
+                        const int jj = PLANE16 ? __shfl(bj, q, 64) : Js[buf * 64 + q];  // 0 for slots beyond np
                         f[g] = p.inp_feat[(int64_t)jj * cin + ch_safe];
                     }
                 };
-                auto run = [&](const PairRec& c, int np, int g0, const float (&f)[4]) {
+                auto run = [&](const PairRec& c, int buf, int np, int g0, const float (&f)[4]) {
                     if (4 * g0 >= np) return;
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int q = 4 * (g0 + g) + mg;
                         const float fv = (q < np && ch_ok) ? f[g] + fi : 0.0f;
-                        const float x = __shfl(c.x, q, 64), y = __shfl(c.y, q, 64);
+                        f32x4 rc = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if constexpr (!PLANE16) rc = Rs[buf * 64 + q];  // the record of slot q: one 16-byte broadcast read
+                        const float x = PLANE16 ? __shfl(c.x, q, 64) : rc.x, y = PLANE16 ? __shfl(c.y, q, 64) : rc.y;
                         if constexpr (PLANE16) {
                             const float wxy = hat(x - cxs[0]) * hat(y - cys[0]);
                             const float w0 = __shfl(c.z, q, 64);  // a * hat(z - plane): 0 for slots beyond np
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
                             if ((KTT ? KTT : KT) > 3)
                                 bacc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(wxy * __shfl(c.w3, q, 64), fv, bacc[3], 0, 0, 0);
                         } else {
-                            const float z = __shfl(c.z, q, 64), a = __shfl(c.a, q, 64);  // a == 0 for slots beyond np
+                            const float z = rc.z, a = rc.w;  // a == 0 for slots beyond np
 #pragma unroll
                             for (int mt = 0; mt < kMaxKT; ++mt)
                                 if (mt < (KTT ? KTT : KT) && (!ORDER || ((c.need[mt] >> (4 * (g0 + g))) & 0xfull) != 0ull))
@@ -221,39 +230,49 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
                         }
                     }
                 };
-                // ORDER: sort the batch by the tiles the pairs touch; need[t] = ballot of "slot touches tile t" in the sorted order
-                auto order = [&](PairRec& r, int& j, bool v) {
-                    if (!order_on) return;
-                    uint32_t tm = 0;
-                    if (v && r.a != 0.0f) {
-                        const int x0 = (int)r.x, y0 = (int)r.y, z0 = (int)r.z;  // (clamped to [0, size - 1]: never negative)
-                        const int x1 = min(x0 + 1, p.sx - 1), y1 = min(y0 + 1, p.sy - 1), z1 = min(z0 + 1, p.sz - 1);
+                // !PLANE16: the batch's records go to LDS in SLOT order -- ORDER: sorted by the tiles the pairs touch, else list order --
+                // where the splat reads {x, y, z, a} of slot q with one broadcast ds_read_b128 and the feature loads read its index
+                // (the four ds_bpermute per group of 4 pairs this replaces -- 128 per batch, each waited for -- were the floor of the
+                // 2-D layers: 129 of 157 us per launch with the matrix instructions taken out).  need[t] = ballot of "slot touches
+                // tile t".  Two buffers: the next batch is staged while the current one still has quarters to go.
+                auto stage = [&](PairRec& r, int& j, bool v, int buf) {
+                    if constexpr (PLANE16) return;
+                    uint32_t tm = 0xfu;
+                    int rank = lane;
+                    if (order_on) {
+                        tm = 0;
+                        if (v && r.a != 0.0f) {
+                            const int x0 = (int)r.x, y0 = (int)r.y, z0 = (int)r.z;  // (clamped to [0, size - 1]: never negative)
+                            const int x1 = min(x0 + 1, p.sx - 1), y1 = min(y0 + 1, p.sy - 1), z1 = min(z0 + 1, p.sz - 1);
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) {
-                            const int cell = (((c & 4) ? z1 : z0) * p.sy + ((c & 2) ? y1 : y0)) * p.sx + ((c & 1) ? x1 : x0);
-                            tm |= 1u << (cell >> 4);
+                            for (int c = 0; c < 8; ++c) {
+                                const int cell = (((c & 4) ? z1 : z0) * p.sy + ((c & 2) ? y1 : y0)) * p.sx + ((c & 1) ? x1 : x0);
+                                tm |= 1u << (cell >> 4);
+                            }
+                        }
+                        // key: 2 * (first tile) + (touches a later one too); pairs without a footprint, then lanes without a pair, last
+                        const int first = tm ? __builtin_ctz(tm) : 0;
+                        const int key = tm ? 2 * first + ((tm >> first) > 1u ? 1 : 0) : (v ? 7 : 8);  // (the last tile has no later one: 7 is free)
+                        const unsigned long long below = (1ull << lane) - 1ull;
+                        int base = 0;
+#pragma unroll
+                        for (int k = 0; k < 9; ++k) {
+                            const unsigned long long bk = __ballot(key == k);
+                            if (key == k) rank = base + (int)__popcll(bk & below);
+                            base += (int)__popcll(bk);
                         }
                     }
-                    // key: 2 * (first tile) + (touches a later one too), pairs without a footprint last
-                    const int first = tm ? __builtin_ctz(tm) : 0;
-                    const int key = tm ? 2 * first + ((tm >> first) > 1u ? 1 : 0) : (v ? 7 : 8);  // (the last tile has no later one: 7 is free)
-                    const unsigned long long below = (1ull << lane) - 1ull;
-                    int rank = 0, base = 0;
+                    Rs[buf * 64 + rank] = (f32x4){r.x, r.y, r.z, r.a};
+                    Js[buf * 64 + rank] = j;
+                    if (order_on) Ts[rank] = tm;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (order_on) {
+                        tm = Ts[lane];
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) {
-                        const unsigned long long bk = __ballot(key == k);
-                        if (key == k) rank = base + (int)__popcll(bk & below);
-                        base += (int)__popcll(bk);
+                        for (int mt = 0; mt < kMaxKT; ++mt) r.need[mt] = __ballot((tm >> mt) & 1u);
                     }
-                    const int dst = rank << 2;
-                    r.x = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.x)));
-                    r.y = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.y)));
-                    r.z = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.z)));
-                    r.a = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(r.a)));
-                    j = __builtin_amdgcn_ds_permute(dst, j);
-                    tm = (uint32_t)__builtin_amdgcn_ds_permute(dst, (int)tm);
-#pragma unroll
-                    for (int mt = 0; mt < kMaxKT; ++mt) r.need[mt] = dbg == 1 ? ~0ull : (dbg == 2 ? 0ull : __ballot((tm >> mt) & 1u));
                 };
                 if (nb > 0) {
                 int j0, j1;
@@ -263,32 +282,33 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
                 ld_idx(1, j1, nv1, v1);
                 ld_pos(j0, v0, px, py, pz);
                 PairRec cur = geom(j0, nv0, v0, px, py, pz);
-                order(cur, j0, v0);
+                stage(cur, j0, v0, 0);
                 int curj = j0;
                 int np_cur = (int)min((int64_t)64, re - rb);
                 // three quarter-batch feature buffers rotate: a load has two quarters of MFMAs to land
                 float fA[4], fB[4], fC[4];
-                issue(curj, np_cur, 0, fA);
-                issue(curj, np_cur, 4, fB);
+                issue(curj, 0, np_cur, 0, fA);
+                issue(curj, 0, np_cur, 4, fB);
                 ld_pos(j1, v1, px, py, pz);
                 for (int b = 0; b < nb; ++b) {
                     int j2;
                     float nv2;
                     bool v2;
                     ld_idx(b + 2, j2, nv2, v2);
-                    issue(curj, np_cur, 8, fC);
-                    run(cur, np_cur, 0, fA);
-                    issue(curj, np_cur, 12, fA);
-                    run(cur, np_cur, 4, fB);
+                    const int bc = b & 1, bn = bc ^ 1;
+                    issue(curj, bc, np_cur, 8, fC);
+                    run(cur, bc, np_cur, 0, fA);
+                    issue(curj, bc, np_cur, 12, fA);
+                    run(cur, bc, np_cur, 4, fB);
                     PairRec nxt = geom(j1, nv1, v1, px, py, pz);
-                    order(nxt, j1, v1);
+                    stage(nxt, j1, v1, bn);
                     const int nxtj = j1;
                     const int np_nxt = (int)min((int64_t)64, max((int64_t)0, re - rb - 64 * (int64_t)(b + 1)));
-                    issue(nxtj, np_nxt, 0, fB);
+                    issue(nxtj, bn, np_nxt, 0, fB);
                     ld_pos(j2, v2, px, py, pz);
-                    run(cur, np_cur, 8, fC);
-                    issue(nxtj, np_nxt, 4, fC);
-                    run(cur, np_cur, 12, fA);
+                    run(cur, bc, np_cur, 8, fC);
+                    issue(nxtj, bn, np_nxt, 4, fC);
+                    run(cur, bc, np_cur, 12, fA);
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         fA[g] = fB[g];
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(kMThreads, 2) void cconv_mfma_kernel(const CconvPar
         float v = 0.0f;
 #pragma unroll
         for (int w = 0; w < kMWaves; ++w) v += red[((size_t)w * MTM + ptt) * ncol + o];
-        if (p.csplit & 255) {  // this chunk's share: cconv_mfma_sum_chunks adds the chunks in order, the bias and the value to accumulate to
+        if (p.csplit) {  // this chunk's share: cconv_mfma_sum_chunks adds the chunks in order, the bias and the value to accumulate to
             p.partial[((size_t)chunk_lo * p.n_out + ii) * cout + o] = v;
             continue;
         }
@@ -408,7 +428,7 @@ static MfmaCfg mfma_cfg(int K, int cin, int cout) {
     const size_t r = (size_t)kMWaves * MTM * 16 * c.NT;
     if (b < r) b = r;
     c.bfloats = b;
-    c.lds = (b + MTM) * sizeof(float);
+    c.lds = (b + MTM) * sizeof(float) + (size_t)kMWaves * kMStage;
     c.packed_floats = (size_t)c.nchunks * c.nblocks * 4 * c.NT * 16 * 4;
     return c;
 }
@@ -460,7 +480,7 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
     p.tiles_per_xcd = (int)((ntiles + 7) / 8);
     const unsigned grid = (unsigned)p.tiles_per_xcd * 8u;
     const size_t partial = (a->flags & DMCF_FLAG_NORMALIZE) ? 0 : cconv_mfma_partial_floats(p.K, p.cin, p.cout, p.n_out);
-    p.csplit = (partial ? 1 : 0) | ((getenv("DMCF_MFMA_DEBUG") ? atoi(getenv("DMCF_MFMA_DEBUG")) : 0) << 8);
+    p.csplit = partial ? 1 : 0;
     p.partial = partial ? packed + align_up(cfg.packed_floats, 64) : nullptr;
     const bool generic = !(a->coordinate_mapping == DMCF_MAP_BALL_TO_CUBE_VOLUME_PRESERVING &&
                            a->interpolation == DMCF_INTERP_LINEAR && (a->flags & DMCF_FLAG_ALIGN_CORNERS));
@@ -487,12 +507,12 @@ int cconv_mfma_launch(CconvParams p, const dmcf_cconv_args* a, int dz, int dy, i
         return DMCF_ELAUNCH;
     }
     void* kargs[] = {(void*)&p};
-    e = hipLaunchKernel(fn, dim3(grid, (p.csplit & 255) ? (unsigned)p.nchunks : 1u), dim3(kMThreads), kargs, cfg.lds, stream);
+    e = hipLaunchKernel(fn, dim3(grid, p.csplit ? (unsigned)p.nchunks : 1u), dim3(kMThreads), kargs, cfg.lds, stream);
     if (e != hipSuccess) {
         g_last_hip_error = (int)e;
         return DMCF_ELAUNCH;
     }
-    if (p.csplit & 255) {
+    if (p.csplit) {
         const int64_t total = p.n_out * p.cout;
         hipLaunchKernelGGL(cconv_mfma_sum_chunks, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p.partial, p.nchunks, p.n_out,
                            p.cout, p.bias, p.out, (p.flags & DMCF_FLAG_ACCUMULATE) ? 1 : 0);

@@ -1,5 +1,4 @@
-# the small configurations after a kernel / dispatch change: parity tests of the 2-D models, then the three long rollouts
+# the small configurations after a kernel / dispatch change: parity tests of the 2-D models, then the long rollouts
 OUT=${1:-gpurun_out/r05s}; mkdir -p $OUT
-timeout 1200 python -m pytest tests/test_gpu_ops.py -q -x -k "mfma or matrix_core or cconv" 2>&1 | tail -n 3
-timeout 1500 python -m pytest tests/test_gpu_model.py -q -x -k "config or rollout" 2>&1 | tail -n 3
+timeout 1500 python -m pytest tests/test_gpu_model.py -q -x -k "config or rollout" 2>&1 | tail -n 2
 for r in "waterramps 600" "wbcsph 3200"; do set -- $r; timeout 900 python tools/long_rollout.py $1 $2 --out $OUT/rollout_$1.json >> $OUT/rollouts.log 2>&1; tail -n 1 $OUT/rollouts.log | cut -c1-600; done
