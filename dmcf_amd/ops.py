@@ -340,7 +340,7 @@ def frs_flags(ignore_query_point):
 
 
 def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True,
-                        hash_table=None, capacity_hint=None, row_stride=None):
+                        hash_table=None, capacity_hint=None, row_stride=None, max_count=None):
     """-> NeighborSearchResult(neighbors_index int32 [P], neighbors_row_splits int64 [m+1],
     neighbors_distance float32 [P] (squared L2; empty if not return_distances)).
 
@@ -384,7 +384,8 @@ def fixed_radius_search(points, queries, radius, ignore_query_point=False, retur
         index = torch.empty(cap, dtype=torch.int32, device=dev)
         dist = torch.empty(cap if return_distances else 0, dtype=torch.float32, device=dev)
         counts = torch.empty(m, dtype=torch.int32, device=dev)
-        max_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        if max_count is None:  # (a caller with many searches per step hands out slots of ONE zeroed tensor: a fill less per search)
+            max_count = torch.zeros(1, dtype=torch.int32, device=dev)
         t0 = timer.begin() if timer is not None else None  # (after the allocations: a hipMalloc is not kernel time)
         _lib.check(L.dmcf_frs_search_padded(_ptr(queries), m, n, radius, flags, _ptr(ws), nbytes, stride, _ptr(row_splits),
                                             _ptr(counts), _ptr(index), _ptr(dist) if return_distances else None,
@@ -442,14 +443,14 @@ class FixedRadiusSearch:
         self.max_hash_table_size = max_hash_table_size
 
     def __call__(self, points, queries, radius, points_row_splits=None, queries_row_splits=None,
-                 hash_table_size_factor=1 / 64, hash_table=None, capacity_hint=None, row_stride=None):
+                 hash_table_size_factor=1 / 64, hash_table=None, capacity_hint=None, row_stride=None, max_count=None):
         if points_row_splits is not None or queries_row_splits is not None:
             raise NotImplementedError("batched row_splits are not used by DMCF (batch items are looped, "
                                       "pipelines/simulator.py:68-70)")
         if isinstance(radius, torch.Tensor):
             radius = float(radius)
         return fixed_radius_search(points, queries, radius, self.ignore_query_point, self.return_distances,
-                                   hash_table=hash_table, capacity_hint=capacity_hint, row_stride=row_stride)
+                                   hash_table=hash_table, capacity_hint=capacity_hint, row_stride=row_stride, max_count=max_count)
 
     call = __call__
 

@@ -97,6 +97,7 @@ class _NeighborCache:
                 r.release()
             if exc_type is None:
                 self.expect = dict(self.uses)
+            self._maxc = None
             self.uses = {}
             self.slot_of = {}
             from .. import lattice
@@ -117,12 +118,22 @@ class _NeighborCache:
             if exc_type is None and pending:
                 # one synchronisation per step: validate the estimated capacities, refresh the estimates (the longest row and
                 # the number of pairs of every list)
-                def stats(r):
-                    if isinstance(r, ops.PaddedNeighborList):
-                        return torch.stack([r.max_count[0].long(), r.total_ref.long()])
-                    rs = r.neighbors_row_splits
-                    return torch.stack([torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(()), rs[-1]])
-                vals = torch.stack([stats(r) for _, _, r in pending]).tolist()
+                # (the padded lists' numbers are gathered by four small launches for all of them, not three per list)
+                pad = [k for k, (_, _, r) in enumerate(pending) if isinstance(r, ops.PaddedNeighborList)]
+                oth = [k for k, (_, _, r) in enumerate(pending) if not isinstance(r, ops.PaddedNeighborList)]
+                parts = []
+                if pad:
+                    parts.append(torch.cat([pending[k][2].max_count for k in pad]).long())
+                    parts.append(torch.stack([pending[k][2].total_ref for k in pad]).long())
+                for k in oth:
+                    rs = pending[k][2].neighbors_row_splits
+                    parts.append(torch.stack([torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(()), rs[-1]]))
+                flat = torch.cat(parts).tolist()
+                vals = [None] * len(pending)
+                for i, k in enumerate(pad):
+                    vals[k] = (flat[i], flat[len(pad) + i])
+                for i, k in enumerate(oth):
+                    vals[k] = (flat[2 * len(pad) + 2 * i], flat[2 * len(pad) + 2 * i + 1])
                 fresh, tot = {}, {}
                 over = []
                 for (hkey, slot, r), (mx, total) in zip(pending, vals):
@@ -150,6 +161,14 @@ class _NeighborCache:
     @staticmethod
     def _key(t):
         return (t.data_ptr(), tuple(t.shape), t._version)
+
+    def _max_count_slot(self, device):
+        """One element of a tensor zeroed once per step: where a padded search leaves its longest row (a fill per search otherwise)."""
+        pool = getattr(self, "_maxc", None)
+        if pool is None or pool[1] >= pool[0].shape[0] or pool[0].device != device:
+            pool = self._maxc = [torch.zeros(64, dtype=torch.int32, device=device), 0]
+        pool[1] += 1
+        return pool[0][pool[1] - 1: pool[1]]
 
     def _flush(self):
         for r in self.done:
@@ -230,7 +249,8 @@ class _NeighborCache:
                 # count + scan + write into a buffer sized from the previous step's pairs -- still no host round trip.
                 res = frs(points, queries, radius, hash_table=table, capacity_hint=total + total // 4)
             else:
-                res = frs(points, queries, radius, hash_table=table, row_stride=stride, capacity_hint=self.caps.get(slot))
+                res = frs(points, queries, radius, hash_table=table, row_stride=stride, capacity_hint=self.caps.get(slot),
+                          max_count=self._max_count_slot(points.device))
                 self.caps[slot] = getattr(res, "capacity", None)
         else:
             res = frs(points, queries, radius, hash_table=table)

@@ -10,7 +10,7 @@ from dmcf_amd import ops
 
 def install(monkeypatch):
     def fixed_radius_search(points, queries, radius, ignore_query_point=False, return_distances=True, hash_table=None,
-                            capacity_hint=None, row_stride=None):
+                            capacity_hint=None, row_stride=None, max_count=None):
         idx, rs, d = O.fixed_radius_search(points.numpy(), queries.numpy(), radius, ignore_query_point)
         return ops.NeighborSearchResult(torch.from_numpy(idx), torch.from_numpy(rs), torch.from_numpy(d), total=len(idx))
 

@@ -1217,7 +1217,7 @@ def test_reserve_device_memory(dev):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("n,n_boxes", [(1, 1), (777, 3), (50000, 7)])
+@pytest.mark.parametrize("n,n_boxes", [(0, 2), (1, 1), (777, 3), (50000, 7)])
 def test_ghost_select_equals_the_host_form(n, n_boxes):
     """dmcf_ghost_count / dmcf_ghost_write against the torch form the sharded rollout used for every ghost plan
     (parallel._gap2_all + nonzero): the same lists, box-major then ascending point index, for all widths at once."""
