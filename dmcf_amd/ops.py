@@ -850,6 +850,9 @@ GRID_MAX_CELLS_PER_POINT = 64
 GRID_MIN_CELLS = 1 << 22
 
 
+_GRID_CELLS = {}  # (voxel sizes of the levels, flags) -> cells of each level's box at the last call: grid_pos_many's estimates
+
+
 class GridTooSparse(RuntimeError):
     """The bounding box of the candidate cells has more than GRID_MAX_CELLS cells (a few particles very far apart):
     the caller uses the sort-based device formulation instead."""
@@ -874,27 +877,53 @@ def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=No
         _lib.check(L.dmcf_grid_pos_bounds(_ptr(pos), n, vs, cflag, _ptr(cen) if cen is not None else None, int(pad),
                                           float(hyst), _ptr(ws), ws_bytes, _stream()), "dmcf_grid_pos_bounds")
         levels.append(dict(vs=vs, ws=ws))
-    hdrs = torch.stack([lv["ws"][0:64] for lv in levels]).cpu()  # (host round trip 1 of 2: every level's header)
-    for lv, hdr in zip(levels, hdrs):
-        lv["center_host"] = hdr[40:52].view(torch.float32).tolist()
-        lv["minp"], lv["dims"] = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
-        cells = lv["cells"] = int(hdr[24:32].view(torch.int64).item())
-        if cells < 0:
-            raise _lib.DmcfError("grid_pos: positions are not finite")
-        if cells > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
-            raise GridTooSparse(f"{cells} lattice cells in the bounding box")
-    for lv in levels:
-        lv["table"] = torch.empty(max(lv["cells"], 1), dtype=torch.int32, device=pos.device)
+    def read_headers():
+        hdrs = torch.stack([lv["ws"][0:64] for lv in levels]).cpu()
+        for lv, hdr in zip(levels, hdrs):
+            lv["center_host"] = hdr[40:52].view(torch.float32).tolist()
+            lv["minp"], lv["dims"] = hdr[0:12].view(torch.int32).tolist(), hdr[12:24].view(torch.int32).tolist()
+            lv["cells"] = int(hdr[24:32].view(torch.int64).item())
+            lv["total"] = int(hdr[32:40].view(torch.int64).item())
+            if lv["cells"] < 0:
+                raise _lib.DmcfError("grid_pos: positions are not finite")
+            if lv["cells"] > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
+                raise GridTooSparse(f"{lv['cells']} lattice cells in the bounding box")
+
+    def count(lv, capacity):
+        lv["table"] = torch.empty(max(capacity, 1), dtype=torch.int32, device=pos.device)
+        lv["capacity"] = capacity
         _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, lv["vs"], cflag, int(pad), float(hyst), _ptr(lv["ws"]), ws_bytes,
-                                         _ptr(lv["table"]), lv["cells"], _stream()), "dmcf_grid_pos_count")
-    totals = torch.stack([lv["ws"][32:40] for lv in levels]).cpu()  # (host round trip 2 of 2: every level's point count)
+                                         _ptr(lv["table"]), capacity, _stream()), "dmcf_grid_pos_count")
+
+    # A rollout asks for the same levels step after step and their boxes move slowly: with the cell count of the last call as an
+    # estimate (+ 1/4, in size classes) the count pass runs BEFORE anything is read, and ONE host round trip brings header and point
+    # count of every level; a level whose box outgrew its table is counted again with the exact size (a second round trip, rare).
+    key = (tuple(tuple(float(x) for x in lv["vs"]) for lv in levels), bool(centralize), int(pad), float(hyst))
+    est = _GRID_CELLS.get(key)
+    if est is not None and len(est) == len(levels):
+        for lv, c in zip(levels, est):
+            count(lv, _size_class(c + c // 4))
+        read_headers()
+        again = [lv for lv in levels if lv["cells"] > lv["capacity"]]
+        for lv in again:
+            count(lv, lv["cells"])
+        if again:
+            read_headers()
+    else:
+        read_headers()  # (host round trip 1 of 2: every level's header)
+        for lv in levels:
+            count(lv, lv["cells"])
+        read_headers()  # (host round trip 2 of 2: every level's point count)
+    while len(_GRID_CELLS) > 32:
+        _GRID_CELLS.pop(next(iter(_GRID_CELLS)))
+    _GRID_CELLS[key] = [lv["cells"] for lv in levels]
+    totals = [lv["total"] for lv in levels]
     res = []
-    for lv, tot in zip(levels, totals):
-        total = int(tot.view(torch.int64).item())
+    for lv, total in zip(levels, totals):
         out = torch.empty((total, 3), dtype=torch.float32, device=pos.device)
         if total:
             _lib.check(L.dmcf_grid_pos_write(_ptr(pos), n, lv["vs"], cflag, int(pad), float(hyst), _ptr(lv["ws"]), ws_bytes,
-                                             _ptr(lv["table"]), lv["cells"], _ptr(out), total, _stream()), "dmcf_grid_pos_write")
+                                             _ptr(lv["table"]), lv["capacity"], _ptr(out), total, _stream()), "dmcf_grid_pos_write")
             if centralize and center is None:
                 # out = float(cell) * voxel + mean(pos): every lattice built from these positions shares the centre exactly
                 # (dmcf_amd/lattice.py; the lattice form of ContinuousConv uses it)
