@@ -110,7 +110,9 @@ class PaddedNeighborList(NeighborSearchResult):
         """0-dim device tensor holding P (no synchronisation); summed once per list, not once per consumer."""
         t = getattr(self, "_total_ref", None)
         if t is None:
-            t = self._total_ref = self.row_count.sum()
+            # (an int32 tensor summed into int64 costs a cast launch and the reduction; rows x stride bounds the total on the host)
+            small = self.row_count.shape[0] * self.stride < 2 ** 31
+            t = self._total_ref = self.row_count.sum(dtype=torch.int32) if small else self.row_count.sum()
         return t
 
     def release(self):
