@@ -779,6 +779,8 @@ class ShardedSimulator:
                                        if float(r) * (1.0 + 1e-5) + 1e-6 <= float(width) * (1.0 + 1e-5) + 1e-6]
             if name == "s0":
                 widths += [self._lattice_margin(st) for st in m.strides if st != 1]
+            if len({round(float(w), 9) for w in widths}) > 8:  # (dmcf_ghost_count takes 8 widths: the rarer ones are derived)
+                widths = sorted(widths, reverse=True)[:1] + sorted({float(np.float32(r)) for r in m.particle_radii}, reverse=True)[:7]
             plans = GhostPlan.build_fused(self.comm, self._mdecomp, pos, widths)
             wide = plans[round(float(width), 9)]
             for w, plan in plans.items():
@@ -905,7 +907,7 @@ class ShardedSimulator:
             adv, _ = m.integrate_pos_vel(pos0, vel0, acc)
             payload = torch.cat([pos0, vel0] + ([acc] if acc is not None else []), dim=1)
             fused = os.environ.get("DMCF_SHARD_FUSED", "1")
-            if fused == "force" or (fused != "0" and adv.is_cuda):
+            if comm.world <= 64 and (fused == "force" or (fused != "0" and adv.is_cuda)):  # (dmcf_ghost_count takes 64 boxes)
                 # the selection kernels with the ownership test (csrc/ghost.hip): rows per owner and the stable order by owner
                 sel = ops.ghost_select(adv, _boxes_tensor(self.decomp, list(range(comm.world)), adv.device), [-1.0])
                 counts = host(sel.totals[0])
