@@ -730,15 +730,19 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
         # is still valid and is not formed again (DMCF_FLAG_FILTER_PACKED: one launch less per layer and step)
         name = ctypes.create_string_buffer(96)
         L.dmcf_cconv_kernel_name(ctypes.byref(a), name, 96)
-        key = (filters.data_ptr(), filters._version, tuple(filters.shape), bool(symmetric), int(sym_axis), name.value, str(filters.device))
+        # Identity of the filter VALUES: the tensor object itself (held by the cache, so neither its address nor its id can be
+        # reused by another tensor while the entry lives) + its version counter.  In-place writes through autograd-visible
+        # calls (copy_, load_state_dict, optimiser steps) bump the counter; a write through ``.data`` does not -- after one,
+        # call ``layer.invalidate_packed()``.  Derived tensors (a fresh object per call) never hit.
+        key = (filters._version, tuple(filters.shape), bool(symmetric), int(sym_axis), name.value, str(filters.device))
         ws = packed_cache.get("ws")
-        if packed_cache.get("key") == key and ws is not None and ws.numel() >= nbytes:
+        if packed_cache.get("src") is filters and packed_cache.get("key") == key and ws is not None and ws.numel() >= nbytes:
             a.flags |= FLAG_FILTER_PACKED
         else:
             # (the workspace of a small launch also holds scratch that grows with n_out: a quarter of headroom, so that a scene
             # whose point counts drift does not repack every step)
             ws = torch.empty(nbytes + nbytes // 4, dtype=torch.uint8, device=filters.device)
-            packed_cache["key"], packed_cache["ws"] = key, ws
+            packed_cache["key"], packed_cache["ws"], packed_cache["src"] = key, ws, filters
         nbytes = ws.numel()
     if ws is None:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)

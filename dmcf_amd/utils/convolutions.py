@@ -464,8 +464,18 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
         self.extra_bias = None
         self._packed = {}  # the workspace of the last dmcf_cconv_forward and what its packed filter was made from (ops.cconv_forward)
 
+    def invalidate_packed(self):
+        """Drops the cached packed filter (ops.cconv_forward).  Needed only after writing the weights through ``.data`` --
+        the one way to change a tensor that its version counter does not see."""
+        self._packed.clear()
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._packed.clear()
+        return super()._load_from_state_dict(*args, **kwargs)
+
     # -- weights (lazy, from the first input's channel count: convolutions.py:228-275) ----------------
     def build(self, in_channels, device=None):
+        self._packed.clear()
         device = device or self._device or "cuda"
         self.in_channels = int(in_channels)
         if self.circular:
@@ -631,7 +641,8 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
             bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=n_pairs_ref,
             neighbors_row_count=row_count, skip_self=skip_self, row_length_hint=self.row_length_hint,
             out=acc, accumulate=acc is not None,
-            packed_cache=self._packed if os.environ.get("DMCF_CACHE_PACKED_FILTERS", "1") != "0" else None)
+            packed_cache=self._packed if (kernel is self.kernel and os.environ.get("DMCF_CACHE_PACKED_FILTERS", "1") != "0")
+            else None)  # (a derived filter tensor -- circular -- is a new object every call: never cached)
         if self._direct_kernel is None and in_step and self.radius_search_ignore_query_points:
             # (asked once per layer: the dispatch looks at the layer, never at the list)
             self._direct_kernel = ops.cconv_forward(

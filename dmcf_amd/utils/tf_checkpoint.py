@@ -132,6 +132,8 @@ def _assign(module, attr, value, device):
     import torch
     t = torch.from_numpy(np.array(value, copy=True)).to(device)
     setattr(module, attr, torch.nn.Parameter(t, requires_grad=False))
+    if hasattr(module, "invalidate_packed"):
+        module.invalidate_packed()
 
 
 def model_weight_items(model):

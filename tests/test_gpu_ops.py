@@ -1106,9 +1106,28 @@ def test_packed_filter_is_kept_between_calls_and_redone_when_the_weights_change(
         y4 = conv(feat, pos, pos, 0.3)
     finally:
         os.environ.pop("DMCF_CCONV_KERNEL")
-    assert conv._packed["key"][5] != key1[5] and torch.allclose(y4, y3, rtol=1e-4, atol=1e-5 * float(y3.abs().max()))
+    assert conv._packed["key"][4] != key1[4] and torch.allclose(y4, y3, rtol=1e-4, atol=1e-5 * float(y3.abs().max()))
     y5 = conv(feat, pos, pos, 0.3)
     assert torch.equal(y5, y3)
+    # a NEW parameter object with other values (tf_checkpoint._assign; usually lands on the old one's address): seen, because the
+    # cache holds the tensor it packed, not its address
+    old = conv.kernel
+    conv.kernel = torch.nn.Parameter(old.detach() * 0.5, requires_grad=False)
+    del old
+    y6 = conv(feat, pos, pos, 0.3)
+    assert conv._packed["src"] is conv.kernel and torch.allclose(y6, y1, rtol=1e-6, atol=0)
+    # a write through .data is the one change the version counter misses: invalidate_packed() is the documented remedy
+    conv.kernel.data.mul_(2.0)
+    conv.invalidate_packed()
+    y7 = conv(feat, pos, pos, 0.3)
+    assert torch.allclose(y7, y3, rtol=1e-6, atol=0)
+    # load_state_dict drops the entry too
+    sd = {k: v.clone() for k, v in conv.state_dict().items()}
+    sd["kernel"] = sd["kernel"] * 0.5
+    conv.load_state_dict(sd)
+    assert not conv._packed
+    y8 = conv(feat, pos, pos, 0.3)
+    assert torch.allclose(y8, y1, rtol=1e-6, atol=0)
 
 
 @pytest.mark.parametrize("cin,cout,ks,dim", [(24, 8, (1, 8, 8), 2), (32, 64, (1, 4, 4), 2), (40, 24, (4, 4, 4), 3)])
