@@ -128,6 +128,15 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-side", type=int, default=None,
                     help="edge of the CPU-baseline box (default: --side, i.e. ONE step of the CPU oracle on the bench's own scene -- "
                          "about a minute of the host's cores at 1M particles; smaller = a bounded sample from the same generator; 0 = skip)")
+    ap.add_argument("--config", default="box", choices=["box", "waterramps", "wbcsph", "liquid3d_dam"],
+                    help="box (default) = BASELINE.json config 5, the headline; the others = configs 2 / 3 / 4 on one GPU "
+                         "(tools/long_rollout.py's scenes): the same JSON line with dispatches and synchronising reads per step")
+    ap.add_argument("--scene", default="column", choices=["column", "settled"],
+                    help="--config box only.  column (default, the headline): config 5 as specified -- a 5 m column under g, far outside "
+                         "the network's training range, which dissolves inside the window.  settled: the same box, particles and "
+                         "network with the particles at rest and gravity scaled by --settled-gravity, so that the state the "
+                         "kernels are timed on is stationary")
+    ap.add_argument("--settled-gravity", type=float, default=0.05, help="--scene settled: fraction of g = -9.81")
     ap.add_argument("--layers-json", default=None, help="write the per-launch table here")
     ap.add_argument("--reserve-gib", type=float, default=None,
                     help="Simulator(reserve_gib=...) in GiB (default: the product's opt-in 'auto' rule, 40 KiB per particle handed "
@@ -221,9 +230,156 @@ def cited_traffic(kernel):
     return best
 
 
+SMALL_CONFIGS = {
+    "waterramps": "BASELINE.json config 2 (WaterRamps 2-D, ~2k particles, 600-step rollout): the WaterRamps SymNet (configs/WaterRamps.yml) "
+                  "on a 45 x 45 = 2025-particle 2-D box + shell, seeded stand-in weights (the reference's blob is missing)",
+    "wbcsph": "BASELINE.json config 3 (WBC-SPH 2-D, 3200-step rollout): the WBC-SPH SymNet (configs/WBC-SPH.yml, 4 scales, grav_eqvar) on a "
+              "60 x 60 = 3600-particle 2-D box + shell, seeded stand-in weights (the reference's blob is missing)",
+    "liquid3d_dam": "BASELINE.json config 4 (Liquid3d 3-D, ~100k particles): a 50 x 40 x 50 = 100,000-particle dam break in an open tank, "
+                    "Liquid3d SymNet with the reference's checkpoint weights",
+}
+
+
+def small_config_main(args):
+    """``--config waterramps | wbcsph | liquid3d_dam``: BASELINE.json configs 2 / 3 / 4 on one GPU, the same JSON line.  These
+    steps are paced by dispatch count and host reads, not by any kernel, so the line also carries the GPU kernel dispatches and
+    the synchronising device -> host reads of ONE step (counted on an extra step after the timed window).  The timed window
+    runs as Simulator.run_rollout runs its loop (inside steady_steps) WITHOUT the per-launch events; the per-kernel table comes
+    from a second, untimed pass of the same length."""
+    import warnings
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the DMCF hot path has no CPU fallback)")
+    from dmcf_amd import models, ops
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.pipelines.simulator import steady_steps
+    from dmcf_amd.utils import tf_checkpoint as tc
+    from tools import long_rollout, scenes
+    dev = torch.device("cuda", 0)
+    cfg, w, scene, grav = long_rollout.setup(args.config)
+    model = getattr(models, cfg["name"])(**cfg)
+    tc.load_into_model(model, w, device=dev)
+    sim = Simulator(model, device="cuda:0", reserve_gib="auto" if args.reserve_gib is None else args.reserve_gib)
+    state = scenes.model_inputs(scene, device=dev, grav=grav)
+    n = int(state[0].shape[0])
+    lo = torch.tensor(scene["box"].min(axis=0), device=dev)
+    hi = torch.tensor(scene["box"].max(axis=0), device=dev)
+    if args.config == "liquid3d_dam":
+        hi[1] = 3.0e38  # the tank is open at the top
+    if scene["box"][:, 2].max() == scene["box"][:, 2].min():
+        lo[2], hi[2] = -3.0e38, 3.0e38  # 2-D scenes
+    for _ in range(args.warmup):
+        state = sim.step([state])[0]
+    snap0 = scene_snapshot(state[0], state[1], lo, hi)
+    rep0 = sim.repeated_steps
+    allocs0 = torch.cuda.memory_stats(dev).get("num_device_alloc", 0)
+    with steady_steps() as steady:
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            state = sim.step([state])[0]
+            steady.tick()
+        torch.cuda.synchronize(dev)
+        elapsed = time.perf_counter() - t0
+        snap1 = scene_snapshot(state[0], state[1], lo, hi)
+        repeated = sim.repeated_steps - rep0
+        allocs = torch.cuda.memory_stats(dev).get("num_device_alloc", 0) - allocs0
+        assert torch.isfinite(state[0]).all()
+        # ---- untimed: one step's synchronising reads and kernel dispatches
+        torch.cuda.set_sync_debug_mode("warn")
+        with warnings.catch_warnings(record=True) as ws:
+            warnings.simplefilter("always")
+            state = sim.step([state])[0]
+        torch.cuda.set_sync_debug_mode("default")
+        sync_sites = {}
+        for wv in ws:
+            k = f"{os.path.basename(wv.filename)}:{wv.lineno}"
+            sync_sites[k] = sync_sites.get(k, 0) + 1
+        dispatches = None
+        try:
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                state = sim.step([state])[0]
+                torch.cuda.synchronize(dev)
+            kinds = {}
+            for e in prof.events():
+                if getattr(e, "device_type", None) is not None and "cuda" in str(e.device_type).lower():
+                    kinds[e.name] = kinds.get(e.name, 0) + 1
+            memops = sum(v for k, v in kinds.items() if k.lower().startswith(("memcpy", "memset")))
+            dispatches = dict(kernels=sum(kinds.values()) - memops, memcpy_memset=memops)
+        except Exception as e:  # (the count is a diagnostic: never fail the line for it)
+            dispatches = dict(error=f"{type(e).__name__}: {e}")
+        # ---- untimed: the same number of steps with HIP events around every library launch -> per-kernel table, per-step times
+        ops.timer = ops.LaunchTimer()
+        marks, step_ms = [], []
+        for _ in range(args.steps):
+            marks.append(len(ops.timer.records))
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            state = sim.step([state])[0]
+            torch.cuda.synchronize(dev)
+            step_ms.append(1e3 * (time.perf_counter() - t1))
+            steady.tick()
+        timer, ops.timer = ops.timer, None
+    recs = timer.results()
+    table, dominant = summarise(recs, args.steps)
+    dom = table["by_kernel"].get(dominant, dict(achieved=0.0, frac=0.0, launches=0, avg_launch_ms=0.0, algorithmic_bytes_per_launch=0.0))
+    other = {}
+    for k, m, ms in recs:
+        other[k] = other.get(k, 0.0) + ms
+    line = {
+        "metric": "rollout_particle_steps_per_sec", "value": n * args.steps / elapsed, "unit": "particle-steps/s", "n_gpus": 1,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": SMALL_CONFIGS[args.config] + f"; {n} fluid + {int(state[4].shape[0])} boundary particles, one rollout step",
+                   "parallelism": "single GPU", "particles_per_gpu": n},
+        "roofline": {"bound": "hbm", "kernel": f"dmcf::{dominant}", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": dom["frac"], "traffic": None, "launches": dom["launches"], "avg_launch_ms": dom["avg_launch_ms"],
+                     "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "frac_flops": dom.get("frac_flops"),
+                     "note": "from the instrumented pass; a step of this size is bound by dispatches and host reads, not by this kernel"},
+        "roofline_groups": table,
+        "kernel_ms_per_step": {k: v / args.steps for k, v in other.items()},
+        "library_launch_ms_per_step": sum(other.values()) / args.steps,
+        "dispatches_per_step": dispatches,
+        "synchronising_reads_per_step": {"count": len(ws), "sites": sync_sites},
+        "step_ms_instrumented": {"median": float(np.median(step_ms)), "first": float(step_ms[0]), "last": float(step_ms[-1]),
+                                 "note": "second pass, one device synchronise per step and events around every library launch"},
+        "scene_state": {"simulated_steps_before_window": args.warmup, "simulated_steps_at_end": args.warmup + args.steps,
+                        "fluid_outside_shell_at_window_start": snap0[0], "fluid_outside_shell_at_end": snap1[0],
+                        "max_speed_at_window_start": snap0[1], "max_speed_at_end": snap1[1],
+                        "repeated_steps_in_window": repeated, "device_allocations_in_window": int(allocs),
+                        "reserved_gib": torch.cuda.memory_stats(dev)["reserved_bytes.all.current"] / 2 ** 30},
+    }
+    if args.cpu_side is None or args.cpu_side > 0:
+        # the CPU oracle on the same scene from its initial state: whole steps until ~10 s are spent (at most 40)
+        import oracle  # noqa: F401
+        from oracle.model_ref import ModelRef
+        ref = ModelRef(cfg, w)
+        data = scenes.model_inputs(scene, grav=grav)
+        t1, k = time.time(), 0
+        while k < 40 and (k == 0 or time.time() - t1 < 10.0):
+            p, v = ref.step(data)
+            data = [p, v] + data[2:]
+            k += 1
+        dt = time.time() - t1
+        line["cpu_baseline"] = dict(value=n * k / dt, unit="particle-steps/s", cores=len(os.sched_getaffinity(0)), kind="port",
+                                    sample=f"{k} consecutive step(s) of the CPU oracle (oracle/model_ref.py: numpy + OpenMP C restatement "
+                                           f"of the Open3D CPU algorithms; not TensorFlow/Open3D) on the same scene from its initial state, {dt:.1f} s")
+    if args.layers_json:
+        json.dump([dict(kind=k, ms=ms, **m) for k, m, ms in recs], open(args.layers_json, "w"))
+    print(json.dumps(line), flush=True)
+
+
 def main():
     args = parse_args()
     in_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if args.config != "box":
+        if args.gpus != 1:
+            raise SystemExit("--config waterramps / wbcsph / liquid3d_dam are single-GPU lines")
+        return small_config_main(args)
+    if args.scene == "settled" and args.gpus != 1:
+        raise SystemExit("--scene settled is a single-GPU line")
     if args.gpus > 1 and not in_launcher:
         # the driver's contract: plain `python bench.py --gpus N` -- start the N ranks ourselves
         raise SystemExit(subprocess.call(launcher_command(sys.argv[1:], args.gpus)))
@@ -284,10 +440,12 @@ def main():
     sim_kw = dict(reserve_gib="auto" if args.reserve_gib is None else args.reserve_gib)
     if not sharded:
         sim = Simulator(model, device=f"cuda:{local_rank}", **sim_kw)
-        scene = scenes.box_scene(args.side)
+        settled = args.scene == "settled"
+        scene = scenes.box_scene(args.side, vel_std=0.0 if settled else 0.1)
         n_fluid = scene["pos"].shape[0]
         n_total = n_fluid
-        state = scenes.model_inputs(scene, device=dev)
+        # (settled: gravity enters as the per-particle acceleration input, models/pbf_model.py:234-240 -- the model is untouched)
+        state = scenes.model_inputs(scene, device=dev, grav=[0.0, -9.81 * args.settled_gravity, 0.0] if settled else None)
         step = lambda st: sim.step([st])[0]  # noqa: E731
         par = "single GPU"
     else:
@@ -342,10 +500,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_marks = []
-    for _ in range(args.steps):
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # (device time stamps; nothing waits for them)
+    step_events[0].record()
+    for i in range(args.steps):
         if ops.timer is not None:
             step_marks.append(len(ops.timer.records))
         state = step(state)
+        step_events[i + 1].record()
         if os.environ.get("DMCF_BENCH_DEBUG"):
             torch.cuda.synchronize(dev)
             ms = torch.cuda.memory_stats(dev)
@@ -366,7 +527,13 @@ def main():
         v2 = torch.tensor([snap0[1], snap1[1]], dtype=torch.float64, device=dev)
         dist.all_reduce(v2, op=dist.ReduceOp.MAX)
         snap0, snap1, allocs = [int(t2[0]), float(v2[0])], [int(t2[1]), float(v2[1])], int(t2[2])
+    step_ms = [step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)]
+    q = max(args.steps // 4, 1)
+    extra["step_ms"] = {"first_quarter": float(np.mean(step_ms[:q])), "last_quarter": float(np.mean(step_ms[-q:])),
+                        "drift": float(np.mean(step_ms[-q:]) / np.mean(step_ms[:q]) - 1.0), "median": float(np.median(step_ms)),
+                        "note": "device time between consecutive steps' ends on the launch stream (rank 0's)"}
     extra["scene_state"] = {
+        "scene": args.scene if not sharded else "column",
         "simulated_steps_before_window": args.warmup, "simulated_steps_at_end": args.warmup + args.steps,
         "fluid_outside_shell_at_window_start": snap0[0], "fluid_outside_shell_at_end": snap1[0],
         "max_speed_at_window_start": snap0[1], "max_speed_at_end": snap1[1],
@@ -374,7 +541,9 @@ def main():
         "repeated_steps_in_window": None if sharded else sim.repeated_steps - repeated0,
         "device_allocations_in_window": int(allocs),
         "reserved_gib": torch.cuda.memory_stats(dev)["reserved_bytes.all.current"] / 2 ** 30,
-        "note": "config 5's 5 m column is far outside the network's training range: particles leak through the 2-layer shell "
+        "note": ("the box of config 5 with its particles at rest under %.3g g: a stationary state, for judging kernel work "
+                 "(the headline is --scene column)" % args.settled_gravity) if (not sharded and args.scene == "settled") else
+                "config 5's 5 m column is far outside the network's training range: particles leak through the 2-layer shell "
                 "as the rollout goes on, rows lengthen and steps get slower (DESIGN.md section 4.1)"}
     if sharded:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -429,7 +598,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"synthetic 3-D box (BASELINE.json config 5), {n_fluid} fluid particles per GPU + closed 2-layer "
                                    f"boundary shell ({scene['box'].shape[0]} boundary particles on rank 0), Liquid3d SymNet (18 CConv/ASCC "
-                                   "layers, reference checkpoint weights), one rollout step",
+                                   "layers, reference checkpoint weights), one rollout step"
+                                   + (f"; SETTLED variant: particles at rest, gravity x {args.settled_gravity}" if (not sharded and args.scene == "settled") else ""),
                        "parallelism": par, "particles_per_gpu": n_fluid},
             "roofline": {"bound": "hbm", "kernel": f"dmcf::{dominant}", "achieved": dom["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": dom["frac"], "traffic": traffic, "traffic_source": traffic_source,
