@@ -78,11 +78,39 @@ class LatticeConvArgs(ctypes.Structure):
     ]
 
 
+class CconvScatterArgs(ctypes.Structure):
+    """struct dmcf_cconv_scatter_args (include/dmcf_hip.h)."""
+    _fields_ = [
+        ("filters", ctypes.c_void_p),
+        ("filter_dims", ctypes.c_int32 * 5),
+        ("out_positions", ctypes.c_void_p),
+        ("n_out", ctypes.c_int64),
+        ("inp_positions", ctypes.c_void_p),
+        ("n_inp", ctypes.c_int64),
+        ("inp_features", ctypes.c_void_p),
+        ("t_index", ctypes.c_void_p),
+        ("t_row_begin", ctypes.c_void_p),
+        ("t_row_count", ctypes.c_void_p),
+        ("t_capacity", ctypes.c_int64),
+        ("plan", ctypes.c_void_p),
+        ("block_cells", ctypes.c_int32),
+        ("reach", ctypes.c_int32),
+        ("extent", ctypes.c_float),
+        ("window_fac", ctypes.c_float),
+        ("window", ctypes.c_int32),
+        ("flags", ctypes.c_int32),
+        ("bias", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+        ("error_flag", ctypes.c_void_p),
+    ]
+
+
 # names every entry point include/dmcf_hip.h declares (tests/test_abi.py cross-checks against the header)
 SYMBOLS = [
     "dmcf_version", "dmcf_error_string", "dmcf_last_hip_error",
     "dmcf_frs_workspace_bytes", "dmcf_frs_build", "dmcf_frs_count", "dmcf_frs_write", "dmcf_frs_search_padded", "dmcf_frs_window_sum",
     "dmcf_cconv_workspace_bytes", "dmcf_cconv_forward", "dmcf_cconv_kernel_name",
+    "dmcf_cconv_scatter_plan_bytes", "dmcf_cconv_scatter_plan", "dmcf_cconv_scatter_workspace_bytes", "dmcf_cconv_scatter_forward",
     "dmcf_lattice_conv_workspace_bytes", "dmcf_lattice_conv_forward",
     "dmcf_lattice_conv_batch_workspace_bytes", "dmcf_lattice_conv_forward_batch",
     "dmcf_reduce_subarrays_sum", "dmcf_points_aabb_workspace_bytes", "dmcf_points_aabb", "dmcf_dense_forward",
@@ -138,6 +166,15 @@ def lib():
     L.dmcf_cconv_forward.argtypes = [c.POINTER(CconvArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_cconv_kernel_name.restype = c.c_int
     L.dmcf_cconv_kernel_name.argtypes = [c.POINTER(CconvArgs), c.c_char_p, c.c_size_t]
+    L.dmcf_cconv_scatter_plan_bytes.restype = c.c_size_t
+    L.dmcf_cconv_scatter_plan_bytes.argtypes = [c.c_int64]
+    L.dmcf_cconv_scatter_plan.restype = c.c_int
+    L.dmcf_cconv_scatter_plan.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_int64, c.c_float, c.c_float, c.c_int32, c.c_void_p,
+                                          c.c_size_t, c.c_void_p]
+    L.dmcf_cconv_scatter_workspace_bytes.restype = c.c_size_t
+    L.dmcf_cconv_scatter_workspace_bytes.argtypes = [c.POINTER(CconvScatterArgs)]
+    L.dmcf_cconv_scatter_forward.restype = c.c_int
+    L.dmcf_cconv_scatter_forward.argtypes = [c.POINTER(CconvScatterArgs), c.c_void_p, c.c_size_t, c.c_void_p]
     L.dmcf_lattice_conv_workspace_bytes.restype = c.c_size_t
     L.dmcf_lattice_conv_workspace_bytes.argtypes = [c.POINTER(LatticeConvArgs)]
     L.dmcf_lattice_conv_forward.restype = c.c_int

@@ -760,6 +760,96 @@ def cconv_forward(filters, out_positions, extent, inp_positions, inp_features, n
     return out
 
 
+class ScatterPlan:
+    """dmcf_cconv_scatter_plan's output (include/dmcf_hip.h): the input points counting-sorted by the block of ``block_cells``^3
+    lattice cells they lie in.  Depends on the two point sets, the lattice spacing and the radius only -- one plan serves every
+    layer of a step between the same two sets.  Built on the device without a host round trip."""
+
+    def __init__(self, buf, voxel, block_cells, reach, n_inp, keep):
+        self.buf, self.voxel, self.block_cells, self.reach, self.n_inp = buf, float(voxel), int(block_cells), int(reach), int(n_inp)
+        self._keep = keep  # (the operands the plan was made from)
+
+
+SCATTER_BLOCK_CELLS = 4  # m: blocks of m^3 lattice cells (0.4 units of the 0.1 lattice of Liquid3d: ~500 particles)
+
+
+def scatter_reach(radius, voxel):
+    return int(np.ceil(np.float32(radius) / np.float32(voxel) - 1e-4))
+
+
+def scatter_plan(inp_positions, out_positions, voxel, radius, block_cells=None):
+    L = _lib.lib()
+    inp = _dev_f32(inp_positions, "inp_positions", 3)
+    out = _dev_f32(out_positions, "out_positions", 3)
+    m = int(block_cells or SCATTER_BLOCK_CELLS)
+    n = inp.shape[0]
+    nbytes = L.dmcf_cconv_scatter_plan_bytes(n)
+    buf = torch.empty(nbytes, dtype=torch.uint8, device=inp.device)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(L.dmcf_cconv_scatter_plan(_ptr(inp), n, _ptr(out), out.shape[0], float(voxel), 2.0 * float(radius), m, _ptr(buf), nbytes,
+                                         _stream()), "dmcf_cconv_scatter_plan")
+    if timer is not None:
+        timer.end("scatter_plan", dict(n_points=n), t0)
+    return ScatterPlan(buf, voxel, m, scatter_reach(radius, voxel), n, (inp, out))
+
+
+def cconv_scatter_supported(filters, block_cells, reach):
+    """Does dmcf_cconv_scatter_forward take a layer of this shape (4x4x4 filter, 4 or 8 outputs, a box that fits the LDS)?"""
+    if tuple(filters.shape[:3]) != (4, 4, 4) or filters.shape[3] > 32 or filters.shape[4] not in (4, 8):
+        return False
+    return block_cells + 2 * reach + 1 <= (13 if filters.shape[4] == 4 else 11)
+
+
+def cconv_scatter_forward(filters, out_positions, extent, inp_positions, inp_features, t_index, t_row_begin, t_row_count, plan,
+                          window=None, window_fac=1.0, bias=None, out=None, accumulate=False, error_flag=None, n_pairs_ref=None):
+    """One call of dmcf_cconv_scatter_forward (splat S: filter first, input stationary, 64-bit fixed-point sums): the operator
+    of cconv_forward for particles -> coarse lattice layers with 4 or 8 output channels, walking the TRANSPOSED list (row j = the
+    output points within extent / 2 of input point j; ``t_row_count`` None for CSR row splits)."""
+    L = _lib.lib()
+    filters = _dev_f32(filters, "filters")
+    out_positions = _dev_f32(out_positions, "out_positions", 3)
+    inp_positions = _dev_f32(inp_positions, "inp_positions", 3)
+    cin, cout = int(filters.shape[3]), int(filters.shape[4])
+    inp_features = _dev_f32(inp_features, "inp_features", cin)
+    n_out, n_inp = out_positions.shape[0], inp_positions.shape[0]
+    if plan.n_inp != n_inp:
+        raise ValueError("the plan was made for another input point set")
+    if window not in (None, "poly6"):
+        raise NotImplementedError("cconv_scatter_forward: window must be None or 'poly6'")
+    if out is None:
+        if accumulate:
+            raise ValueError("accumulate=True needs an out tensor")
+        out = torch.empty((n_out, cout), dtype=torch.float32, device=filters.device)
+    elif out.shape != (n_out, cout) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out has the wrong shape / dtype / layout")
+    a = _lib.CconvScatterArgs()
+    a.filters = _ptr(filters)
+    for k in range(5):
+        a.filter_dims[k] = int(filters.shape[k])
+    a.out_positions, a.n_out = _ptr(out_positions), n_out
+    a.inp_positions, a.n_inp = _ptr(inp_positions), n_inp
+    a.inp_features = _ptr(inp_features)
+    a.t_index, a.t_row_begin = _ptr(t_index), _ptr(t_row_begin)
+    a.t_row_count = _ptr(t_row_count) if t_row_count is not None else None
+    a.t_capacity = int(t_index.shape[0])
+    a.plan = _ptr(plan.buf)
+    a.block_cells, a.reach = plan.block_cells, plan.reach
+    a.extent, a.window_fac, a.window = float(extent), float(window_fac), WINDOWS[window]
+    a.flags = FLAG_ALIGN_CORNERS | (FLAG_ACCUMULATE if accumulate else 0)
+    a.bias = _ptr(bias) if bias is not None else None
+    a.out = _ptr(out)
+    a.error_flag = _ptr(error_flag) if error_flag is not None else None
+    nbytes = L.dmcf_cconv_scatter_workspace_bytes(ctypes.byref(a))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=filters.device)
+    t0 = timer.begin() if timer is not None else None
+    _lib.check(L.dmcf_cconv_scatter_forward(ctypes.byref(a), _ptr(ws), nbytes, _stream()), "dmcf_cconv_scatter_forward")
+    if timer is not None:
+        pairs = n_pairs_ref if n_pairs_ref is not None else (t_row_count.sum() if t_row_count is not None else t_row_begin[-1])
+        timer.end("cconv", dict(pairs=pairs, n_out=n_out, cin=cin, cout=cout, K=64, symmetric=False,
+                                kernel=f"cconv_sct_kernel<{cout}>", pair_values=False, accumulate=bool(accumulate)), t0)
+    return out
+
+
 def continuous_conv(filters, out_positions, extents, offset, inp_positions, inp_features, inp_importance,
                     neighbors_index, neighbors_row_splits, neighbors_importance, align_corners=True,
                     coordinate_mapping="ball_to_cube_radial", interpolation="linear", normalize=True,

@@ -22,6 +22,12 @@ from .tools.losses import WindowFunction
 
 __all__ = ["ContinuousConv", "neighbor_cache"]
 
+# dmcf_cconv_scatter_forward (splat S) is taken for particles -> coarse-lattice layers with these output channel counts (8 is
+# implemented and tested but measures slower than the gather kernels: tools/bench_scatter.py) ...
+SCATTER_OUT_CHANNELS = (4,)
+SCATTER_MIN_INPUTS = 4096           # ... for point sets big enough to fill the device (small scenes are paced by launches),
+SCATTER_MAX_LATTICE_CELLS = 1 << 16  # and lattices whose cell coordinates stay exact in float32 arithmetic
+
 
 class _NeighborCache:
     """Per-step reuse of neighbour lists and grids.
@@ -57,6 +63,7 @@ class _NeighborCache:
         self.reports = []  # (int64 device tensor, callback(list) -> outgrown?) read with the step's one synchronisation (report())
         self.lists = {}
         self.tables = {}
+        self.plans = {}
         self.keepalive = []
         self.key = None
         self.states = {}  # key -> (hints, caps, expect) of the rollouts that are not the current one
@@ -104,6 +111,7 @@ class _NeighborCache:
             lattice.clear()
             self.lists.clear()
             self.tables.clear()
+            self.plans.clear()
             self.keepalive.clear()
             reports, self.reports = self.reports, []
             outgrown = False
@@ -183,6 +191,16 @@ class _NeighborCache:
         if self.expect.get(slot) == self.uses[slot]:
             self.lists.pop(key, None)
             self.done.append(res)
+
+    def scatter_plan(self, inp_positions, out_positions, voxel, radius, block_cells):
+        """dmcf_cconv_scatter_plan for this pair of point sets, once per step."""
+        key = (self._key(inp_positions), self._key(out_positions), float(radius), int(block_cells))
+        plan = self.plans.get(key) if self.depth > 0 else None
+        if plan is None:
+            plan = ops.scatter_plan(inp_positions, out_positions, voxel, radius, block_cells)
+            if self.depth > 0:
+                self.plans[key] = plan
+        return plan
 
     def with_query_points(self, frs, points, queries, radius):
         """For a search that ignores the query points (``frs.ignore_query_point``) over points == queries: the list of the
@@ -579,6 +597,26 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                 d["_conv_values"], d["_conv_output"] = None, (None if _CACHE.depth > 0 else out_features)
                 return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             radius = float(np.float32(0.5) * np.float32(extent))  # :353
+            sct = self._scatter_form(inp_features, inp_positions, out_positions, inp_importance, fixed_radius_search_hash_table,
+                                     radius)
+            if sct is not None:
+                # particles -> coarse lattice with 4 output channels: filter first, input stationary, over the TRANSPOSED list
+                # (dmcf_cconv_scatter_forward; DMCF_SCATTER_CONV=0 keeps the gather form) -- the list of the later
+                # lattice -> particles layers of the step, searched here if this layer is the first to ask for it
+                voxel, m = sct
+                tl = _CACHE.search(self.fixed_radius_search, out_positions, inp_positions, radius, distances=False)
+                t_idx, t_rb, _ = tl.raw()
+                d["nns"] = None
+                d["_n_out_last"] = out_positions.shape[0]
+                d["_pairs_last"] = tl.total_ref
+                fuse_bias = self.use_bias and not self.use_dense_layer_for_center
+                out_features = ops.cconv_scatter_forward(
+                    self.kernel, out_positions, extent, inp_positions, inp_features, t_idx, t_rb, getattr(tl, "row_count", None),
+                    _CACHE.scatter_plan(inp_positions, out_positions, voxel, radius, m), window=self.window_function.name,
+                    window_fac=self.window_function.fac, bias=self._epilogue_bias(fuse_bias, extra_bias), out=acc,
+                    accumulate=acc is not None, n_pairs_ref=tl.total_ref)
+                d["_conv_values"], d["_conv_output"] = None, (None if _CACHE.depth > 0 else out_features)
+                return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             if fixed_radius_search_hash_table is not None:
                 d["nns"] = self.fixed_radius_search(inp_positions, out_positions, radius,
                                                     hash_table=fixed_radius_search_hash_table)
@@ -687,6 +725,29 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
         if self.activation is not None:
             out_features = self.activation(out_features)
         return out_features
+
+    def _scatter_form(self, inp_features, inp_positions, out_positions, inp_importance, hash_table, radius):
+        """(voxel, block_cells) if dmcf_cconv_scatter_forward applies to this call: the outputs are a registered grid_pos lattice
+        with one spacing on all axes, the inputs are not a lattice of that family (then the stencil form applies), few output
+        channels, a 4x4x4 filter with the options that kernel implements, and the default (symmetric) neighbour set -- the
+        transposed list then holds the same pairs as the forward one."""
+        from .. import lattice
+        if (os.environ.get("DMCF_SCATTER_CONV", "1") == "0" or not lattice.enabled() or hash_table is not None
+                or inp_importance is not None or self.symmetric or self.circular or self.normalize
+                or not isinstance(self.window_function, WindowFunction) or self.window_function.name != "poly6"
+                or self.radius_search_ignore_query_points or self.radius_search_metric != "L2" or not inp_features.is_cuda
+                or self.kernel_size != [4, 4, 4] or self.in_channels > 32 or self.filters not in SCATTER_OUT_CHANNELS
+                or not self.align_corners or self.coordinate_mapping != "ball_to_cube_volume_preserving"
+                or self.interpolation != "linear" or inp_positions.shape[0] < SCATTER_MIN_INPUTS):
+            return None
+        info = lattice.lookup(out_positions)
+        if info is None or not (info.voxel[0] == info.voxel[1] == info.voxel[2]) or max(info.dims) > SCATTER_MAX_LATTICE_CELLS:
+            return None
+        reach = ops.scatter_reach(radius, info.voxel[0])
+        m = min(ops.SCATTER_BLOCK_CELLS, (13 if self.filters == 4 else 11) - 1 - 2 * reach)
+        if m < 1 or out_positions.shape[0] * 4 > inp_positions.shape[0]:
+            return None  # (a fine lattice: few pairs per flushed slot, the gather form is faster -- DESIGN.md section 4.2, splat S)
+        return info.voxel[0], m
 
     def _lattice_form(self, inp_features, inp_positions, out_positions, inp_importance, hash_table, extent):
         """The LatticePair for this call if dmcf_lattice_conv_forward applies: both position tensors registered grid_pos

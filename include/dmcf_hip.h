@@ -236,6 +236,63 @@ int dmcf_cconv_forward(const dmcf_cconv_args* args, void* workspace, size_t work
 int dmcf_cconv_kernel_name(const dmcf_cconv_args* args, char* name, size_t name_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * ml3d.ops.continuous_conv (utils/convolutions.py:414-431) FROM particles ONTO a coarse grid_pos lattice with few output
+ * channels -- the layers models/hrnet.py:83-93 builds for (input scale 0, output scale >= 1) with layer_channels[..][scale] of
+ * 4 or 8 (configs/Liquid3d.yml:11: [[16], [8], [4]] / [[32], [16], [8]]).  Same operator, other order of evaluation ("filter
+ * first", input stationary; dmcf_amd/csrc/cconv_sct.hip):  G_j = f_j . W once per INPUT point, then per pair the trilinear
+ * interpolation of G_j added into the output point.  It walks the TRANSPOSED neighbour list: row j = the output points within
+ * extent / 2 of input point j -- the list FixedRadiusSearch returns for (points = out_positions, queries = inp_positions), which
+ * holds the same pairs as the forward list when the search's neighbour set is symmetric (the default set of this library).
+ * Sums are formed in 64-bit fixed point (a term c enters as round(c * 2^s), 2^s * max_j |f_j|_1 * max |W| <= 2^30, both maxima
+ * formed on the device inside the call), so the result does not depend on the order of the additions: bit reproducible like
+ * every other kernel here, with LDS and global atomics doing the adds.
+ *
+ * dmcf_cconv_scatter_plan (once per pair of point sets and radius; every layer between them shares it) counting-sorts the input
+ * points by the block of block_cells^3 lattice cells they lie in (cell of a point = floor((x - out_positions[0]) / voxel)); all
+ * outputs a block reaches lie in a box of (block_cells + 2 reach + 1)^3 lattice cells whose 64-bit accumulators live in LDS and
+ * are flushed once per block.  No host round trip; points far outside the bulk (beyond a 128^3-block region around the mean) are
+ * handled one by one.  `plan` is caller-owned device memory of dmcf_cconv_scatter_plan_bytes(n_inp) bytes.
+ *
+ * Restrictions (DMCF_EUNSUPPORTED otherwise): 4x4x4 filters, cout 4 or 8, cin <= 32, DMCF_WINDOW_NONE / POLY6 evaluated from the
+ * positions, volume-preserving map, linear interpolation; flags: DMCF_FLAG_ALIGN_CORNERS (required) | DMCF_FLAG_ACCUMULATE;
+ * block_cells + 2 reach + 1 <= 13 at cout 4 (11 at cout 8): the box must fit the CU's LDS.
+ * workspace: dmcf_cconv_scatter_workspace_bytes (the 64-bit sums; zeroed by the call).  error_flag (optional device int32, the
+ * caller zeroes it): set to 1 when a pair fell outside its block's box, i.e. the plan was not made from these positions,
+ * voxel and radius -- the pair is then dropped.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dmcf_cconv_scatter_plan_bytes(int64_t n_inp);
+int dmcf_cconv_scatter_plan(const float* inp_positions, int64_t n_inp, const float* out_positions, int64_t n_out, float voxel,
+                            float extent, int32_t block_cells, void* plan, size_t plan_bytes, dmcf_stream_t stream);
+
+typedef struct dmcf_cconv_scatter_args {
+    const float* filters;          /* [4][4][4][cin][cout] */
+    int32_t filter_dims[5];
+    const float* out_positions;    /* [n_out][3], a lattice of spacing voxel */
+    int64_t n_out;
+    const float* inp_positions;    /* [n_inp][3] */
+    int64_t n_inp;
+    const float* inp_features;     /* [n_inp][cin] */
+    const int32_t* t_index;        /* transposed list: output indices, row j = input point j */
+    const int64_t* t_row_begin;    /* [n_inp + 1] CSR row splits, or [n_inp] row begins when t_row_count is given */
+    const int32_t* t_row_count;    /* optional [n_inp] (padded rows); NULL = CSR */
+    int64_t t_capacity;            /* entries t_index holds */
+    const void* plan;              /* dmcf_cconv_scatter_plan's output for these positions */
+    int32_t block_cells;           /* as passed to the plan */
+    int32_t reach;                 /* ceil(extent / 2 / voxel) */
+    float extent;
+    float window_fac;
+    int32_t window;
+    int32_t flags;
+    const float* bias;             /* [cout] or NULL */
+    float* out;                    /* [n_out][cout] */
+    int32_t* error_flag;
+} dmcf_cconv_scatter_args;
+
+size_t dmcf_cconv_scatter_workspace_bytes(const dmcf_cconv_scatter_args* args);
+int dmcf_cconv_scatter_forward(const dmcf_cconv_scatter_args* args, void* workspace, size_t workspace_bytes,
+                               dmcf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * ml3d.ops.continuous_conv (utils/convolutions.py:414-431) between two point sets on ALIGNED REGULAR LATTICES -- the
  * coarse scales of the multi-scale models: models/hrnet.py:85-92 convolves between the outputs of grid_pos
  * (utils/tools/losses.py:136-181, via get_dilated_pos :266-272), which share one centre and whose voxel sizes are integer

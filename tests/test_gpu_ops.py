@@ -1303,3 +1303,55 @@ def test_single_launch_table_build_equals_the_ten_launch_one(dev, monkeypatch, n
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
     assert n < 100 or res[True][0].numel() > n
+
+
+@pytest.mark.parametrize("padded", [False, True])
+@pytest.mark.parametrize("cin,cout", [(24, 4), (16, 8), (5, 4), (24, 8)])
+def test_scatter_form_matches_the_oracle_and_the_gather_form(oracle, dev, cin, cout, padded):
+    """Splat S (dmcf_cconv_scatter_forward: filter first, input stationary, 64-bit fixed-point sums) on the geometry it is built
+    for -- particles at the bench's density onto the coarse grid_pos lattice (spacing 0.1, radius 0.4) -- against the CPU
+    oracle on the FORWARD list and against the gather form (cconv_forward), walking the TRANSPOSED list in CSR and in padded form;
+    bit reproducible; the plan's boxes hold every pair (error flag 0)."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(100 * cin + cout)
+    side, h, radius, voxel = 18, 0.05, 0.4, 0.1
+    ax = (np.arange(side) + 0.5) * h
+    inp = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3)
+    inp = (inp + rng.uniform(-0.1 * h, 0.1 * h, size=inp.shape) + np.array([0.37, -1.2, 2.05])).astype(np.float32)
+    feat = np.maximum(rng.normal(size=(inp.shape[0], cin)), 0).astype(np.float32)
+    filt = rng.uniform(-1, 1, size=(4, 4, 4, cin, cout)).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    P, F, W, B = _t(inp, dev), _t(feat, dev), _t(filt, dev), _t(bias, dev)
+    Q = ops.grid_pos(P, torch.tensor([voxel] * 3), centralize=True)
+    out = Q.cpu().numpy()
+    fwd = ops.fixed_radius_search(P, Q, radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in fwd)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2),
+                                 f64=True) + bias
+    y_gather = ops.cconv_forward(W, Q, 2 * radius, P, F, fwd.neighbors_index, fwd.neighbors_row_splits,
+                                 neighbors_value=fwd.neighbors_distance, window="poly6", bias=B)
+    if padded:
+        t = ops.fixed_radius_search(Q, P, radius, return_distances=False, row_stride=400)
+        assert int(t.max_count.item()) <= 400
+        t_idx, t_rb, t_cnt = t.raw()[0], t.raw()[1], t.row_count
+    else:
+        t = ops.fixed_radius_search(Q, P, radius, return_distances=False)
+        t_idx, t_rb, t_cnt = t.neighbors_index, t.neighbors_row_splits, None
+        assert int(t_rb[-1]) == idx.shape[0]  # the transposed list holds the same pairs
+    plan = ops.scatter_plan(P, Q, voxel, radius, block_cells=2 if cout == 8 else None)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    y = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t_idx, t_rb, t_cnt, plan, window="poly6", bias=B, error_flag=flag)
+    assert int(flag.item()) == 0
+    _close(y.cpu().numpy(), ref)
+    scale = float(np.abs(ref).max())
+    assert float((y - y_gather).abs().max()) <= 2e-6 * scale
+    y2 = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t_idx, t_rb, t_cnt, plan, window="poly6", bias=B)
+    assert torch.equal(y, y2), "fixed-point sums must not depend on the schedule"
+    # accumulate into an existing tensor, no window, another block size
+    acc = torch.full_like(y, 0.5)
+    plan3 = ops.scatter_plan(P, Q, voxel, radius, block_cells=1 if cout == 8 else 2)
+    y3 = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t_idx, t_rb, t_cnt, plan3, window="poly6", bias=B, out=acc, accumulate=True)
+    assert y3 is acc and float((y3 - 0.5 - y).abs().max()) <= 1e-6 * scale
+    ref0 = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, None, f64=True)
+    y0 = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t_idx, t_rb, t_cnt, plan, window=None)
+    _close(y0.cpu().numpy(), ref0)
