@@ -18,10 +18,11 @@
 //     device).  All outputs a block can reach lie in a box of D^3 lattice cells, D = m + 2 reach + 1, whose accumulators live
 //     in LDS ([Cout][D^3] 64-bit integers, channel major: conflict free for distinct slots).  A block of ~64 particles adds ~16k
 //     pairs into ~1000 slots and flushes each touched slot ONCE with a global atomic: 13 pairs per flushed value.
-//   * sums are FIXED POINT: a contribution c is added as round(c * 2^s) into a 64-bit integer, 2^s = 2^30 / (a power-of-two bound
+//   * sums are FIXED POINT: a contribution c is added as round(c * 2^s) into a 64-bit integer, 2^s = 2^46 / (a power-of-two bound
 //     of |c|: max_j |f_j|_1 * max |W|, formed on the device inside the call).  Integer addition is associative, so LDS
 //     atomics, global atomics and any schedule give THE SAME BITS: the step stays bit reproducible with no ordering, no staging
-//     and no barrier in the pair loop.  Resolution: 2^-30 of the bound per term (terms are float32: 2^-24 of themselves).
+//     and no barrier in the pair loop.  Resolution: 2^-46 of the bound per term (terms are float32: 2^-24 of themselves; 2^-30
+//     was tried first and showed in the dam break, where a few splashing particles set a bound a thousand times a typical term).
 //
 // Workgroup = 8 waves; a block's rows go by in chunks of 16: G of the chunk = F[16 x Cin] . W[Cin x 64 Cout] on the matrix cores
 // (the filter stays in registers as B fragments, each wave forms its 16-column tiles), double buffered in LDS, one barrier per
@@ -112,12 +113,19 @@ __device__ __forceinline__ uint32_t sct_f2ord(float f) {
 }
 __device__ __forceinline__ float sct_ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
 
-// 2^s with 2^s * bound <= 2^30 (bound = max_j |f_j|_1 * max |W| >= any pair's contribution)
+// 2^s with 2^s * bound <= 2^46 (bound = max_j |f_j|_1 * max |W| >= any pair's contribution; rows hold < 2^16 pairs)
 __device__ __forceinline__ float sct_scale(const uint32_t* bound, float window_fac) {
     const float b = __uint_as_float(bound[0]) * __uint_as_float(bound[1]) * fmaxf(1.0f, fabsf(window_fac));
     int e = 0;
     if (b > 0.0f && isfinite(b)) (void)frexpf(b, &e);  // b = m 2^e, 0.5 <= m < 1
-    return ldexpf(1.0f, 30 - e);
+    return ldexpf(1.0f, 46 - e);
+}
+
+// round(y) as a 64-bit integer for |y| <= 2^46, exact above 1: y = hi 2^23 + lo with both parts exact in float32
+__device__ __forceinline__ long long sct_fixed(float y) {
+    const float hi = truncf(y * 0x1p-23f);
+    const float lo = fmaf(-hi, 0x1p23f, y);
+    return (long long)(int)hi * (1ll << 23) + (long long)__float2int_rn(lo);
 }
 
 // ---- plan kernels -------------------------------------------------------------------------------------------------------
@@ -518,7 +526,7 @@ __global__ __launch_bounds__(64 * WAVES, (COUT == 4 && WAVES == 8) ? 2 : 1) void
                     Sidx[slot] = iA;
 #ifndef SX_NOATOM
 #pragma unroll
-                    for (int o = 0; o < COUT; ++o) lds_add_i64(Acc + o * NSp + slot, (long long)__float2int_rn(acc[o]));
+                    for (int o = 0; o < COUT; ++o) lds_add_i64(Acc + o * NSp + slot, sct_fixed(acc[o]));
 #else
                     if (acc[0] + acc[COUT - 1] == 123.456f) Acc[slot] = 1;
 #endif

@@ -176,6 +176,31 @@ __device__ __forceinline__ bool grid_bases(const GridParams& p, const GridHeader
     return diff;
 }
 
+// A scene that has dissolved into spray (the 100k dam break after ~40 steps, the 1M box once particles leave the shell) has a
+// bounding box of billions of cells for a million occupied ones: the dense table `first[cell]` does not fit.  HASHED table
+// (table_cells < 0 at the entry points: -table_cells slots, a power of two): slot = open addressing on the 64-bit cell index,
+// first[slot] as before, the keys behind the `first` array.  Same three passes, same owners, same order: bit-identical output
+// (round 6; until then a sort-based torch formulation with six host round trips took over -- 25 ms per step of the dam break).
+constexpr unsigned long long kGridEmpty = ~0ull;
+__device__ __forceinline__ uint32_t grid_hash(int64_t cell, uint32_t mask) {
+    return (uint32_t)(((unsigned long long)cell * 0x9E3779B97F4A7C15ull) >> 32) & mask;
+}
+template <bool INSERT>
+__device__ __forceinline__ int64_t grid_slot(unsigned long long* keys, uint32_t mask, int64_t cell) {
+    uint32_t s = grid_hash(cell, mask);
+    for (uint32_t probe = 0; probe <= mask; ++probe, s = (s + 1) & mask) {
+        if (INSERT) {
+            const unsigned long long old = atomicCAS(keys + s, kGridEmpty, (unsigned long long)cell);
+            if (old == kGridEmpty || old == (unsigned long long)cell) return s;
+        } else {
+            const unsigned long long k = keys[s];
+            if (k == (unsigned long long)cell) return s;
+            if (k == kGridEmpty) return -1;
+        }
+    }
+    return -1;  // (table full: the caller sized it for every candidate, so this does not happen)
+}
+
 // MODE 0: atomicMin pass; MODE 1: count owners per row; MODE 2: write owners
 template <int MODE>
 __global__ __launch_bounds__(256) void grid_pass(const GridParams p, const GridHeader* __restrict__ h,
@@ -211,8 +236,13 @@ __global__ __launch_bounds__(256) void grid_pass(const GridParams p, const GridH
         for (int i1 = 0; i1 < p.len[1]; ++i1)
             for (int i2 = 0; i2 < p.len[2]; ++i2, ++o) {
                 const int g0 = c[0] + p.lo[0] + i0, g1 = c[1] + p.lo[1] + i1, g2 = c[2] + p.lo[2] + i2;
-                const int64_t cell = g0 + g1 * d0 + g2 * d01;
-                if (cell < 0 || cell >= table_cells) continue;  // table smaller than the header says: never out of bounds
+                int64_t cell = g0 + g1 * d0 + g2 * d01;
+                if (table_cells < 0) {
+                    const uint32_t mask = (uint32_t)(-table_cells) - 1u;
+                    unsigned long long* keys = (unsigned long long*)(first + (-table_cells));
+                    cell = MODE == 0 ? grid_slot<true>(keys, mask, cell) : grid_slot<false>(keys, mask, cell);
+                    if (cell < 0) continue;
+                } else if (cell < 0 || cell >= table_cells) continue;  // table smaller than the header says: never out of bounds
                 const uint32_t k = k0 + (uint32_t)o;
                 if (MODE == 0) {
                     atomicMin(first + cell, k);
@@ -317,7 +347,8 @@ int dmcf_grid_pos_count(const float* positions, int64_t n_points, const float* v
     GridParams p;
     int rc = grid_params(p, positions, n_points, voxel_size, centralize, pad, hyst);
     if (rc != DMCF_OK) return rc;
-    if (!workspace || ((uintptr_t)workspace & 255) || table_cells < 0 || (table_cells > 0 && !cell_table)) return DMCF_EINVAL;
+    if (!workspace || ((uintptr_t)workspace & 255) || (table_cells != 0 && !cell_table)) return DMCF_EINVAL;
+    if (table_cells < 0 && ((-table_cells) & (-table_cells - 1))) return DMCF_EINVAL;  // hashed: a power of two of slots
     const GridLayout L = grid_layout(n_points);
     if (workspace_bytes < L.total) return DMCF_EWORKSPACE;
     char* ws = (char*)workspace;
@@ -326,7 +357,9 @@ int dmcf_grid_pos_count(const float* positions, int64_t n_points, const float* v
     int32_t* counts = (int32_t*)(ws + L.off_counts);
     int64_t* row_off = (int64_t*)(ws + L.off_rowoff);
     const int64_t rows = 2 * n_points;
-    if (table_cells > 0 && hipMemsetAsync(first, 0xff, (size_t)table_cells * 4, stream) != hipSuccess) return DMCF_ELAUNCH;
+    // (hashed: 4 bytes of `first` + 8 bytes of key per slot, all ones = empty)
+    const size_t table_bytes = table_cells >= 0 ? (size_t)table_cells * 4 : (size_t)(-table_cells) * 12;
+    if (table_bytes > 0 && hipMemsetAsync(first, 0xff, table_bytes, stream) != hipSuccess) return DMCF_ELAUNCH;
     if (rows > 0) {
         const unsigned g = (unsigned)((rows + 255) / 256);
         hipLaunchKernelGGL((grid_pass<0>), dim3(g), dim3(256), 0, stream, p, h, first, counts, (const int64_t*)nullptr,

@@ -957,8 +957,8 @@ class GridTooSparse(RuntimeError):
 def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=None):
     """``grid_pos`` (utils/tools/losses.py:136-181) for SEVERAL voxel sizes over the same positions -- the coarse levels of one step
     (losses.py:266-272) -- via dmcf_grid_pos_bounds/_count/_write with TWO host round trips for all of them (cells of every level,
-    then points of every level) instead of two per level.  -> [(points, (minp, dims) | None), ...]; raises GridTooSparse if any
-    level's box is too sparse for the dense cell table (the caller then takes the levels one at a time)."""
+    then points of every level) instead of two per level.  -> [(points, (minp, dims) | None), ...].  A level whose box is too sparse
+    for the dense cell table (GRID_MAX_CELLS_PER_POINT) takes the hashed table; GridTooSparse is no longer raised (round 6)."""
     import numpy as np
     L = _lib.lib()
     pos = _dev_f32(pos, "pos", 3)
@@ -982,11 +982,19 @@ def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=No
             lv["total"] = int(hdr[32:40].view(torch.int64).item())
             if lv["cells"] < 0:
                 raise _lib.DmcfError("grid_pos: positions are not finite")
-            if lv["cells"] > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n)):
-                raise GridTooSparse(f"{lv['cells']} lattice cells in the bounding box")
+            # too sparse for the dense cell table (a few particles far from the rest): the hashed table (include/dmcf_hip.h)
+            lv["sparse"] = lv["cells"] > min(GRID_MAX_CELLS, max(GRID_MIN_CELLS, GRID_MAX_CELLS_PER_POINT * n))
+
+    noff = 1
+    for x in np.asarray(voxel_sizes[0], dtype=np.float32).reshape(3):
+        noff *= (2 + 2 * int(pad)) if x >= 1e-5 else 1
+    hash_slots = 1 << max(int(4 * n * noff - 1).bit_length(), 10)  # >= twice the 2 n noff candidates
 
     def count(lv, capacity):
-        lv["table"] = torch.empty(max(capacity, 1), dtype=torch.int32, device=pos.device)
+        if capacity < 0:  # hashed: 4 + 8 bytes per slot
+            lv["table"] = torch.empty(3 * (-capacity), dtype=torch.int32, device=pos.device)
+        else:
+            lv["table"] = torch.empty(max(capacity, 1), dtype=torch.int32, device=pos.device)
         lv["capacity"] = capacity
         _lib.check(L.dmcf_grid_pos_count(_ptr(pos), n, lv["vs"], cflag, int(pad), float(hyst), _ptr(lv["ws"]), ws_bytes,
                                          _ptr(lv["table"]), capacity, _stream()), "dmcf_grid_pos_count")
@@ -997,22 +1005,22 @@ def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=No
     key = (tuple(tuple(float(x) for x in lv["vs"]) for lv in levels), bool(centralize), int(pad), float(hyst))
     est = _GRID_CELLS.get(key)
     if est is not None and len(est) == len(levels):
-        for lv, c in zip(levels, est):
-            count(lv, _size_class(c + c // 4))
+        for lv, c in zip(levels, est):  # (c < 0: the level was sparse at the last call)
+            count(lv, -hash_slots if c < 0 else _size_class(c + c // 4))
         read_headers()
-        again = [lv for lv in levels if lv["cells"] > lv["capacity"]]
+        again = [lv for lv in levels if lv["capacity"] >= 0 and (lv["sparse"] or lv["cells"] > lv["capacity"])]
         for lv in again:
-            count(lv, lv["cells"])
+            count(lv, -hash_slots if lv["sparse"] else lv["cells"])
         if again:
             read_headers()
     else:
         read_headers()  # (host round trip 1 of 2: every level's header)
         for lv in levels:
-            count(lv, lv["cells"])
+            count(lv, -hash_slots if lv["sparse"] else lv["cells"])
         read_headers()  # (host round trip 2 of 2: every level's point count)
     while len(_GRID_CELLS) > 32:
-        _GRID_CELLS.pop(next(iter(_GRID_CELLS)))
-    _GRID_CELLS[key] = [lv["cells"] for lv in levels]
+        _GRID_CELLS.pop(next(iter(_GRID_CELLS)), None)
+    _GRID_CELLS[key] = [-1 if lv["sparse"] else lv["cells"] for lv in levels]
     totals = [lv["total"] for lv in levels]
     res = []
     for lv, total in zip(levels, totals):

@@ -243,7 +243,7 @@ int dmcf_cconv_kernel_name(const dmcf_cconv_args* args, char* name, size_t name_
  * interpolation of G_j added into the output point.  It walks the TRANSPOSED neighbour list: row j = the output points within
  * extent / 2 of input point j -- the list FixedRadiusSearch returns for (points = out_positions, queries = inp_positions), which
  * holds the same pairs as the forward list when the search's neighbour set is symmetric (the default set of this library).
- * Sums are formed in 64-bit fixed point (a term c enters as round(c * 2^s), 2^s * max_j |f_j|_1 * max |W| <= 2^30, both maxima
+ * Sums are formed in 64-bit fixed point (a term c enters as round(c * 2^s), 2^s * max_j |f_j|_1 * max |W| <= 2^46, both maxima
  * formed on the device inside the call), so the result does not depend on the order of the additions: bit reproducible like
  * every other kernel here, with LDS and global atomics doing the adds.
  *
@@ -417,6 +417,10 @@ int dmcf_ghost_write(const float* points, int64_t n, const float* boxes, int32_t
  * floats or NULL.  The same (positions, voxel_size, centralize, pad, hyst, workspace) must be passed to all
  * three calls.  Candidate ranks are 32-bit: 2 * n_points * (2 + 2 pad)^3 must stay below 2^32
  * (DMCF_EUNSUPPORTED otherwise).
+ * SPARSE scenes (a few particles far from the rest: `cells` in the billions for a million occupied ones): pass
+ * table_cells = -S to count / write, S a power of two >= twice the number of candidates 2 * n_points * (2 + 2 pad)^3 at most
+ * occupied, and a table of 12 * S bytes: the kernels then hash the cell index into S slots (open addressing) instead of
+ * indexing a dense table.  Same points, same order.
  * ---------------------------------------------------------------------------------------------- */
 size_t dmcf_grid_pos_workspace_bytes(int64_t n_points);
 int dmcf_grid_pos_bounds(const float* positions, int64_t n_points, const float* voxel_size, int centralize,

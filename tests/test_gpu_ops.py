@@ -696,12 +696,18 @@ def test_grid_pos_edge_cases(oracle, dev):
     a = grid_pos(_t(p, dev), vs, centralize=True, center=_t(c, dev)).cpu().numpy()
     b = grid_pos(torch.from_numpy(p), vs, centralize=True, center=torch.from_numpy(c)).numpy()
     assert np.array_equal(a, b)
-    # two clusters very far apart: the dense cell table would be huge -> sort-based device form, same result
+    # two clusters very far apart: the dense cell table would be huge -> the HASHED cell table (round 6; until then a
+    # sort-based torch formulation), same points in the same order
     far = np.concatenate([p[:500], p[:500] + np.float32([4000, 4000, 4000])])
-    with pytest.raises(ops.GridTooSparse):
-        ops.grid_pos(_t(far, dev), np.float32([0.01, 0.01, 0.01]))
-    g = grid_pos(_t(far, dev), [0.01, 0.01, 0.01], centralize=False).cpu().numpy()
+    g = ops.grid_pos(_t(far, dev), np.float32([0.01, 0.01, 0.01])).cpu().numpy()
     assert np.array_equal(g, oracle.grid_pos(far, [0.01, 0.01, 0.01]))
+    g = grid_pos(_t(far, dev), [0.01, 0.01, 0.01], centralize=True).cpu().numpy()
+    assert np.array_equal(g, oracle.grid_pos(far, [0.01, 0.01, 0.01], centralize=True))
+    # ... and several levels at once, one of them sparse (the rollout's call, with and without the previous call's estimates)
+    for _ in range(2):
+        many = ops.grid_pos_many(_t(far, dev), [np.float32([v] * 3) for v in (0.01, 0.02, 200.0)], centralize=True)
+        for (pts, _box), v in zip(many, (0.01, 0.02, 200.0)):
+            assert np.array_equal(pts.cpu().numpy(), oracle.grid_pos(far, [v] * 3, centralize=True))
     # non-finite positions are an error, not a crash
     bad = p[:10].copy()
     bad[3, 1] = np.nan
@@ -710,8 +716,8 @@ def test_grid_pos_edge_cases(oracle, dev):
 
 
 def test_grid_pos_200k_matches_sort_formulation(dev):
-    """Size the oracle would not finish quickly: HIP kernels against the torch sort/unique formulation on the
-    device (forced through GRID_MAX_CELLS = 0), bit for bit."""
+    """Size the oracle would not finish quickly: the HIP kernels with the dense AND with the hashed cell table (forced through
+    GRID_MAX_CELLS = 0) against the torch sort / unique formulation of the same code (the host form, on the CPU), bit for bit."""
     from dmcf_amd import ops
     from dmcf_amd.utils.tools.losses import grid_pos
     g = torch.Generator(device=dev).manual_seed(0)
@@ -724,7 +730,8 @@ def test_grid_pos_200k_matches_sort_formulation(dev):
         b = grid_pos(p, [0.05, 0.05, 0.05], centralize=True, center=c)
     finally:
         ops.GRID_MAX_CELLS = old
-    assert a.shape == b.shape and torch.equal(a, b)
+    ref = grid_pos(p.cpu(), [0.05, 0.05, 0.05], centralize=True, center=c.cpu())
+    assert a.shape == b.shape and torch.equal(a, b) and torch.equal(a.cpu(), ref)
 
 
 @pytest.mark.parametrize("mapping,interp,align,normalize", [

@@ -1,6 +1,7 @@
 """Diagnostic: the 1M bench scene after N rollout steps on the GPU (particles leaking through the shell),
 then ONE oracle step from that state with every CConv call replayed on the HIP kernels with identical inputs, the neighbour
-search compared row by row, and the lattices compared point by point.  usage: python tools/diag_degraded.py [side] [steps]"""
+search compared row by row, and the lattices compared point by point.  usage: python tools/diag_degraded.py [side] [steps]
+SCENE=liquid3d_dam: the dam break of config 4 instead of the box; DMCF_FRS_SET=open3d: that neighbour set on both sides."""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,7 +21,14 @@ cfg = configs.LIQUID3D
 model = getattr(models, cfg["name"])(**cfg)
 tc.load_into_model(model, w, device=dev)
 sim = Simulator(model, device="cuda", reserve_gib="auto")
-state = scenes.model_inputs(scenes.box_scene(side), device=dev)
+if os.environ.get("SCENE"):
+    from tools import long_rollout
+    state = scenes.model_inputs(long_rollout.setup(os.environ["SCENE"])[2], device=dev)
+else:
+    state = scenes.model_inputs(scenes.box_scene(side), device=dev)
+import oracle as _oracle
+_bins = _oracle.search_bins({"distance": "all", "open3d": "own+corners", "open3d_corners": "corners"}[os.environ.get("DMCF_FRS_SET", "distance")])
+_bins.__enter__()
 for _ in range(steps):
     state = sim.step([state])[0]
 before = [None if x is None else x.cpu().numpy() for x in state]
@@ -79,6 +87,10 @@ ref.record = replay
 pos_ref, vel_ref = ref.step(before)
 print("step %d: pos hip-vs-oracle %.2e  correction %.2e" % (steps + 1, rel(out[0].cpu().numpy(), pos_ref),
                                                            rel(model.pos_correction.cpu().numpy(), ref.pos_correction)))
+_e = np.abs(out[0].cpu().numpy() - pos_ref).max(axis=1)
+_w = np.argsort(-_e)[:5]
+print("worst particles:", [(int(i), float(_e[i]), before[0][i].tolist(), float(np.linalg.norm(before[1][i])),
+                            model.pos_correction[i].cpu().numpy().tolist(), ref.pos_correction[i].tolist()) for i in _w])
 # the lattices
 allp = np.concatenate([ref.pos_adv, ref.box_kept]) if hasattr(ref, "pos_adv") else None
 for k, s in enumerate(getattr(ref, "dilated_pos", []) or []):
