@@ -170,7 +170,9 @@ class LatticeInfo:
         c = self.cells()
         minp, dims = list(self.minp), list(self.dims)
         lo_box = torch.tensor(minp, dtype=torch.int32, device=dev)
-        rel = (c - lo_box).long()
+        # (a registered box that does not hold every point -- register_points with a caller's box -- must not reach bincount with a
+        # negative entry: such points are counted in the box's border cells, i.e. as far out as the histogram can say)
+        rel = torch.minimum((c - lo_box).long().clamp_(min=0), torch.tensor(dims, device=dev) - 1)
         hist = torch.cat([torch.bincount(rel[:, k], minlength=dims[k])[: dims[k]] for k in range(3)])
         key = (_CACHE.key, self.voxel)
 
@@ -220,8 +222,9 @@ class LatticeInfo:
                 valid = (idx >= 0).to(torch.float32).unsqueeze(1)
                 idx = idx.clamp(min=0)
             pos = self.gpos.index_select(0, idx).contiguous()
-            if valid is not None:  # the padding rows: far from every point (empty rows)
-                pos = torch.where(valid > 0, pos, torch.full_like(pos, _FAR))
+            if valid is not None:  # the padding rows: far from every point (empty rows) -- beyond the lattice's own box
+                far = max(_FAR, 4.0 * (self.max_abs or 0.0) + 1.0e3)
+                pos = torch.where(valid > 0, pos, torch.full_like(pos, far))
         self._core = (lo, [hi[k] - lo[k] for k in range(3)], idx, pos, valid)
         return self._core
 

@@ -1018,8 +1018,11 @@ def grid_pos_many(pos, voxel_sizes, centralize=False, pad=0, hyst=0.1, center=No
         for lv in levels:
             count(lv, -hash_slots if lv["sparse"] else lv["cells"])
         read_headers()  # (host round trip 2 of 2: every level's point count)
-    while len(_GRID_CELLS) > 32:
-        _GRID_CELLS.pop(next(iter(_GRID_CELLS)), None)
+    while len(_GRID_CELLS) > 32:  # (virtual ranks are threads sharing this dict: evict without iterating a dict another thread resizes)
+        try:
+            _GRID_CELLS.pop(next(iter(_GRID_CELLS)), None)
+        except (RuntimeError, StopIteration):
+            break
     _GRID_CELLS[key] = [-1 if lv["sparse"] else lv["cells"] for lv in levels]
     totals = [lv["total"] for lv in levels]
     res = []

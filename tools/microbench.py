@@ -36,8 +36,21 @@ def main():
              ("ASCC 32->3 s0->s0 R0.1", s0, s0, 0.1, 32, 3, (6, 3, 6), "peak", True),
              # conv200_1 + conv300_1 of Liquid3d as ONE block-diagonal launch (models/hrnet.py, _paired_convs): 8 + 16 channels
              ("LQ  24->64 s1->s0 R0.2", s1, s0, 0.2, 24, 64, (4, 4, 4), "poly6", False)]
+    cases.append(("S4  24->4  s0->s2 R0.4 (splat S: scatter form over the transposed list)", s0, cases[9][2], 0.4, 24, 4, (4, 4, 4), "poly6", False))
     for name, inp, out, R, cin, cout, ks, win, sym in cases:
         if os.environ.get('ONLY') and not any(name.startswith(o) for o in os.environ['ONLY'].split(',')): continue
+        if name.startswith("S4"):
+            t = ops.fixed_radius_search(out, inp, R, return_distances=False)
+            plan = ops.scatter_plan(inp, out, 0.1, R)
+            feat = torch.rand(inp.shape[0], cin, device=dev, generator=g)
+            W = torch.rand(*ks, cin, cout, device=dev, generator=g) - 0.5
+            f = lambda: ops.cconv_scatter_forward(W, out, 2 * R, inp, feat, t.neighbors_index, t.neighbors_row_splits, None, plan, window=win)
+            f()
+            ms = timed(f)
+            P = t.neighbors_index.shape[0]
+            by = P * (20 + 4 * cin) + out.shape[0] * (20 + 4 * cout) + 4 * 64 * cin * cout
+            print(f"{name}: pairs {P/1e6:7.1f}M  {ms:7.2f} ms  {1e6*ms/P/((cin+7)//8):.4f} ns/pair/chunk  alg {by/ms/1e6:7.0f} GB/s ({100*by/ms/1e6/8000:.1f}% of 8 TB/s)", flush=True)
+            continue
         # lists without distances, as the networks use them (the window is evaluated on distances re-formed from the positions: the
         # 'plain' instantiations of splats D / E); MB_DIST=1: with the distance array
         dist = os.environ.get('MB_DIST') == '1'
