@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void reduce_subarrays_sum_kernel(const float* 
 
 extern "C" {
 
-int dmcf_version(void) { return 20500; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF; 2.3.0: row_length_hint (splat F); 2.4.0: dmcf_points_aabb; 2.5.0: DMCF_FLAG_FILTER_PACKED, row_length_hint = 1 (splat H)
+int dmcf_version(void) { return 20600; }  // 2.0.0: round 2 removed dmcf_cconv_geometry and the geometry field of dmcf_cconv_args; 2.1.0: filter_tile_mask; 2.2.0: DMCF_FLAG_SKIP_SELF; 2.3.0: row_length_hint (splat F); 2.4.0: dmcf_points_aabb; 2.5.0: DMCF_FLAG_FILTER_PACKED, row_length_hint = 1 (splat H); 2.6.0: dmcf_cconv_scatter_* (splat S), hashed grid_pos table (table_cells < 0)
 
 const char* dmcf_error_string(int code) {
     switch (code) {

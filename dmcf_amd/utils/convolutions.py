@@ -342,6 +342,12 @@ def neighbor_cache(estimate=False, key=None):
     return _CacheScope(estimate, key)
 
 
+def _scatter_guard(vals):
+    if any(vals):
+        raise RuntimeError("dmcf_cconv_scatter_forward dropped pairs: a block's box did not hold an output it reaches (plan / positions mismatch)")
+    return False
+
+
 def _hint_key(frs, points, queries, radius):
     """What a search is, for the estimates carried from one step to the next: radius, the size class of both point sets
     (half powers of two: particle counts drift by a few per cent per step, the lattices' with them) and the search's flags."""
@@ -610,11 +616,15 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                 d["_n_out_last"] = out_positions.shape[0]
                 d["_pairs_last"] = tl.total_ref
                 fuse_bias = self.use_bias and not self.use_dense_layer_for_center
+                # (the kernel's guard -- a pair outside its block's box, i.e. a plan that does not match the positions -- is read with
+                # the step's one synchronisation and fails loudly; it has never fired)
+                flag = _CACHE._max_count_slot(inp_positions.device) if _CACHE.depth > 0 else torch.zeros(1, dtype=torch.int32, device=inp_positions.device)
                 out_features = ops.cconv_scatter_forward(
                     self.kernel, out_positions, extent, inp_positions, inp_features, t_idx, t_rb, getattr(tl, "row_count", None),
                     _CACHE.scatter_plan(inp_positions, out_positions, voxel, radius, m), window=self.window_function.name,
                     window_fac=self.window_function.fac, bias=self._epilogue_bias(fuse_bias, extra_bias), out=acc,
-                    accumulate=acc is not None, n_pairs_ref=tl.total_ref)
+                    accumulate=acc is not None, n_pairs_ref=tl.total_ref, error_flag=flag)
+                _CACHE.report(flag, _scatter_guard)
                 d["_conv_values"], d["_conv_output"] = None, (None if _CACHE.depth > 0 else out_features)
                 return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
             if fixed_radius_search_hash_table is not None:
