@@ -70,6 +70,33 @@ def test_virtual_ranks_match_single_rank_on_gpu(world, monkeypatch):
     _check(res, ref, n)
 
 
+def test_virtual_ranks_take_the_scatter_form_and_match_the_gather_form(monkeypatch):
+    """Splat S (dmcf_cconv_scatter_forward) inside a SHARDED step: a rank's 24 -> 4 layer onto its owned s2 lattice points walks the
+    transposed list over (owned + ghost) particles.  Two virtual ranks with the form forced on for these small blocks against one
+    rank with the form off (splat F): positions within 1e-5, the scatter kernel seen on every rank."""
+    from dmcf_amd import ops, parallel
+    from dmcf_amd.utils import convolutions
+    from tools import scenes
+    dev = torch.device("cuda:0")
+    parts = [scenes.box_slab_scene(14, 2, r, seed=11) for r in range(2)]  # 28 x 14 x 14 box
+    scene = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    n = scene["pos"].shape[0]
+    monkeypatch.setenv("DMCF_SCATTER_CONV", "0")
+    ref = parallel.run_local_ranks(1, lambda c: _run_rank(c, parallel.SlabDecomposition(0, []), scene, 3, dev))
+    monkeypatch.setenv("DMCF_SCATTER_CONV", "1")
+    monkeypatch.setattr(convolutions, "SCATTER_MIN_INPUTS", 256)
+    ops.timer = ops.LaunchTimer()
+    try:
+        decomp = parallel.SlabDecomposition.uniform(0, 0.0, 28 * 0.05, 2)
+        res = parallel.run_local_ranks(2, lambda c: _run_rank(c, decomp, scene, 3, dev))
+        torch.cuda.synchronize()
+        kernels = [m.get("kernel", "") for k, m, _ in ops.timer.results() if k == "cconv"]
+    finally:
+        ops.timer = None
+    assert sum(k.startswith("cconv_sct_kernel") for k in kernels) >= 2 * 3, kernels[:40]
+    _check(res, ref, n)
+
+
 @pytest.mark.parametrize("grid", [[2, 2, 1], [2, 2, 2]])
 def test_virtual_block_ranks_match_single_rank_on_gpu(grid, monkeypatch):
     """SURVEY.md section 8e's partitioning: 2x2x1 and 2x2x2 blocks of one 24^3 box (the pieces bench.py --gpus 4 / 8 gives

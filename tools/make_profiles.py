@@ -64,7 +64,7 @@ def pmc(src, tag, P):
             if ": pairs" in l:
                 name = l.split()[0]
                 mb[name] = (float(l.split("pairs")[1].split("M")[0]) * 1e6, float(l.split("M")[1].split("ms")[0]))
-    case_of = dict(pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC",
+    case_of = dict(sct_S4="S4", pair_L4="L4", pair_L3="L3", pair4_LQ="LQ", cls1_L8="L8", cls2_L5="L5", cls2n_L6="L6", cls4_LP="LP", z3_L14="L14", direct_ASCC="ASCC",
                    ws_L14="L14", ws_L2="L2")
     # (forced kernels: their time is in microbench_short.log, not in the default-dispatch table)
     forced = {}
@@ -251,6 +251,47 @@ def virtual_ranks(src, tag, P):
     open(f"{P}/{tag}_virtual_rank_kernel_time.md", "w").write("\n".join(out) + "\n")
 
 
+def scatter(src, tag, P):
+    if not os.path.exists(f"{src}/bench_scatter.log"):
+        return
+    clean = lambda t: "".join(l for l in t.splitlines(True) if "amdgpu.ids" not in l).rstrip()
+    out = [f"# Splat S (filter first, input stationary, fixed-point sums) against the gather kernels ({tag}; `cconv_sct.hip`, DESIGN section 4.3)\n",
+           "`python tools/bench_scatter.py`: the particles of the 100^3 box + shell onto the coarse `grid_pos` lattices, whole calls (memset + bound "
+           "+ kernel + finish for S), min of 5; `plan` = dmcf_cconv_scatter_plan, once per pair of point sets and step:\n", "```",
+           clean(open(f"{src}/bench_scatter.log").read()), "```\n"]
+    if os.path.exists(f"{src}/sct_variants.log"):
+        out += ["The same with one part of the kernel removed each (`make -C dmcf_amd/csrc sct_variants`, `tools/sct_variants.sh`; wrong results, "
+                "right timing of what is left): NOATOM = no LDS adds (and therefore nothing to flush), NOFLUSH = no global atomics, NOGATHER = "
+                "G_j read at one fixed cell:\n", "```", clean(open(f"{src}/sct_variants.log").read()), "```"]
+    open(f"{P}/{tag}_scatter.md", "w").write("\n".join(out) + "\n")
+
+
+def more_bench_lines(src, tag, P):
+    """Appends the lines of the other BASELINE configs and of the settled scene to <tag>_bench_lines.md."""
+    path = f"{P}/{tag}_bench_lines.md"
+    out = [open(path).read().rstrip(), ""]
+    for name, title in (("bench_settled", "`python bench.py --scene settled --steps 20 --warmup 5 --cpu-side 0` (every timed step starts from the state after the warm-up)"),
+                        ("bench_waterramps", "`python bench.py --config waterramps --steps 600 --warmup 20` (BASELINE config 2)"),
+                        ("bench_wbcsph", "`python bench.py --config wbcsph --steps 600 --warmup 20` (BASELINE config 3)"),
+                        ("bench_liquid3d_dam_first20", "`python bench.py --config liquid3d_dam --steps 20 --warmup 1` (BASELINE config 4, steps 2 - 21)"),
+                        ("bench_liquid3d_dam", "`python bench.py --config liquid3d_dam --steps 200 --warmup 20 --cpu-side 0` (BASELINE config 4, steps 21 - 220: the scene dissolves)")):
+        f = f"{src}/{name}.log"
+        if not os.path.exists(f):
+            continue
+        try:
+            d = last_json(f)
+        except ValueError:
+            out += [f"{title}: FAILED", "```", open(f).read()[-1500:], "```", ""]
+            continue
+        keep = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "roofline", "step_ms",
+                                      "dispatches_per_step", "synchronising_reads_per_step", "library_launch_ms_per_step", "step_ms_instrumented",
+                                      "kernel_ms_per_step", "scene_state", "cpu_baseline") if k in d}
+        bk = {k: dict(ms_per_step=round(v["ms_per_step"], 4), launches=v["launches"], frac=round(v["frac"], 4), frac_flops=round(v.get("frac_flops", 0) or 0, 4))
+              for k, v in d.get("roofline_groups", {}).get("by_kernel", {}).items()}
+        out += [title + ":\n", "```json", json.dumps(keep), "```", "per kernel: `" + json.dumps(bk) + "`", ""]
+    open(path, "w").write("\n".join(out) + "\n")
+
+
 def main(src, tag):
     P = os.path.join(ROOT, "profiles")
     b, d = last_json(f"{src}/bench.log"), last_json(f"{src}/bench_driver.log")
@@ -262,7 +303,10 @@ def main(src, tag):
     ghosts(src, tag, P)
     wave_specialisation(src, tag, P)
     small_configs(src, tag, P)
-    virtual_ranks(src, tag, P)
+    if os.path.exists(f"{src}/vranks_111.log"):
+        virtual_ranks(src, tag, P)
+    scatter(src, tag, P)
+    more_bench_lines(src, tag, P)
     print("wrote", [f for f in sorted(os.listdir(P)) if f.startswith(tag)])
 
 
