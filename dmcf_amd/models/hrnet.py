@@ -248,7 +248,7 @@ class HRNet(PBFNet):
             return ops.cconv_forward(kernel, po, ext, pi, f, index, row_splits, neighbors_value=raw_dist,
                                      window=a.window_function.name, window_fac=a.window_function.fac,
                                      align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
-                                     interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
+                                     interpolation=a.interpolation, bias=bias, n_pairs_ref=_convs.pairs_ref(nns),
                                      neighbors_row_count=getattr(nns, "row_count", None), filter_tile_mask=mask,
                                      row_length_hint=a.row_length_hint)
         out = self.apply_conv(launch, feats, inp_pos, out_pos, extent)

@@ -351,7 +351,7 @@ class PBFNet(BaseModel):
         out = ops.cconv_forward(kernel, out_pos, extent, inp_pos, feats, index, row_splits, neighbors_value=raw_dist,
                                 window=a.window_function.name, window_fac=a.window_function.fac,
                                 align_corners=a.align_corners, coordinate_mapping=a.coordinate_mapping,
-                                interpolation=a.interpolation, bias=bias, n_pairs_ref=nns.total_ref,
+                                interpolation=a.interpolation, bias=bias, n_pairs_ref=_convs.pairs_ref(nns),
                                 neighbors_row_count=getattr(nns, "row_count", None))
         a.nns = self.obs_convs.nns = None
         return out, nns

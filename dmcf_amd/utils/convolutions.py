@@ -27,6 +27,7 @@ __all__ = ["ContinuousConv", "neighbor_cache"]
 SCATTER_OUT_CHANNELS = (4,)
 SCATTER_MIN_INPUTS = 4096           # ... for point sets big enough to fill the device (small scenes are paced by launches),
 SCATTER_MAX_LATTICE_CELLS = 1 << 16  # and lattices whose cell coordinates stay exact in float32 arithmetic
+SMALL_LIST_ENTRIES = 1 << 21  # padded lists up to this size stay padded whatever their fill (see _NeighborCache.search: 4 total + 2^22)
 
 
 class _NeighborCache:
@@ -132,14 +133,18 @@ class _NeighborCache:
                 parts = []
                 if pad:
                     parts.append(torch.cat([pending[k][2].max_count for k in pad]).long())
-                    parts.append(torch.stack([pending[k][2].total_ref for k in pad]).long())
+                    # (a list whose padded rows are small never takes the estimated-CSR form, so its pair count is not needed: no
+                    # reduction launch for it -- ten per step of the 2-D models)
+                    small = [pending[k][2].row_count.shape[0] * pending[k][2].stride <= SMALL_LIST_ENTRIES for k in pad]
+                    zero = ops.const_tensor([0], torch.int64, pending[pad[0]][2].row_count.device)[0]
+                    parts.append(torch.stack([zero if sm else pending[k][2].total_ref.long() for k, sm in zip(pad, small)]))
                 for k in oth:
                     rs = pending[k][2].neighbors_row_splits
                     parts.append(torch.stack([torch.diff(rs).max() if rs.shape[0] > 1 else rs.new_zeros(()), rs[-1]]))
                 flat = torch.cat(parts).tolist()
                 vals = [None] * len(pending)
                 for i, k in enumerate(pad):
-                    vals[k] = (flat[i], flat[len(pad) + i])
+                    vals[k] = (flat[i], None if small[i] else flat[len(pad) + i])
                 for i, k in enumerate(oth):
                     vals[k] = (flat[2 * len(pad) + 2 * i], flat[2 * len(pad) + 2 * i + 1])
                 fresh, tot = {}, {}
@@ -151,7 +156,8 @@ class _NeighborCache:
                     elif r.overflowed(total):
                         over.append((hkey, "pairs", r.capacity, int(total)))
                     fresh[hkey] = max(fresh.get(hkey, 0), int(mx))  # (searches of one class share the longest of their rows)
-                    tot[slot] = int(total)
+                    if total is not None:
+                        tot[slot] = int(total)
                 # estimates come from the PREVIOUS step only: a class this step did not search is forgotten (its next search runs
                 # the exact two passes once).  Keeping old entries let one search inherit another's: in the dam break the
                 # lattices grow through the half-octave size classes, and at step 81 the s0 -> s2 list (2,300-entry rows)
@@ -340,6 +346,13 @@ def neighbor_cache(estimate=False, key=None):
     -- e.g. (model, scene slot) -- so that the estimates one rollout leaves behind (row capacities, consumers per list, by
     position in the step's search sequence) are not applied to another model or another scene of the same batch."""
     return _CacheScope(estimate, key)
+
+
+def pairs_ref(nns):
+    """The list's pair count as a device scalar -- for the per-launch records of an installed ops.timer only.  Forming it is a
+    reduction launch per list (ten per step of a 2-D model, 6 % of its dispatches); a step without a timer never asks: the layers'
+    `_avg_neighbors` statistic (convolutions.py:385-388) resolves the list lazily, when somebody reads it."""
+    return nns.total_ref if ops.timer is not None else None
 
 
 def _scatter_guard(vals):
@@ -595,7 +608,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                         self.kernel, pos_s, extent, inp_positions, inp_features, ni, nrs, neighbors_value=raw_dist,
                         window=self.window_function.name, window_fac=self.window_function.fac, align_corners=self.align_corners,
                         coordinate_mapping=self.coordinate_mapping, interpolation=self.interpolation,
-                        bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=nns.total_ref,
+                        bias=self._epilogue_bias(fuse_bias, extra_bias), n_pairs_ref=pairs_ref(nns),
                         neighbors_row_count=getattr(nns, "row_count", None), row_length_hint=1)
                     if valid is not None:
                         res = res * valid
@@ -614,7 +627,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                 t_idx, t_rb, _ = tl.raw()
                 d["nns"] = None
                 d["_n_out_last"] = out_positions.shape[0]
-                d["_pairs_last"] = tl.total_ref
+                d["_pairs_last"] = tl
                 fuse_bias = self.use_bias and not self.use_dense_layer_for_center
                 # (the kernel's guard -- a pair outside its block's box, i.e. a plan that does not match the positions -- is read with
                 # the step's one synchronisation and fails loudly; it has never fired)
@@ -623,7 +636,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                     self.kernel, out_positions, extent, inp_positions, inp_features, t_idx, t_rb, getattr(tl, "row_count", None),
                     _CACHE.scatter_plan(inp_positions, out_positions, voxel, radius, m), window=self.window_function.name,
                     window_fac=self.window_function.fac, bias=self._epilogue_bias(fuse_bias, extra_bias), out=acc,
-                    accumulate=acc is not None, n_pairs_ref=tl.total_ref, error_flag=flag)
+                    accumulate=acc is not None, n_pairs_ref=pairs_ref(tl), error_flag=flag)
                 _CACHE.report(flag, _scatter_guard)
                 d["_conv_values"], d["_conv_output"] = None, (None if _CACHE.depth > 0 else out_features)
                 return self._finish(out_features, inp_features, extra_bias if self.use_dense_layer_for_center else None)
@@ -641,7 +654,7 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
             # raw(): buffers that may be longer than P (no host round trip); the kernels only follow row_splits
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
             row_count = getattr(self.nns, "row_count", None)  # padded rows of the single-pass search
-            n_pairs_ref = self.nns.total_ref
+            n_pairs_ref = pairs_ref(self.nns)
             if self.window_function is not None:  # :359-379
                 if isinstance(self.window_function, WindowFunction):
                     window, window_fac = self.window_function.name, self.window_function.fac
@@ -654,7 +667,8 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
         # stats (convolutions.py:385-388) are formed lazily (property _avg_neighbors): no host sync here
         d["_n_out_last"] = out_positions.shape[0]
-        d["_pairs_last"] = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
+        d["_pairs_last"] = self.nns if (n_pairs_ref is None and getattr(self, "nns", None) is not None and user_neighbors_index is None) \
+            else (n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0])
 
         kernel = self.kernel
         symmetric = self.symmetric
@@ -786,6 +800,8 @@ class ContinuousConv(PlainAttributes, torch.nn.Module):
     def _avg_neighbors(self):
         """pairs / outputs of the last call (convolutions.py:385-388); synchronises when read."""
         pairs = self._pairs_last
+        if hasattr(pairs, "total_ref"):  # (the list itself: its total is formed now, not in every step)
+            pairs = pairs.total_ref
         pairs = int(pairs.item()) if isinstance(pairs, torch.Tensor) else pairs
         return pairs / max(self._n_out_last, 1)
 
@@ -836,7 +852,7 @@ class PointSampling(PlainAttributes, torch.nn.Module):
                                          distances=not isinstance(self.window_function, WindowFunction))
             neighbors_index, neighbors_row_splits, raw_dist = self.nns.raw()
             row_count = getattr(self.nns, "row_count", None)
-            n_pairs_ref = self.nns.total_ref
+            n_pairs_ref = pairs_ref(self.nns)
             if self.window_function is not None:  # :1015-1019
                 if isinstance(self.window_function, WindowFunction):
                     window, window_fac, neighbors_value = self.window_function.name, self.window_function.fac, raw_dist
@@ -847,7 +863,7 @@ class PointSampling(PlainAttributes, torch.nn.Module):
                         neighbors_row_splits, row_count = self.nns.csr_row_splits, None
                     window, neighbors_value = "explicit", self.window_function(q).to(torch.float32)
         self._n_out_last = out_positions.shape[0]
-        self._pairs_last = n_pairs_ref if n_pairs_ref is not None else neighbors_index.shape[0]
+        self._pairs_last = n_pairs_ref if n_pairs_ref is not None else (self.nns if user_neighbors_index is None else neighbors_index.shape[0])
         # ml3d.ops.continuous_conv with its defaults (:1038-1052): align_corners=False, ball_to_cube_radial, linear --
         # irrelevant for a one-cell filter, every neighbour puts all its weight on that cell
         out = ops.cconv_forward(self.kernel, out_positions, extent, inp_positions, inp_features, neighbors_index,
