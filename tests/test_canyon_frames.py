@@ -48,6 +48,17 @@ def test_oracle_step_lands_nearer_the_next_frame(oracle, fx, weights, t):
     assert ratio <= canyon.RATIO_BAR and cos >= canyon.COSINE_BAR, (t, ratio, cos)
 
 
+def test_oracle_rollout_stays_near_the_frames(oracle, fx, weights):
+    """Four free-running steps from frame 8 against frame 12 (tools/canyon.rollout_score): 0.30 measured, bar 0.4."""
+    from oracle.model_ref import ModelRef
+    ref = ModelRef(configs.LIQUID3D, weights)
+    ratio = canyon.rollout_score(fx, lambda p, v: ref.step([p, v, None, None, fx["box"], fx["box_normals"]]))
+    assert ratio <= canyon.ROLLOUT_BAR, ratio
+    # ... and the bar has teeth where one step has none: out_scale x 0.5 (one step: 0.68 against 0.67) reads 0.47
+    half = ModelRef(dict(configs.LIQUID3D, out_scale=[0.00390625] * 3), weights)
+    assert canyon.rollout_score(fx, lambda p, v: half.step([p, v, None, None, fx["box"], fx["box_normals"]])) > canyon.ROLLOUT_BAR
+
+
 def test_oracle_wrong_readings_are_told_apart(oracle, fx, weights):
     """The bars have teeth: three of the readings profiles/r06_reading_sweep.md separates, on one frame."""
     from oracle.model_ref import ModelRef
@@ -83,3 +94,26 @@ def test_hip_step_lands_nearer_the_next_frame(fx, weights, t, mode, monkeypatch)
     ratio, cos = canyon.score(fx, t, out[0].cpu().numpy())
     print(f"canyon frame {t} [{mode}]: ratio {ratio:.3f} cosine {cos:.3f}")
     assert ratio <= canyon.RATIO_BAR and cos >= canyon.COSINE_BAR, (t, ratio, cos)
+
+
+@pytest.mark.gpu
+def test_hip_rollout_stays_near_the_frames(fx, weights):
+    """The PRODUCT path free-running for four steps from frame 8 against frame 12 -- no oracle in this test."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but torch.cuda.is_available() is False")
+    from dmcf_amd import models
+    from dmcf_amd.pipelines import Simulator
+    from dmcf_amd.utils import tf_checkpoint as tc
+    dev = torch.device("cuda:0")
+    model = models.SymNet(**configs.LIQUID3D)
+    tc.load_into_model(model, weights, device=dev)
+    sim = Simulator(model, device="cuda")
+    box, nrm = (torch.from_numpy(np.ascontiguousarray(fx[k])).to(dev) for k in ("box", "box_normals"))
+
+    def step(p, v):
+        out = sim.step([[torch.from_numpy(np.ascontiguousarray(p)).to(dev), torch.from_numpy(np.ascontiguousarray(v)).to(dev), None, None, box, nrm]])[0]
+        return out[0].cpu().numpy(), out[1].cpu().numpy()
+    ratio = canyon.rollout_score(fx, step)
+    print(f"canyon 4-step rollout from frame 8: ratio {ratio:.3f}")
+    assert ratio <= canyon.ROLLOUT_BAR, ratio

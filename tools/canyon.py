@@ -52,3 +52,25 @@ def score(fx, t, pos_pred):
     c, n = (pred - pint).ravel(), (target - pint).ravel()
     cos = float(c @ n / max(np.linalg.norm(c) * np.linalg.norm(n), 1e-300))
     return float(e_net / e_int), cos
+
+
+ROLLOUT_FROM, ROLLOUT_STEPS, ROLLOUT_BAR = 8, 4, 0.4
+
+
+def rollout_score(fx, step, t0=ROLLOUT_FROM, k=ROLLOUT_STEPS):
+    """A free-running rollout of k steps from frame t0 against frame t0 + k: mean |rollout - frame| over mean |k bare integration
+    steps - frame|.  ``step(pos, vel) -> (pos', vel')`` on numpy float32.  Sharper than one step (errors of a wrong reading compound,
+    the network's help accumulates): the oracle reaches 0.30 -- the network removes 70 % of what integration alone misses -- and e.g.
+    ``out_scale`` x 0.5, which one step cannot tell from the shipped value, reads 0.47."""
+    i = t0 - fx["first"]
+    pos, vel = fx["pos"][i], fx["vel"][i]
+    pi, vi = pos.copy(), vel.copy()
+    g = np.array([0, -9.81, 0], dtype=np.float32)
+    for _ in range(k):
+        pos, vel = step(pos, vel)
+        vi = (vi + np.float32(0.02) * g).astype(np.float32)
+        pi = (pi + np.float32(0.02) * vi).astype(np.float32)
+    target = fx["pos"][i + k].astype(np.float64)
+    e = np.linalg.norm(np.asarray(pos, dtype=np.float64) - target, axis=1).mean()
+    e_int = np.linalg.norm(pi.astype(np.float64) - target, axis=1).mean()
+    return float(e / e_int)
