@@ -793,6 +793,17 @@ def scatter_plan(inp_positions, out_positions, voxel, radius, block_cells=None):
     return ScatterPlan(buf, voxel, m, scatter_reach(radius, voxel), n, (inp, out))
 
 
+def scatter_kernel_name(cout, block_cells, reach):
+    """The instantiation dmcf_cconv_scatter_forward launches, as rocprofv3 prints it (csrc/cconv_sct.hip: sct_waves)."""
+    ns = (block_cells + 2 * reach + 1) ** 3
+    ns = (ns + 3) & ~3
+
+    def lds(waves):
+        return cout * ns * 8 + ns * 4 + 2 * 2 * waves * 64 * cout * 4 + 16
+    waves = 8 if (2 * lds(8) <= 160 * 1024 or cout != 4 or lds(16) > 160 * 1024) else 16
+    return f"cconv_sct_kernel<{cout}, {waves}>"
+
+
 def cconv_scatter_supported(filters, block_cells, reach):
     """Does dmcf_cconv_scatter_forward take a layer of this shape (4x4x4 filter, 4 or 8 outputs, a box that fits the LDS)?"""
     if tuple(filters.shape[:3]) != (4, 4, 4) or filters.shape[3] > 32 or filters.shape[4] not in (4, 8):
@@ -846,7 +857,7 @@ def cconv_scatter_forward(filters, out_positions, extent, inp_positions, inp_fea
     if timer is not None:
         pairs = n_pairs_ref if n_pairs_ref is not None else (t_row_count.sum() if t_row_count is not None else t_row_begin[-1])
         timer.end("cconv", dict(pairs=pairs, n_out=n_out, cin=cin, cout=cout, K=64, symmetric=False,
-                                kernel=f"cconv_sct_kernel<{cout}>", pair_values=False, accumulate=bool(accumulate)), t0)
+                                kernel=scatter_kernel_name(cout, plan.block_cells, plan.reach), pair_values=False, accumulate=bool(accumulate)), t0)
     return out
 
 
