@@ -16,20 +16,22 @@
 //
 //   * input points are processed in BLOCKS of m x m x m lattice cells (dmcf_cconv_scatter_plan counting-sorts them by block on the
 //     device).  All outputs a block can reach lie in a box of D^3 lattice cells, D = m + 2 reach + 1, whose accumulators live
-//     in LDS ([Cout][D^3] 64-bit integers, channel major: conflict free for distinct slots).  A block of ~64 particles adds ~16k
-//     pairs into ~1000 slots and flushes each touched slot ONCE with a global atomic: 13 pairs per flushed value.
+//     in LDS ([Cout][D^3] 64-bit integers, channel major: conflict free for distinct slots).  A block of ~500 particles (m = 4) adds
+//     ~130k pairs into ~2000 slots and flushes each touched slot ONCE with a global atomic: ~70 pairs per flushed value.
 //   * sums are FIXED POINT: a contribution c is added as round(c * 2^s) into a 64-bit integer, 2^s = 2^46 / (a power-of-two bound
 //     of |c|: cin max |f| * max |W| >= max_j |f_j|_1 max |W|, formed on the device inside the call).  Integer addition is associative, so LDS
 //     atomics, global atomics and any schedule give THE SAME BITS: the step stays bit reproducible with no ordering, no staging
 //     and no barrier in the pair loop.  Resolution: 2^-46 of the bound per term (terms are float32: 2^-24 of themselves; 2^-30
 //     was tried first and showed in the dam break, where a few splashing particles set a bound a thousand times a typical term).
 //
-// Workgroup = 8 waves; a block's rows go by in chunks of 16: G of the chunk = F[16 x Cin] . W[Cin x 64 Cout] on the matrix cores
-// (the filter stays in registers as B fragments, each wave forms its 16-column tiles), double buffered in LDS, one barrier per
-// chunk; then every wave walks two of the chunk's rows as one stream of 64-pair batches with the indices two batches and the
-// output positions one batch ahead.  2 workgroups per CU at Cout = 4 (LDS: accumulators 42.6 KB + slot -> output index 5.3 KB +
-// G chunks 32 KB).  Per 64-pair batch ~150 vector instructions, all 64 lanes busy (splat F: 64 matrix instructions + ~190 scalar
-// + ~240 vector per batch at two waves per SIMD).
+// Workgroup = 8 or 16 waves (sct_waves: 8 while two workgroups fit a CU's LDS -- block_cells 2 --, else 16 in one -- block_cells 4,
+// the default: a quarter of the flushes).  A block's rows go by in chunks of 16 (32): G of the chunk = F[rows x Cin] . W[Cin x 64 Cout]
+// on the matrix cores (the filter stays in registers as B fragments, each wave forms its 16-column tiles), double buffered in LDS,
+// one barrier per chunk; then every wave walks two of the chunk's rows as one stream of 64-pair batches with the indices two
+// batches and the output positions one batch ahead.  LDS at Cout = 4, block_cells 4: accumulators 70 KB + slot -> output index
+// 8.8 KB + G chunks 64 KB.  Measured (profiles/r06_kernel_pmc.md, case S4): 4.1 vector + 0.7 scalar + 0.26 LDS instructions per pair,
+// VALU active 78 % at 3.75 waves per SIMD (splat F on the same pairs: 4.0 + 2.7 + 0.9 and one matrix instruction per pair, 65 % busy
+// at 1.8 waves).
 //
 // Restrictions (the dispatch in dmcf_amd/utils/convolutions.py checks them, the entry point returns DMCF_EUNSUPPORTED): 4x4x4 filter,
 // Cout 4 or 8, Cin <= 32, linear interpolation, align_corners, volume-preserving map, poly6 or no window (formed from the positions),
