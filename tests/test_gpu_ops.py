@@ -1362,3 +1362,38 @@ def test_scatter_form_matches_the_oracle_and_the_gather_form(oracle, dev, cin, c
     ref0 = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, None, f64=True)
     y0 = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t_idx, t_rb, t_cnt, plan, window=None)
     _close(y0.cpu().numpy(), ref0)
+
+
+def test_scatter_form_with_stray_particles(oracle, dev):
+    """Splat S when a few particles sit far outside the bulk (a splash): they fall outside the plan's 128^3-block region and are
+    walked as one-row blocks of their own (`overflow`); the lattice holds points around them too.  Against the gather form and
+    the oracle; the error flag stays 0."""
+    from dmcf_amd import ops
+    rng = np.random.default_rng(77)
+    side, h, radius, voxel, cin, cout = 14, 0.05, 0.4, 0.1, 24, 4
+    ax = (np.arange(side) + 0.5) * h
+    bulk = np.stack(np.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3) + rng.uniform(-0.005, 0.005, size=(side ** 3, 3))
+    strays = np.array([[60.0, 0.3, 0.2], [60.05, 0.31, 0.22], [-45.0, 2.0, 70.0], [0.3, -90.0, 0.1], [0.35, 0.35, 33.0]])
+    inp = np.concatenate([bulk, strays]).astype(np.float32)
+    feat = np.maximum(rng.normal(size=(inp.shape[0], cin)), 0).astype(np.float32)
+    filt = rng.uniform(-1, 1, size=(4, 4, 4, cin, cout)).astype(np.float32)
+    P, F, W = _t(inp, dev), _t(feat, dev), _t(filt, dev)
+    Q = ops.grid_pos(P, torch.tensor([voxel] * 3), centralize=True)
+    out = Q.cpu().numpy()
+    fwd = ops.fixed_radius_search(P, Q, radius, return_distances=True)
+    idx, rs, d = (x.cpu().numpy() for x in fwd)
+    ref = oracle.continuous_conv(filt, out, 2 * radius, inp, feat, idx, rs, oracle.window("poly6", d / np.float32(radius) ** 2), f64=True)
+    t = ops.fixed_radius_search(Q, P, radius, return_distances=False)
+    for m in (2, 4):
+        plan = ops.scatter_plan(P, Q, voxel, radius, block_cells=m)
+        hdr = plan.buf[:256].view(torch.int32).cpu().numpy()
+        assert hdr[12] >= 4, f"expected overflow rows, header says {hdr[12]}"  # (n_overflow: the strays beyond the region)
+        flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        y = ops.cconv_scatter_forward(W, Q, 2 * radius, P, F, t.neighbors_index, t.neighbors_row_splits, None, plan, window="poly6",
+                                      error_flag=flag)
+        assert int(flag.item()) == 0
+        _close(y.cpu().numpy(), ref)
+        # rows of the lattice points around the strays are not empty and come out right
+        far = np.abs(out).max(axis=1) > 20
+        assert far.sum() > 8 and np.abs(ref[far]).max() > 0
+        assert np.abs(y.cpu().numpy()[far] - ref[far]).max() <= 1e-5 * np.abs(ref).max()
