@@ -27,7 +27,8 @@ def bench_lines(src, tag, P, b, d):
              "| kernel | ms/step | frac | ms/step (driver) | frac (driver) | algorithmic GB / launch | PMC HBM GB / launch |", "|---|---:|---:|---:|---:|---:|---:|"]
     dk = d["roofline_groups"]["by_kernel"]
     for k, v in b["roofline_groups"]["by_kernel"].items():
-        hb = [x for n, x in tb.items() if n.endswith("::" + k) or (k == "lat_conv_kernel" and "lat_conv" in n)]
+        hb = [x for n, x in tb.items() if n.endswith("::" + k) or (k == "lat_conv_kernel" and "lat_conv" in n)
+              or (k.startswith("cconv_sct_kernel<") and n.split("::")[-1].startswith(k[:-1]))]  # (r06's first lines say <4>, rocprof <4, 16>)
         pm = f"{sum(x['hbm_bytes_per_launch'] * x['launches'] for x in hb) / max(sum(x['launches'] for x in hb), 1) / 1e9:.2f}" if hb else ""
         w = dk.get(k, dict(ms_per_step=float('nan'), frac=float('nan')))
         lines.append(f"| `{k}` | {v['ms_per_step']:.2f} | {v['frac']:.3f} | {w['ms_per_step']:.2f} | {w['frac']:.3f} | {v['algorithmic_bytes_per_launch'] / 1e9:.2f} | {pm} |")
